@@ -1,0 +1,94 @@
+"""ORACLE tooling — generates tests/golden/*.npz by running the REAL reference (imported from /root/reference).
+
+Run in the build container only (the reference does not exist on the GPU box):
+    python oracle/gen_golden.py            # pi3 network vectors (needs ~10 GB RAM, ~2 min)
+The reference's pi3 classes are imported unmodified; weights are the recipe weights (pi3_slam_amd/recipe.py) loaded
+through load_state_dict, inputs are recipe streams too, so tests regenerate both and the .npz only carries outputs
+and a few intermediate activations (captured with forward hooks).  The script also runs the oracle restatement
+(oracle/pi3_ref.py) on the same data and prints the differences, which is the "pin" of the oracle.
+"""
+from __future__ import annotations
+
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"
+sys.path.insert(0, REPO)
+
+from pi3_slam_amd.recipe import recipe_unit, fnv1a64  # noqa: E402
+from pi3_slam_amd.weights import Pi3Config, recipe_state_dict_cpu  # noqa: E402
+
+CASES = {
+    # name: (B, N, H, W)
+    "pi3_tiny_a": (1, 3, 28, 42),
+    "pi3_tiny_b": (1, 2, 42, 56),
+}
+
+
+def golden_images(name: str, B: int, N: int, H: int, W: int) -> torch.Tensor:
+    """Deterministic test frames in [0, 1): smooth-ish (low-frequency ramp + recipe noise) so patches differ."""
+    u = recipe_unit(fnv1a64("golden.images." + name), B * N * 3 * H * W).reshape(B, N, 3, H, W)
+    yy = np.linspace(0, 1, H, dtype=np.float32)[None, None, None, :, None]
+    xx = np.linspace(0, 1, W, dtype=np.float32)[None, None, None, None, :]
+    img = 0.5 + 0.25 * (u.astype(np.float32)) + 0.2 * (yy - 0.5) + 0.1 * (xx - 0.5)
+    return torch.from_numpy(np.clip(img, 0.0, 1.0).astype(np.float32))
+
+
+def main() -> None:
+    sys.path.insert(0, REF)
+    from pi3.models.pi3 import Pi3  # the real reference network
+    from oracle import pi3_ref
+
+    cfg = Pi3Config()
+    t0 = time.time()
+    sd = recipe_state_dict_cpu(cfg)
+    print(f"recipe weights: {len(sd)} tensors in {time.time() - t0:.1f}s")
+    model = Pi3().eval()
+    missing, unexpected = model.load_state_dict(sd, strict=False)
+    assert not unexpected and set(missing) <= {"image_mean", "image_std"}, (missing, unexpected)
+
+    out_dir = os.path.join(REPO, "tests", "golden")
+    os.makedirs(out_dir, exist_ok=True)
+    for name, (B, N, H, W) in CASES.items():
+        imgs = golden_images(name, B, N, H, W)
+        cap = {}
+        hooks = [
+            model.encoder.blocks[0].register_forward_pre_hook(lambda m, a: cap.__setitem__("tokens", a[0].detach().clone())),
+            model.decoder[0].register_forward_pre_hook(lambda m, a: cap.__setitem__("enc_out", a[0].detach().clone())),
+            model.decoder[0].register_forward_hook(lambda m, a, o: cap.__setitem__("dec0", o.detach().clone())),
+            model.decoder[1].register_forward_hook(lambda m, a, o: cap.__setitem__("dec1", o.detach().clone())),
+            model.point_decoder.register_forward_pre_hook(lambda m, a: cap.__setitem__("dec_cat", a[0].detach().clone())),
+            model.point_decoder.register_forward_hook(lambda m, a, o: cap.__setitem__("point_decoder", o.detach().clone())),
+            model.conf_decoder.register_forward_hook(lambda m, a, o: cap.__setitem__("conf_decoder", o.detach().clone())),
+            model.camera_decoder.register_forward_hook(lambda m, a, o: cap.__setitem__("camera_decoder", o.detach().clone())),
+        ]
+        t0 = time.time()
+        with torch.no_grad():
+            ref = model(imgs)
+        for h in hooks:
+            h.remove()
+        print(f"{name}: reference forward {time.time() - t0:.1f}s")
+        t0 = time.time()
+        orc = pi3_ref.pi3_forward(sd, imgs, cfg, return_intermediates=True)
+        print(f"{name}: oracle forward {time.time() - t0:.1f}s")
+        save = {"shape": np.array([B, N, H, W])}
+        for k in ("points", "local_points", "conf", "camera_poses"):
+            save[k] = ref[k].numpy()
+            d = (ref[k] - orc[k]).abs().max().item()
+            print(f"   {k:14s} ref-vs-oracle max|d| = {d:.3e}   (ref max {ref[k].abs().max().item():.3f})")
+        for k, v in cap.items():
+            v2 = v.reshape(-1, v.shape[-1])
+            save["i_" + k] = v2.numpy()
+            d = (v2 - orc["_intermediates"][k]).abs().max().item()
+            print(f"   i_{k:12s} ref-vs-oracle max|d| = {d:.3e}   (ref max {v2.abs().max().item():.3f})")
+        np.savez_compressed(os.path.join(out_dir, name + ".npz"), **save)
+        print("   wrote", os.path.join(out_dir, name + ".npz"))
+
+
+if __name__ == "__main__":
+    main()

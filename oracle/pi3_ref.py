@@ -1,0 +1,221 @@
+"""ORACLE — test infrastructure only.  CPU fp32 restatement of the reference pi3 forward pass.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module; the product path
+(pi3_slam_amd/) never does.  Every function cites the reference lines it restates (paths relative to the
+urbste/Pi3_SLAM checkout).  Pinning: oracle/gen_golden.py runs the REAL reference classes (imported from
+/root/reference in the build container) on recipe weights and stores inputs + outputs under tests/golden/;
+tests/test_oracle_golden.py checks this restatement against those vectors (parity pinned for the pi3 network).
+
+Plain torch ops on CPU tensors, no autocast, attention written out as softmax(q k^T / sqrt(d)) v.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional, Tuple
+
+import torch
+import torch.nn.functional as F
+
+EPS = 1e-6
+
+
+def layer_norm(x, w, b, eps=EPS):
+    return F.layer_norm(x, (x.shape[-1],), w, b, eps)
+
+
+def rope2d(tokens: torch.Tensor, positions: torch.Tensor, base: float = 100.0) -> torch.Tensor:
+    """pi3/models/layers/pos_embed.py:112-159 (== pi3/models/curope/curope.cpp:11-47), fp32.
+    tokens (B, h, S, 64), positions (B, S, 2) integer (y, x)."""
+    D = tokens.shape[-1] // 2
+    inv_freq = 1.0 / (base ** (torch.arange(0, D, 2).float() / D))          # pos_embed.py:122
+    npos = int(positions.max()) + 1
+    t = torch.arange(npos, dtype=inv_freq.dtype)
+    freqs = torch.einsum("i,j->ij", t, inv_freq)
+    freqs = torch.cat((freqs, freqs), dim=-1)
+    cos, sin = freqs.cos(), freqs.sin()
+
+    def rot_half(x):
+        x1, x2 = x[..., : x.shape[-1] // 2], x[..., x.shape[-1] // 2:]
+        return torch.cat((-x2, x1), dim=-1)
+
+    def apply1d(tok, pos1d):
+        c = F.embedding(pos1d, cos)[:, None, :, :]
+        s = F.embedding(pos1d, sin)[:, None, :, :]
+        return tok * c + rot_half(tok) * s
+
+    y, x = tokens.chunk(2, dim=-1)
+    y = apply1d(y, positions[:, :, 0])
+    x = apply1d(x, positions[:, :, 1])
+    return torch.cat((y, x), dim=-1)
+
+
+def attention(sd, prefix, x, heads, xpos=None, qk_norm=False, rope_base=100.0):
+    """FlashAttention.forward (pi3/models/layers/attention.py:94-113) / FlashAttentionRope.forward (:323-347)."""
+    B, S, C = x.shape
+    qkv = F.linear(x, sd[f"{prefix}.qkv.weight"], sd[f"{prefix}.qkv.bias"])
+    qkv = qkv.reshape(B, S, 3, heads, C // heads).transpose(1, 3)
+    q, k, v = qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]
+    if qk_norm:  # nn.LayerNorm(head_dim) with the default eps 1e-5 (attention.py:261-262)
+        q = F.layer_norm(q, (q.shape[-1],), sd[f"{prefix}.q_norm.weight"], sd[f"{prefix}.q_norm.bias"], 1e-5)
+        k = F.layer_norm(k, (k.shape[-1],), sd[f"{prefix}.k_norm.weight"], sd[f"{prefix}.k_norm.bias"], 1e-5)
+    if xpos is not None:
+        q = rope2d(q, xpos, rope_base)
+        k = rope2d(k, xpos, rope_base)
+    att = (q @ k.transpose(-1, -2)) * (q.shape[-1] ** -0.5)
+    att = att.softmax(dim=-1)
+    o = (att @ v).transpose(1, 2).reshape(B, S, C)
+    return F.linear(o, sd[f"{prefix}.proj.weight"], sd[f"{prefix}.proj.bias"])
+
+
+def block(sd, prefix, x, heads, xpos=None, qk_norm=False, ls=True, rope_base=100.0):
+    """dinov2 Block.forward (pi3/models/dinov2/layers/block.py:88-113) / BlockRope.forward
+    (pi3/models/layers/block.py:310-335): pre-LN, attention, LayerScale, residual; pre-LN, MLP(GELU erf), LayerScale."""
+    h = attention(sd, f"{prefix}.attn", layer_norm(x, sd[f"{prefix}.norm1.weight"], sd[f"{prefix}.norm1.bias"]),
+                  heads, xpos, qk_norm, rope_base)
+    if ls:
+        h = h * sd[f"{prefix}.ls1.gamma"]
+    x = x + h
+    h = layer_norm(x, sd[f"{prefix}.norm2.weight"], sd[f"{prefix}.norm2.bias"])
+    h = F.linear(h, sd[f"{prefix}.mlp.fc1.weight"], sd[f"{prefix}.mlp.fc1.bias"])
+    h = F.gelu(h)
+    h = F.linear(h, sd[f"{prefix}.mlp.fc2.weight"], sd[f"{prefix}.mlp.fc2.bias"])
+    if ls:
+        h = h * sd[f"{prefix}.ls2.gamma"]
+    return x + h
+
+
+def interpolate_pos_encoding(pos_embed: torch.Tensor, ph: int, pw: int) -> torch.Tensor:
+    """pi3/models/dinov2/models/vision_transformer.py:181-213 with interpolate_offset = 0, antialias = True
+    (dinov2_vitl14_reg, hub/backbones.py:128-140).  Returns (1, 1 + ph*pw, D)."""
+    N = pos_embed.shape[1] - 1
+    M = int(math.sqrt(N))
+    assert N == M * M
+    if ph == M and pw == M:
+        return pos_embed
+    dim = pos_embed.shape[-1]
+    cls = pos_embed[:, 0]
+    patch = pos_embed[:, 1:].reshape(1, M, M, dim).permute(0, 3, 1, 2)
+    patch = F.interpolate(patch, size=(ph, pw), mode="bicubic", antialias=True)
+    patch = patch.permute(0, 2, 3, 1).reshape(1, -1, dim)
+    return torch.cat((cls.unsqueeze(0), patch), dim=1)
+
+
+def prepare_tokens(sd, imgs_norm: torch.Tensor, n_reg: int) -> torch.Tensor:
+    """PatchEmbed.forward (dinov2/layers/patch_embed.py:68-81) + prepare_tokens_with_masks
+    (vision_transformer.py:215-234).  imgs_norm (F, 3, H, W) -> (F, 1 + n_reg + P, D)."""
+    Fr, _, H, W = imgs_norm.shape
+    x = F.conv2d(imgs_norm, sd["encoder.patch_embed.proj.weight"], sd["encoder.patch_embed.proj.bias"], stride=14)
+    x = x.flatten(2).transpose(1, 2)
+    x = torch.cat((sd["encoder.cls_token"].expand(Fr, -1, -1), x), dim=1)
+    x = x + interpolate_pos_encoding(sd["encoder.pos_embed"], H // 14, W // 14)
+    x = torch.cat((x[:, :1], sd["encoder.register_tokens"].expand(Fr, -1, -1), x[:, 1:]), dim=1)
+    return x
+
+
+def svd_orthogonalize(m: torch.Tensor) -> torch.Tensor:
+    """CameraHead.svd_orthogonalize (pi3/models/layers/camera_head.py:74-93)."""
+    m = m.reshape(-1, 3, 3)
+    mt = torch.transpose(F.normalize(m, p=2, dim=-1), -1, -2)
+    u, s, v = torch.svd(mt)
+    det = torch.det(v @ u.transpose(-2, -1))
+    return torch.cat([v[:, :, :-1], v[:, :, -1:] * det.view(-1, 1, 1)], dim=2) @ u.transpose(-2, -1)
+
+
+def camera_head(sd, feat: torch.Tensor) -> torch.Tensor:
+    """CameraHead.forward (camera_head.py:48-72): feat (F, P, C) -> (F, 4, 4)."""
+    for r in range(2):
+        pre = f"camera_head.res_conv.{r}.res_conv"
+        x = F.relu(F.linear(feat, sd[pre + "1.weight"], sd[pre + "1.bias"]))
+        x = F.relu(F.linear(x, sd[pre + "2.weight"], sd[pre + "2.bias"]))
+        x = F.relu(F.linear(x, sd[pre + "3.weight"], sd[pre + "3.bias"]))
+        feat = feat + x
+    v = feat.mean(dim=1)  # AdaptiveAvgPool2d(1) over the patch grid
+    v = F.relu(F.linear(v, sd["camera_head.more_mlps.0.weight"], sd["camera_head.more_mlps.0.bias"]))
+    v = F.relu(F.linear(v, sd["camera_head.more_mlps.2.weight"], sd["camera_head.more_mlps.2.bias"]))
+    t = F.linear(v, sd["camera_head.fc_t.weight"], sd["camera_head.fc_t.bias"])
+    r = F.linear(v, sd["camera_head.fc_rot.weight"], sd["camera_head.fc_rot.bias"])
+    R = svd_orthogonalize(r)
+    pose = torch.zeros(feat.shape[0], 4, 4)
+    pose[:, :3, :3] = R
+    pose[:, :3, 3] = t
+    pose[:, 3, 3] = 1.0
+    return pose
+
+
+def linear_pts3d(sd, prefix: str, tokens: torch.Tensor, H: int, W: int) -> torch.Tensor:
+    """LinearPts3d.forward (pi3/models/layers/transformer_head.py:70-80): (F, P, D) -> (F, H, W, c)."""
+    Fr = tokens.shape[0]
+    feat = F.linear(tokens, sd[f"{prefix}.proj.weight"], sd[f"{prefix}.proj.bias"])
+    feat = feat.transpose(-1, -2).reshape(Fr, -1, H // 14, W // 14)
+    feat = F.pixel_shuffle(feat, 14)
+    return feat.permute(0, 2, 3, 1)
+
+
+@torch.no_grad()
+def pi3_forward(sd: Dict[str, torch.Tensor], imgs: torch.Tensor, cfg, return_intermediates: bool = False):
+    """Pi3.forward (pi3/models/pi3.py:173-216) incl. decode (:132-171) and the three TransformerDecoder heads
+    (transformer_head.py:48-56).  imgs (B, N, 3, H, W) fp32 in [0, 1]; cfg = pi3_slam_amd.weights.Pi3Config."""
+    B, N, _, H, W = imgs.shape
+    heads = cfg.dim // 64
+    mean = torch.tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1)
+    std = torch.tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1)
+    x = (imgs.reshape(B * N, 3, H, W).float() - mean) / std                       # pi3.py:174
+    inter = {}
+    x = prepare_tokens(sd, x, cfg.n_enc_reg)
+    if return_intermediates:
+        inter["tokens"] = x.reshape(-1, cfg.dim).clone()
+    for i in range(cfg.enc_depth):
+        x = block(sd, f"encoder.blocks.{i}", x, heads)
+    x = layer_norm(x, sd["encoder.norm.weight"], sd["encoder.norm.bias"])        # vision_transformer.py:271
+    hidden = x[:, cfg.n_enc_reg + 1:]                                             # x_norm_patchtokens
+    # ---- decode (pi3.py:132-171)
+    ph, pw = H // 14, W // 14
+    reg = sd["register_token"].repeat(B, N, 1, 1).reshape(B * N, cfg.n_dec_reg, cfg.dim)
+    hidden = torch.cat([reg, hidden], dim=1)
+    T = hidden.shape[1]
+    if return_intermediates:
+        inter["enc_out"] = hidden.reshape(-1, cfg.dim).clone()
+    yy, xx = torch.meshgrid(torch.arange(ph), torch.arange(pw), indexing="ij")
+    pos = torch.stack([yy.reshape(-1), xx.reshape(-1)], dim=-1)[None].expand(B * N, -1, 2) + 1
+    pos = torch.cat([torch.zeros(B * N, cfg.n_dec_reg, 2, dtype=pos.dtype), pos], dim=1)
+    outs = []
+    for i in range(cfg.dec_depth):
+        if i % 2 == 0:
+            p_, h_ = pos.reshape(B * N, T, 2), hidden.reshape(B * N, T, -1)
+        else:
+            p_, h_ = pos.reshape(B, N * T, 2), hidden.reshape(B, N * T, -1)
+        hidden = block(sd, f"decoder.{i}", h_, heads, xpos=p_, qk_norm=True, rope_base=cfg.rope_base)
+        if i + 1 in (cfg.dec_depth - 1, cfg.dec_depth):
+            outs.append(hidden.reshape(B * N, T, -1))
+        if return_intermediates and i in (0, 1):
+            inter[f"dec{i}"] = hidden.reshape(-1, cfg.dim).clone()
+    cat = torch.cat(outs, dim=-1)
+    pos = pos.reshape(B * N, T, 2)
+    if return_intermediates:
+        inter["dec_cat"] = cat.reshape(-1, 2 * cfg.dim).clone()
+
+    def head(name):
+        h = F.linear(cat, sd[f"{name}.projects.weight"], sd[f"{name}.projects.bias"])
+        for i in range(cfg.head_depth):
+            h = block(sd, f"{name}.blocks.{i}", h, heads, xpos=pos, qk_norm=False, ls=False,
+                      rope_base=cfg.rope_base)
+        return F.linear(h, sd[f"{name}.linear_out.weight"], sd[f"{name}.linear_out.bias"])
+
+    ph_, ch_, cam_ = head("point_decoder"), head("conf_decoder"), head("camera_decoder")
+    if return_intermediates:
+        inter["point_decoder"] = ph_.reshape(-1, ph_.shape[-1]).clone()
+        inter["conf_decoder"] = ch_.reshape(-1, ch_.shape[-1]).clone()
+        inter["camera_decoder"] = cam_.reshape(-1, cam_.shape[-1]).clone()
+    r = cfg.n_dec_reg
+    ret = linear_pts3d(sd, "point_head", ph_[:, r:], H, W).reshape(B, N, H, W, 3)        # pi3.py:195
+    xy, z = ret.split([2, 1], dim=-1)
+    z = torch.exp(z)
+    local_points = torch.cat([xy * z, z], dim=-1)
+    conf = linear_pts3d(sd, "conf_head", ch_[:, r:], H, W).reshape(B, N, H, W, 1)        # pi3.py:202
+    poses = camera_head(sd, cam_[:, r:]).reshape(B, N, 4, 4)                             # pi3.py:206
+    hom = torch.cat([local_points, torch.ones_like(local_points[..., :1])], dim=-1)      # geometry.py:116-120
+    points = torch.einsum("bnij, bnhwj -> bnhwi", poses, hom)[..., :3]                   # pi3.py:209
+    out = dict(points=points, local_points=local_points, conf=conf, camera_poses=poses)
+    if return_intermediates:
+        out["_intermediates"] = inter
+    return out

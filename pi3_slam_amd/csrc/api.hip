@@ -1,0 +1,38 @@
+// C-ABI plumbing shared by every entry point: error string, launch checking, version.
+// The boundary is declared in include/pi3slam_hip.h; nothing here depends on torch.
+#include "common.h"
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+static thread_local char g_err[512] = "";
+
+void pi3_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+int pi3_check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    pi3_set_error("%s: %s", what, hipGetErrorString(e));
+    return PI3_ERR_LAUNCH;
+  }
+  return PI3_OK;
+}
+
+extern "C" const char* pi3_last_error(void) { return g_err; }
+
+extern "C" int pi3_abi_version(void) { return 1; }
+
+// Number of visible devices (does not create a context); used by the loader to fail loudly on a box without a GPU.
+extern "C" int pi3_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  return n;
+}

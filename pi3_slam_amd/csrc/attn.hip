@@ -1,0 +1,229 @@
+// Streaming-softmax attention forward, head_dim 64, non-causal, bf16 in / bf16 out, fp32 softmax and accumulation.
+//
+// Replaces F.scaled_dot_product_attention in the reference (pi3/models/layers/attention.py:102-107 encoder blocks,
+// :336-341 decoder / head blocks).  The same kernel serves frame attention (batch = frames, S = tokens per frame) and
+// global attention (batch = 1, S = frames * tokens = 64 300 at the north-star config; pi3/models/pi3.py:156-166),
+// which is 70 % of all FLOPs on the path and the roofline-defining kernel.
+//
+// q must arrive PRE-SCALED by head_dim^-0.5 * log2(e) (the producers fold it in before the single bf16 rounding), so
+// the kernel works in the exp2 domain: p = exp2(s - m).
+//
+// gfx950 mapping (one 256-thread workgroup = 4 waves = 128 query rows, one wave = 32 query rows, KV tile = 64 keys):
+//   S^T[key][q] = K . Q^T   : v_mfma_f32_32x32x16_bf16, A = K rows from LDS (ds_read_b128, XOR-swizzled rows),
+//                             B = Q^T held in registers for the whole sweep.  The query index sits on the LANE.
+//   O^T[d][q]  += V^T . P^T : the S^T accumulators, converted to bf16 in place, ARE the B operand (their k order is
+//                             the accumulator row order); A = V^T comes from ds_read_b64_tr_b16 transposed reads in
+//                             exactly that row order.  No cross-lane movement of P, and the query stays on the lane,
+//                             so max / sum / rescale are per-lane scalars (one half-wave exchange for the max).
+//   K/V tiles are register-staged (global_load_dwordx4 issued before the tile's math, ds_write_b128 after it) into a
+//   2-deep LDS ring with one barrier per tile.  The running max is only raised when a tile's max exceeds it by more
+//   than RESCALE_THR (exp2 domain), which removes the O rescale from almost every tile.
+#include "common.h"
+
+struct AttnParams {
+  const bf16_t* q; const bf16_t* k; const bf16_t* v;
+  long tok_stride;    // elements between consecutive tokens in q/k/v
+  long batch_stride;  // elements between consecutive batches in q/k/v
+  bf16_t* o; long o_tok_stride; long o_batch_stride;
+  int S, H, B, nqb;
+};
+
+#define ATT_QB 128
+#define ATT_KT 64
+#define RESCALE_THR 6.0f
+
+__device__ __forceinline__ bf16x8 cat4(bf16x4 a, bf16x4 b) {
+  return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
+  __shared__ __attribute__((aligned(16))) char lds[32768];  // K ring [2][64][128 B] then V ring [2][64][128 B]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+
+  const int nwg = p.nqb * p.H * p.B;
+  const int id = xcd_remap(blockIdx.x, nwg);
+  const int qb = id % p.nqb;
+  const int head = (id / p.nqb) % p.H;
+  const int b = id / (p.nqb * p.H);
+  const int S = p.S;
+
+  const int q0 = qb * ATT_QB + wave * 32;
+  const int qrow = min(q0 + r, S - 1);
+  const bf16_t* qptr = p.q + (long)b * p.batch_stride + (long)qrow * p.tok_stride + head * 64;
+  bf16x8 qf[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) qf[s] = *(const bf16x8*)(qptr + 16 * s + 8 * h);
+
+  f32x16 o[2];
+  o[0] = (f32x16)(0.f);
+  o[1] = (f32x16)(0.f);
+  float m = -INFINITY, l = 0.f;
+
+  const int nt = (S + ATT_KT - 1) / ATT_KT;
+  const bf16_t* kbase = p.k + (long)b * p.batch_stride + head * 64;
+  const bf16_t* vbase = p.v + (long)b * p.batch_stride + head * 64;
+
+  // staging map: 512 16-byte chunks per tile, two per thread
+  int srow[2], sch[2], kw[2], vw[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int cid = tid + 256 * i;
+    srow[i] = cid >> 3;
+    sch[i] = cid & 7;
+    kw[i] = srow[i] * 128 + ((sch[i] ^ ((srow[i] >> 1) & 7)) << 4);
+    vw[i] = 16384 + srow[i] * 128 + ((sch[i] ^ (((srow[i] >> 1) & 1) << 2)) << 4);
+  }
+  u32x4 kr[2], vr[2];
+#define ATT_LOAD(T)                                                      \
+  _Pragma("unroll") for (int i = 0; i < 2; ++i) {                         \
+    int grow = (T) * ATT_KT + srow[i];                                   \
+    grow = grow < S ? grow : S - 1;                                      \
+    kr[i] = *(const u32x4*)(kbase + (long)grow * p.tok_stride + sch[i] * 8); \
+    vr[i] = *(const u32x4*)(vbase + (long)grow * p.tok_stride + sch[i] * 8); \
+  }
+#define ATT_WRITE(BUF)                                   \
+  _Pragma("unroll") for (int i = 0; i < 2; ++i) {         \
+    *(u32x4*)(lds + (BUF) * 8192 + kw[i]) = kr[i];       \
+    *(u32x4*)(lds + (BUF) * 8192 + vw[i]) = vr[i];       \
+  }
+
+  ATT_LOAD(0)
+  ATT_WRITE(0)
+  __syncthreads();
+
+  // fragment read addresses (per lane, tile-invariant)
+  // K rows: row = 32*kt + r, chunk = 2*s + h, swizzle ((row >> 1) & 7) == ((r >> 1) & 7)
+  const int kswz = (r >> 1) & 7;
+  const int krow_off = r * 128;
+  // V transposed reads: 16-lane group g = lane >> 4, i = lane & 15: row = R0 + (i >> 2), cols c0 + 4*(i & 3),
+  // c0 = 32*dt + 16*(g & 1);  R0 = 32*kt + 16*s2 + 4*h (+8 for elements 4..7)
+  const int gi = lane & 15, gg = (lane >> 4) & 1;
+  const int vrow_l = 4 * h + (gi >> 2);            // row inside the 16-row k-step (second read adds 8)
+  const int vcol_l = 16 * gg + 4 * (gi & 3);       // column inside the 32-wide d tile
+  const int vch_l = vcol_l >> 3;                   // 16-byte chunk (0..3) inside the d tile
+  const int vin_l = (vcol_l & 7) * 2;              // byte inside the chunk (0 or 8)
+  const int vswz = ((vrow_l >> 1) & 1) << 2;       // rows R0+q: bit 1 of the row; 32kt+16s2(+8) never touch bit 1
+
+  for (int t = 0; t < nt; ++t) {
+    const int buf = t & 1;
+    if (t + 1 < nt) { ATT_LOAD(t + 1) }
+
+    // ---- S^T = K . Q^T
+    f32x16 sc[2];
+    sc[0] = (f32x16)(0.f);
+    sc[1] = (f32x16)(0.f);
+    const char* kl = lds + buf * 8192 + krow_off;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int off = ((2 * s + h) ^ kswz) << 4;
+      const bf16x8 a0 = *(const bf16x8*)(kl + off);
+      const bf16x8 a1 = *(const bf16x8*)(kl + 32 * 128 + off);
+      sc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, qf[s], sc[0], 0, 0, 0);
+      sc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, qf[s], sc[1], 0, 0, 0);
+    }
+    if (t == nt - 1 && (S & (ATT_KT - 1))) {
+      const int kb = t * ATT_KT + 4 * h;
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int key = kb + 32 * kt + (i & 3) + 8 * (i >> 2);
+          if (key >= S) sc[kt][i] = -INFINITY;
+        }
+    }
+
+    // ---- online softmax (query on the lane; the other half-wave holds the other 32 keys of the same query)
+    float tmax = sc[0][0];
+#pragma unroll
+    for (int i = 1; i < 16; ++i) tmax = fmaxf(tmax, sc[0][i]);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) tmax = fmaxf(tmax, sc[1][i]);
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+    if (!__all(tmax <= m + RESCALE_THR)) {
+      const float mn = fmaxf(m, tmax);
+      const float alpha = __builtin_amdgcn_exp2f(m - mn);
+      l *= alpha;
+      o[0] *= alpha;
+      o[1] *= alpha;
+      m = mn;
+    }
+    bf16x8 pf[2][2];
+    float psum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float pv = __builtin_amdgcn_exp2f(sc[kt][8 * s2 + j] - m);
+          psum += pv;
+          pf[kt][s2][j] = (bf16_t)pv;
+        }
+    l += psum;
+
+    // ---- O^T += V^T . P^T
+    const char* vl = lds + 16384 + buf * 8192;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const int row0 = 32 * kt + 16 * s2 + vrow_l;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          const int ch = (4 * dt + vch_l) ^ vswz;
+          const char* a = vl + row0 * 128 + (ch << 4) + vin_l;
+          const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+              (__attribute__((address_space(3))) bf16x4*)LDS_PTR(a));
+          const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+              (__attribute__((address_space(3))) bf16x4*)LDS_PTR(a + 8 * 128));
+          o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cat4(lo, hi), pf[kt][s2], o[dt], 0, 0, 0);
+        }
+      }
+
+    if (t + 1 < nt) { ATT_WRITE(buf ^ 1) }
+    __syncthreads();
+  }
+
+  // ---- finalize: O[q][d] = O^T[d][q] / l
+  const float lt = l + __shfl_xor(l, 32, 64);
+  const float inv = 1.0f / lt;
+  if (q0 + r < S) {
+    bf16_t* optr = p.o + (long)b * p.o_batch_stride + (long)(q0 + r) * p.o_tok_stride + head * 64;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        u32x2 w;
+        w[0] = pack_bf16x2(o[dt][4 * g + 0] * inv, o[dt][4 * g + 1] * inv);
+        w[1] = pack_bf16x2(o[dt][4 * g + 2] * inv, o[dt][4 * g + 3] * inv);
+        *(u32x2*)(optr + 32 * dt + 8 * g + 4 * h) = w;
+      }
+  }
+}
+
+extern "C" int pi3_attention(const void* q, const void* k, const void* v, long tok_stride, long batch_stride,
+                             void* o, long o_tok_stride, long o_batch_stride, int B, int S, int H, int head_dim,
+                             void* stream) {
+  if (!q || !k || !v || !o || B <= 0 || S <= 0 || H <= 0 || head_dim != 64) {
+    pi3_set_error("pi3_attention: bad arguments B=%d S=%d H=%d head_dim=%d (head_dim must be 64)", B, S, H, head_dim);
+    return PI3_ERR_ARG;
+  }
+  if ((tok_stride % 8) || (batch_stride % 8) || (o_tok_stride % 4) || ((uintptr_t)q & 15) || ((uintptr_t)k & 15) ||
+      ((uintptr_t)v & 15) || ((uintptr_t)o & 7)) {
+    pi3_set_error("pi3_attention: q/k/v must be 16-byte aligned with strides that are multiples of 8 elements");
+    return PI3_ERR_ARG;
+  }
+  AttnParams p;
+  p.q = (const bf16_t*)q; p.k = (const bf16_t*)k; p.v = (const bf16_t*)v;
+  p.tok_stride = tok_stride; p.batch_stride = batch_stride;
+  p.o = (bf16_t*)o; p.o_tok_stride = o_tok_stride; p.o_batch_stride = o_batch_stride;
+  p.S = S; p.H = H; p.B = B; p.nqb = (S + ATT_QB - 1) / ATT_QB;
+  const long nwg = (long)p.nqb * H * B;
+  if (nwg > 0x7fffffffL) {
+    pi3_set_error("pi3_attention: grid too large");
+    return PI3_ERR_ARG;
+  }
+  hipLaunchKernelGGL(attn_fwd_kernel, dim3((unsigned)nwg), dim3(256), 0, (hipStream_t)stream, p);
+  return pi3_check_launch("attn_fwd");
+}

@@ -1,0 +1,70 @@
+// Shared device helpers for the gfx950 (MI355X / CDNA4) kernels of the Pi3-SLAM hot path.
+// Wave width is 64 everywhere; nothing in here is portable to 32-wide hardware and nothing tries to be.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __bf16 bf16_t;
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+#define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+#define GLB_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
+
+// error codes returned through the C-ABI (include/pi3slam_hip.h)
+enum {
+  PI3_OK = 0,
+  PI3_ERR_ARG = -1,      // bad shape / null pointer / unsupported size
+  PI3_ERR_LAUNCH = -2,   // hipLaunch / runtime error (see pi3_last_error)
+  PI3_ERR_WORKSPACE = -3 // caller workspace too small
+};
+
+void pi3_set_error(const char* fmt, ...);
+int pi3_check_launch(const char* what);
+
+__device__ __forceinline__ float bf16_bits_to_f32(uint16_t b) {
+  return __uint_as_float(((uint32_t)b) << 16);
+}
+
+// fp32 -> bf16 round-to-nearest-even through the compiler's cast (v_cvt_pk_bf16_f32 on gfx950; keeps NaN a NaN).
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+  bf16x2 v;
+  v[0] = (bf16_t)lo;
+  v[1] = (bf16_t)hi;
+  return __builtin_bit_cast(uint32_t, v);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// Bijective XCD-aware remap (8 XCDs, blocks dealt round-robin): consecutive logical ids land on one XCD so
+// neighbouring tiles share that XCD's L2. Speed only; correctness never depends on placement.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7;
+  const int xcd = bid & 7, idx = bid >> 3;
+  const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + idx;
+}
+
+__device__ __forceinline__ float gelu_erf(float x) {
+  return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+}

@@ -1,0 +1,236 @@
+// C[M][N] = act(A[M][K] . W[N][K]^T + bias) with fused LayerScale / residual / table-add epilogues.
+//
+// This is the Linear layer of every transformer block on the path (reference: torch.nn.Linear inside
+// pi3/models/layers/block.py:310-335, pi3/models/dinov2/layers/mlp.py:34-40, pi3/models/layers/attention.py:325,345,
+// pi3/models/layers/transformer_head.py:49,55,74, pi3/models/layers/camera_head.py:26-31).  Weights stay in the
+// PyTorch [out][in] layout, so both operands are K-contiguous and feed MFMA fragments straight from 128-byte LDS rows.
+//
+// gfx950 design: 128x128 output tile per 256-thread workgroup (4 waves, 2x2, 64x64 each = 4x4 MFMA 16x16 tiles),
+// K-step = one 128-byte row per operand row (64 bf16 / 32 f32), double-buffered LDS filled by global_load_lds dwordx4
+// (lane-linear LDS image; the bank swizzle goes on the SOURCE address and on the fragment read).  MFMA operands are
+// swapped (A-operand = weight rows, B-operand = activation rows) so that each lane ends up with 4 consecutive output
+// columns of one output row: 8/16-byte stores and float4 bias loads in the epilogue.
+// The f32 variant uses v_mfma_f32_16x16x4_f32 (exact fp32, runs at the vector rate) for the heads the reference
+// computes with autocast disabled (pi3/models/pi3.py:192-209).
+#include "common.h"
+
+struct GemmParams {
+  const void* A; long lda;   // [M][K], element stride
+  const void* W; long ldw;   // [N][K]
+  int M, N, K;
+  const float* bias;         // [N] or null
+  const float* gamma;        // [N] or null  (LayerScale)
+  const float* resid; long ldr;  // fp32 [*][ldr] residual source (indexed by the remapped row) or null
+  void* out; long ldo;       // bf16 or f32
+  int rpg, gstride, goff;    // row remap: orow = (m / rpg) * gstride + goff + (m % rpg); rpg == 0 -> orow = m
+  const float* addtab; long ldadd;  // optional f32 table [rpg][ldadd], row (m % rpg), added after everything else
+  float qscale; int qcols;   // columns n < qcols are multiplied by qscale (softmax scale folded into q)
+};
+
+#define BM 128
+#define BN 128
+#define TILE_BYTES (128 * 128)
+
+template <int ESZ>
+__device__ __forceinline__ void stage_tile(const char* gbase, long ld_bytes, int row0, int rows, long k0_bytes,
+                                           char* lds_tile, int wave, int lane) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int seg = wave * 4 + i;           // 1 KiB segment = 8 rows of 128 B
+    const int row = seg * 8 + (lane >> 3);  // tile row 0..127
+    const int pos = lane & 7;               // 16-byte slot inside the LDS row
+    const int c = pos ^ ((row >> 1) & 7);   // source chunk that must land in this slot
+    int grow = row0 + row;
+    grow = grow < rows ? grow : rows - 1;   // clamp: tail rows re-read the last valid row, results are discarded
+    const char* src = gbase + (long)grow * ld_bytes + k0_bytes + c * 16;
+    __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(lds_tile + seg * 1024), 16, 0, 0);
+  }
+}
+
+template <bool IS_BF16, bool OUT_BF16, int ACT>
+__global__ __launch_bounds__(256) void gemm_tn_kernel(GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wn = wave & 1, wm = wave >> 1;
+  constexpr int ESZ = IS_BF16 ? 2 : 4;
+  constexpr int BK = 128 / ESZ;
+
+  const int nbm = (p.M + BM - 1) / BM, nbn = p.N / BN;
+  const int nwg = nbm * nbn;
+  int id = xcd_remap(blockIdx.x, nwg);
+  // groups of 8 row panels sweep the weight tiles together: the group's A panels + the current W tiles stay in L2
+  constexpr int GM = 8;
+  const int per_group = GM * nbn;
+  const int g = id / per_group;
+  const int gm = min(GM, nbm - g * GM);
+  const int rem = id - g * per_group;
+  const int bm = g * GM + rem % gm;
+  const int bn = rem / gm;
+
+  const char* Ab = (const char*)p.A;
+  const char* Wb = (const char*)p.W;
+  const long lda_b = p.lda * ESZ, ldw_b = p.ldw * ESZ;
+  const int nk = p.K / BK;
+
+  // LDS ring: buffer b holds the A tile at b * 2 * TILE_BYTES and the W tile right after it
+#define LDS_A(b) (smem + (b) * 2 * TILE_BYTES)
+#define LDS_W(b) (smem + (b) * 2 * TILE_BYTES + TILE_BYTES)
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  stage_tile<ESZ>(Ab, lda_b, bm * BM, p.M, 0, LDS_A(0), wave, lane);
+  stage_tile<ESZ>(Wb, ldw_b, bn * BN, p.N, 0, LDS_W(0), wave, lane);
+  __syncthreads();  // drains the LDS-DMA (vmcnt(0)) and publishes the tile
+
+  const int frow = lane & 15;
+  const int swz = (lane >> 1) & 7;  // == ((row >> 1) & 7) for row = 16*i + (lane & 15)
+  const int cq = lane >> 4;
+
+  int cur = 0;
+  for (int t = 0; t < nk; ++t) {
+    if (t + 1 < nk) {
+      stage_tile<ESZ>(Ab, lda_b, bm * BM, p.M, (long)(t + 1) * 128, LDS_A(cur ^ 1), wave, lane);
+      stage_tile<ESZ>(Wb, ldw_b, bn * BN, p.N, (long)(t + 1) * 128, LDS_W(cur ^ 1), wave, lane);
+    }
+    const char* la = LDS_A(cur) + (wm * 64 + frow) * 128;
+    const char* lw = LDS_W(cur) + (wn * 64 + frow) * 128;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const int off = ((cq + 4 * kk) ^ swz) << 4;
+      if constexpr (IS_BF16) {
+        bf16x8 fa[4], fw[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          fa[i] = *(const bf16x8*)(la + i * 16 * 128 + off);
+          fw[i] = *(const bf16x8*)(lw + i * 16 * 128 + off);
+        }
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+          for (int mi = 0; mi < 4; ++mi)
+            acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[ni], fa[mi], acc[ni][mi], 0, 0, 0);
+      } else {
+        f32x4 fa[4], fw[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          fa[i] = *(const f32x4*)(la + i * 16 * 128 + off);
+          fw[i] = *(const f32x4*)(lw + i * 16 * 128 + off);
+        }
+        // lane group q of k-step s supplies k = 4*chunk + s for BOTH operands: a consistent k permutation
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+          for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+              acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x4f32(fw[ni][s], fa[mi][s], acc[ni][mi], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  // ---- epilogue: lane holds rows n = nb + 4*(lane>>4) + r (r = 0..3) of column m = mb + (lane & 15)
+  const int nq = (lane >> 4) * 4;
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi) {
+    const int m = bm * BM + wm * 64 + mi * 16 + frow;
+    if (m >= p.M) continue;
+    long orow = m;
+    int trow = 0;
+    if (p.rpg > 0) {
+      const int gq = m / p.rpg;
+      trow = m - gq * p.rpg;
+      orow = (long)gq * p.gstride + p.goff + trow;
+    }
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+      const int n0 = bn * BN + wn * 64 + ni * 16 + nq;
+      f32x4 v = acc[ni][mi];
+      if (p.bias) {
+        const f32x4 b = *(const f32x4*)(p.bias + n0);
+        v += b;
+      }
+      if (n0 < p.qcols) v *= p.qscale;
+      if constexpr (ACT == 1) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+      } else if constexpr (ACT == 2) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+      }
+      if (p.gamma) {
+        const f32x4 gmm = *(const f32x4*)(p.gamma + n0);
+        v *= gmm;
+      }
+      if (p.resid) {
+        const f32x4 rr = *(const f32x4*)(p.resid + orow * p.ldr + n0);
+        v += rr;
+      }
+      if (p.addtab) {
+        const f32x4 tt = *(const f32x4*)(p.addtab + (long)trow * p.ldadd + n0);
+        v += tt;
+      }
+      if constexpr (OUT_BF16) {
+        u32x2 o;
+        o[0] = pack_bf16x2(v[0], v[1]);
+        o[1] = pack_bf16x2(v[2], v[3]);
+        *(u32x2*)((bf16_t*)p.out + orow * p.ldo + n0) = o;
+      } else {
+        *(f32x4*)((float*)p.out + orow * p.ldo + n0) = v;
+      }
+    }
+  }
+}
+
+template <bool IS_BF16, bool OUT_BF16, int ACT>
+static int launch_gemm(const GemmParams& p, hipStream_t stream) {
+  const int nbm = (p.M + BM - 1) / BM, nbn = p.N / BN;
+  auto kern = gemm_tn_kernel<IS_BF16, OUT_BF16, ACT>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(nbm * nbn), dim3(256), 4 * TILE_BYTES, stream, p);
+  return pi3_check_launch("gemm_tn");
+}
+
+// in_dtype: 0 = bf16 operands, 1 = f32 operands.  out_dtype: 0 = bf16, 1 = f32.  act: 0 none, 1 GELU(erf), 2 ReLU.
+extern "C" int pi3_gemm(const void* A, long lda, const void* W, long ldw, int M, int N, int K, int in_dtype,
+                        const float* bias, const float* gamma, const float* resid, long ldr, void* out, long ldo,
+                        int out_dtype, int act, int rpg, int gstride, int goff, const float* addtab, long ldadd,
+                        float qscale, int qcols, void* stream) {
+  const int bk = in_dtype == 0 ? 64 : 32;
+  if (!A || !W || !out || M <= 0 || N <= 0 || K <= 0 || (N % BN) != 0 || (K % bk) != 0 || act < 0 || act > 2) {
+    pi3_set_error("pi3_gemm: bad arguments M=%d N=%d K=%d (N %% 128 == 0, K %% %d == 0 required)", M, N, K, bk);
+    return PI3_ERR_ARG;
+  }
+  if ((lda * (in_dtype == 0 ? 2 : 4)) % 16 || (ldw * (in_dtype == 0 ? 2 : 4)) % 16 || ((uintptr_t)A & 15) ||
+      ((uintptr_t)W & 15) || ((uintptr_t)out & 15) || (ldo % 4)) {
+    pi3_set_error("pi3_gemm: operands must be 16-byte aligned with 16-byte-multiple row strides");
+    return PI3_ERR_ARG;
+  }
+  GemmParams p;
+  p.A = A; p.lda = lda; p.W = W; p.ldw = ldw; p.M = M; p.N = N; p.K = K;
+  p.bias = bias; p.gamma = gamma; p.resid = resid; p.ldr = ldr; p.out = out; p.ldo = ldo;
+  p.rpg = rpg; p.gstride = gstride; p.goff = goff; p.addtab = addtab; p.ldadd = ldadd;
+  p.qscale = qscale; p.qcols = qcols;
+  hipStream_t s = (hipStream_t)stream;
+#define GEMM_CASE(INB, OUTB, ACTV) \
+  if ((in_dtype == 0) == INB && (out_dtype == 0) == OUTB && act == ACTV) return launch_gemm<INB, OUTB, ACTV>(p, s);
+  GEMM_CASE(true, true, 0)
+  GEMM_CASE(true, true, 1)
+  GEMM_CASE(true, false, 0)
+  GEMM_CASE(true, false, 2)
+  GEMM_CASE(false, false, 0)
+  GEMM_CASE(false, false, 2)
+  GEMM_CASE(false, true, 0)
+#undef GEMM_CASE
+  pi3_set_error("pi3_gemm: unsupported (in_dtype=%d,out_dtype=%d,act=%d) combination", in_dtype, out_dtype, act);
+  return PI3_ERR_ARG;
+}

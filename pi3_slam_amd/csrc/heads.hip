@@ -1,0 +1,133 @@
+// Output heads of the pi3 network after the fp32 head GEMMs: unpatchify + exp/xy*z + pose transform, and the
+// camera-head tail (token mean, MLP, fc_t / fc_rot, SO(3) projection).
+#include "common.h"
+#include "rot3.h"
+
+// ---------------------------------------------------------------------------------------------------------------
+// pfeat [F*P][ldp] fp32 = LinearPts3d.proj output for the point head (588 used columns), cfeat [F*P][ldc] for the
+// conf head (196 used columns).  transformer_head.py:70-80: transpose -> view(B, c*196, h, w) -> pixel_shuffle(14)
+// -> permute  ==>  out[f, y, x, c] = feat[f*P + (y/14)*pw + x/14][c*196 + (y%14)*14 + x%14]   (SURVEY.md §8 a7).
+// pi3.py:195-198: z = exp(z); local = (x*z, y*z, z).  pi3.py:209: points = (pose @ [local, 1])[:3].
+// One thread per pixel; 12-byte-per-pixel outputs are written by consecutive lanes -> coalesced.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void unpatchify_points_kernel(const float* __restrict__ pfeat, long ldp,
+                                                                const float* __restrict__ cfeat, long ldc,
+                                                                const float* __restrict__ poses, int F, int H, int W,
+                                                                int T, int tok_off, float* __restrict__ local_points,
+                                                                float* __restrict__ points, float* __restrict__ conf) {
+  const long npix = (long)F * H * W;
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= npix) return;
+  const int x = (int)(i % W);
+  const long fy = i / W;
+  const int y = (int)(fy % H);
+  const int f = (int)(fy / H);
+  const int pw = W / 14;
+  const int py = y / 14, px = x / 14;
+  const int sub = (y - py * 14) * 14 + (x - px * 14);
+  const long tok = (long)f * T + tok_off + py * pw + px;
+  const float* pr = pfeat + tok * ldp + sub;
+  const float vx = pr[0], vy = pr[196], vz = pr[392];
+  const float z = expf(vz);
+  const float lx = vx * z, ly = vy * z;
+  local_points[3 * i + 0] = lx;
+  local_points[3 * i + 1] = ly;
+  local_points[3 * i + 2] = z;
+  conf[i] = cfeat[tok * ldc + sub];
+  const float* Tm = poses + (long)f * 16;
+#pragma unroll
+  for (int r = 0; r < 3; ++r) points[3 * i + r] = ((Tm[4 * r] * lx + Tm[4 * r + 1] * ly) + Tm[4 * r + 2] * z) + Tm[4 * r + 3];
+}
+
+// Feature rows are addressed as f*T + tok_off + patch, so the head GEMMs may run over all T tokens of a frame
+// (tok_off = 5 skips the register tokens, pi3.py:195 `[:, self.patch_start_idx:]`) or over patch rows only (T = P).
+extern "C" int pi3_unpatchify_points(const float* pfeat, long ldp, const float* cfeat, long ldc, const float* poses,
+                                     int F, int H, int W, int T, int tok_off, float* local_points, float* points,
+                                     float* conf, void* stream) {
+  if (!pfeat || !cfeat || !poses || !local_points || !points || !conf || F <= 0 || H <= 0 || W <= 0 || (H % 14) ||
+      (W % 14) || ldp < 588 || ldc < 196 || tok_off < 0 || T < tok_off + (H / 14) * (W / 14)) {
+    pi3_set_error("pi3_unpatchify_points: bad arguments F=%d H=%d W=%d", F, H, W);
+    return PI3_ERR_ARG;
+  }
+  const long npix = (long)F * H * W;
+  hipLaunchKernelGGL(unpatchify_points_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, pfeat, ldp, cfeat, ldc, poses, F, H, W, T, tok_off, local_points, points, conf);
+  return pi3_check_launch("unpatchify_points");
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Camera-head tail (camera_head.py:55-72): feat [F*P][ld] fp32 is the output of the two ResConvBlocks (run as fp32
+// GEMMs).  Per frame: mean over the P patch tokens (AdaptiveAvgPool2d(1)), two Linear+ReLU (D x D), fc_t (3 x D),
+// fc_rot (9 x D), rows of the 3x3 normalised (F.normalize, eps 1e-12), SO(3) projection (rot3.h), 4x4 pose.
+// One 256-thread workgroup per frame; a wave computes one output neuron at a time (coalesced weight rows).
+// ---------------------------------------------------------------------------------------------------------------
+#define CAM_MAXD 1024
+__device__ __forceinline__ void cam_linear(const float* __restrict__ Wt, const float* __restrict__ bias,
+                                           const float* vin, float* vout, int nout, int D, bool relu, int wave,
+                                           int lane) {
+  for (int j = wave; j < nout; j += 4) {
+    const float* wr = Wt + (long)j * D;
+    float acc = 0.f;
+    for (int k = lane; k < D; k += 64) acc += wr[k] * vin[k];
+    acc = wave_sum(acc);
+    if (lane == 0) {
+      float v = acc + bias[j];
+      vout[j] = relu ? fmaxf(v, 0.f) : v;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void camera_tail_kernel(const float* __restrict__ feat, long ld, long fstride,
+                                                          int P, int D,
+                                                          const float* w1, const float* b1, const float* w2,
+                                                          const float* b2, const float* wt, const float* bt,
+                                                          const float* wr, const float* br, float* __restrict__ poses) {
+  __shared__ float va[CAM_MAXD], vb[CAM_MAXD], tr[12];
+  const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int c = tid; c < D; c += 256) {
+    float acc = 0.f;
+    const float* col = feat + (long)f * fstride + c;
+    for (int p = 0; p < P; ++p) acc += col[(long)p * ld];
+    va[c] = acc / (float)P;
+  }
+  __syncthreads();
+  cam_linear(w1, b1, va, vb, D, D, true, wave, lane);
+  __syncthreads();
+  cam_linear(w2, b2, vb, va, D, D, true, wave, lane);
+  __syncthreads();
+  cam_linear(wt, bt, va, tr, 3, D, false, wave, lane);
+  cam_linear(wr, br, va, tr + 3, 9, D, false, wave, lane);
+  __syncthreads();
+  if (tid == 0) {
+    double A[9], R[9];
+    for (int r = 0; r < 3; ++r) {
+      const float a = tr[3 + 3 * r], b = tr[4 + 3 * r], c = tr[5 + 3 * r];
+      const float nrm = fmaxf(sqrtf(a * a + b * b + c * c), 1e-12f);
+      A[3 * r] = a / nrm;
+      A[3 * r + 1] = b / nrm;
+      A[3 * r + 2] = c / nrm;
+    }
+    nearest_rotation_d(A, R);
+    float* T = poses + (long)f * 16;
+    for (int r = 0; r < 3; ++r) {
+      for (int c = 0; c < 3; ++c) T[4 * r + c] = (float)R[3 * r + c];
+      T[4 * r + 3] = tr[r];
+    }
+    T[12] = 0.f; T[13] = 0.f; T[14] = 0.f; T[15] = 1.f;
+  }
+}
+
+// feat points at the first PATCH token of frame 0; fstride = elements between frames (T * ld when registers are kept).
+extern "C" int pi3_camera_tail(const float* feat, long ld, long fstride, int F, int P, int D, const float* w1,
+                               const float* b1,
+                               const float* w2, const float* b2, const float* wt, const float* bt, const float* wr,
+                               const float* br, float* poses, void* stream) {
+  if (!feat || !w1 || !b1 || !w2 || !b2 || !wt || !bt || !wr || !br || !poses || F <= 0 || P <= 0 || D <= 0 ||
+      D > CAM_MAXD) {
+    pi3_set_error("pi3_camera_tail: bad arguments F=%d P=%d D=%d (D <= %d)", F, P, D, CAM_MAXD);
+    return PI3_ERR_ARG;
+  }
+  hipLaunchKernelGGL(camera_tail_kernel, dim3(F), dim3(256), 0, (hipStream_t)stream, feat, ld, fstride, P, D, w1, b1,
+                     w2, b2, wt, bt, wr, br, poses);
+  return pi3_check_launch("camera_tail");
+}

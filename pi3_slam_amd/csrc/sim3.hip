@@ -1,0 +1,310 @@
+// Overlap-based Sim(3) chunk alignment: steps 1-3 of align_and_refine_reconstructions
+// (utils/reconstruction_alignment.py:74-105) as wavefront-reduction kernels, fp64 accumulation.
+//
+//   1. common tracks      FindCommonTracksByFeatureInReconstructions (:74): a track pair = the same keypoint pixel in
+//                         the same image seen from both chunks' overlap views (view pairs from
+//                         create_view_graph_matches :16-37)  ->  pi3_sim3_match_keypoints (integer, bit-exact)
+//   2. near-half filter   keep pairs whose ref point is closer to the LAST ref camera than the median distance,
+//                         strict '<', np.median semantics (:78-86)
+//   3. closed form Sim(3) OptimizeAlignmentSim3(points_qry, points_ref, perform_optimization=False) (:89-97): the
+//                         Umeyama (1991) similarity qry -> ref;  Sim3d.exp(params).matrix() (:104) is its 4x4
+//   4. apply              TransformReconstruction4 (:105): X' = s R X + t, camera centre likewise, R_cw' = R R_cw
+// The arithmetic of steps 1, 3, 4 lives in pytheia 0.2.9 (C++, not vendored, not installable offline): it is restated
+// from the published algorithm and the reference's call sites (parity unpinned for this stage).
+// Inputs are exactly what a chunk file stores: fp16 keypoints / points (offline_chunk_creator.py:231-241), fp32 poses.
+#include "common.h"
+#include "rot3.h"
+#include <hip/hip_fp16.h>
+
+// ---- 1. keypoint matching: for overlap pair v and qry keypoint j, index of the ref keypoint with identical (x, y)
+// bits in ref overlap frame v, or -1.  kp_* : [ov][K][2] fp16.
+__global__ __launch_bounds__(256) void match_keypoints_kernel(const uint32_t* __restrict__ kp_ref,
+                                                              const uint32_t* __restrict__ kp_qry, int ov, int K,
+                                                              int* __restrict__ idx) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= ov * K) return;
+  const int v = i / K;
+  const uint32_t q = kp_qry[i];
+  int found = -1;
+  // fast path: identical grids in identical order
+  if (kp_ref[i] == q) found = i - v * K;
+  else
+    for (int j = 0; j < K; ++j)
+      if (kp_ref[v * K + j] == q) { found = j; break; }
+  idx[i] = found;
+}
+
+extern "C" int pi3_sim3_match_keypoints(const void* kp_ref, const void* kp_qry, int ov, int K, int* idx,
+                                        void* stream) {
+  if (!kp_ref || !kp_qry || !idx || ov <= 0 || K <= 0) {
+    pi3_set_error("pi3_sim3_match_keypoints: bad arguments");
+    return PI3_ERR_ARG;
+  }
+  hipLaunchKernelGGL(match_keypoints_kernel, dim3((ov * K + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                     (const uint32_t*)kp_ref, (const uint32_t*)kp_qry, ov, K, idx);
+  return pi3_check_launch("sim3_match_keypoints");
+}
+
+// ---- 2 + 3. filter + Umeyama, one 1024-thread workgroup (M = ov*K <= ~8 k pairs: latency-bound by design)
+__device__ __forceinline__ double block_sum(double v, double* red, int tid) {
+  v = wave_sum_f64(v);
+  __syncthreads();
+  if ((tid & 63) == 0) red[tid >> 6] = v;
+  __syncthreads();
+  double s = 0.0;
+  for (int w = 0; w < 16; ++w) s += red[w];
+  return s;
+}
+
+struct PairSrc {
+  const __half* pts_ref;  // [ov][K][3]
+  const __half* pts_qry;  // [ov][K][3]
+  const int* idx;         // [ov][K] ref keypoint index per qry keypoint or -1
+  const uint8_t* w_ref;   // optional validity [ov][K] (e.g. masks) or null
+  const uint8_t* w_qry;
+  int ov, K;
+};
+
+__device__ __forceinline__ bool pair_get(const PairSrc& s, int i, double x[3], double y[3]) {
+  const int j = s.idx[i];
+  if (j < 0) return false;
+  const int v = i / s.K;
+  const int r = v * s.K + j;
+  if (s.w_qry && !s.w_qry[i]) return false;
+  if (s.w_ref && !s.w_ref[r]) return false;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    x[c] = (double)__half2float(s.pts_qry[3 * i + c]);
+    y[c] = (double)__half2float(s.pts_ref[3 * r + c]);
+  }
+  return true;
+}
+
+// k-th smallest (0-based) of the non-negative doubles dist(i), by 8-pass radix select on their bit patterns
+__device__ double select_rank(const PairSrc& s, const double cam[3], int M, unsigned k, unsigned* hist,
+                              unsigned long long* s_prefix, unsigned* s_k, int tid) {
+  if (tid == 0) { *s_prefix = 0ull; *s_k = k; }
+  unsigned long long pmask = 0ull;
+  for (int pass = 7; pass >= 0; --pass) {
+    if (tid < 256) hist[tid] = 0;
+    __syncthreads();
+    const unsigned long long prefix = *s_prefix;
+    for (int i = tid; i < M; i += 1024) {
+      double x[3], y[3];
+      if (!pair_get(s, i, x, y)) continue;
+      const double dx = y[0] - cam[0], dy = y[1] - cam[1], dz = y[2] - cam[2];
+      const unsigned long long key = (unsigned long long)__double_as_longlong(sqrt(dx * dx + dy * dy + dz * dz));
+      if ((key & pmask) == prefix) atomicAdd(&hist[(key >> (8 * pass)) & 255ull], 1u);
+    }
+    __syncthreads();
+    if (tid == 0) {
+      unsigned kk = *s_k, cum = 0;
+      int b = 0;
+      for (; b < 256; ++b) {
+        if (cum + hist[b] > kk) break;
+        cum += hist[b];
+      }
+      *s_k = kk - cum;
+      *s_prefix = prefix | ((unsigned long long)b << (8 * pass));
+    }
+    pmask |= 0xffull << (8 * pass);
+    __syncthreads();
+  }
+  return __longlong_as_double((long long)*s_prefix);
+}
+
+// out (doubles): [0] s, [1..9] R row-major, [10..12] t, [13..28] 4x4 row-major, [29] pairs used, [30] common pairs,
+//                [31] median distance, [32] rms alignment error over the used pairs
+__global__ __launch_bounds__(1024) void sim3_umeyama_kernel(PairSrc s, const float* __restrict__ last_ref_pose,
+                                                            int use_filter, double* __restrict__ out) {
+  __shared__ double red[16];
+  __shared__ unsigned hist[256];
+  __shared__ unsigned long long s_prefix;
+  __shared__ unsigned s_k;
+  __shared__ double sh[16];
+  const int tid = threadIdx.x;
+  const int M = s.ov * s.K;
+  const double cam[3] = {(double)last_ref_pose[3], (double)last_ref_pose[7], (double)last_ref_pose[11]};
+
+  double cnt = 0.0;
+  for (int i = tid; i < M; i += 1024) {
+    double x[3], y[3];
+    if (pair_get(s, i, x, y)) cnt += 1.0;
+  }
+  const double ncommon = block_sum(cnt, red, tid);
+  double med = INFINITY;
+  if (use_filter && ncommon >= 1.0) {
+    const unsigned n = (unsigned)ncommon;
+    const double lo = select_rank(s, cam, M, (n - 1) / 2, hist, &s_prefix, &s_k, tid);
+    const double hi = (n & 1) ? lo : select_rank(s, cam, M, n / 2, hist, &s_prefix, &s_k, tid);
+    med = 0.5 * (lo + hi);  // np.median
+  }
+
+  // pass A: count + means over kept pairs
+  double a[7] = {0, 0, 0, 0, 0, 0, 0};
+  for (int i = tid; i < M; i += 1024) {
+    double x[3], y[3];
+    if (!pair_get(s, i, x, y)) continue;
+    const double dx = y[0] - cam[0], dy = y[1] - cam[1], dz = y[2] - cam[2];
+    if (use_filter && !(sqrt(dx * dx + dy * dy + dz * dz) < med)) continue;
+    a[0] += 1.0;
+    for (int c = 0; c < 3; ++c) { a[1 + c] += x[c]; a[4 + c] += y[c]; }
+  }
+  for (int c = 0; c < 7; ++c) {
+    const double v = block_sum(a[c], red, tid);
+    if (tid == 0) sh[c] = v;
+  }
+  __syncthreads();
+  const double n = sh[0];
+  if (n < 3.0) {  // not enough pairs: report failure through the count, identity transform
+    if (tid == 0) {
+      for (int i = 0; i < 33; ++i) out[i] = 0.0;
+      out[0] = 1.0; out[1] = out[5] = out[9] = 1.0;
+      out[13] = out[18] = out[23] = out[28] = 1.0;
+      out[29] = n; out[30] = ncommon; out[31] = med;
+    }
+    return;
+  }
+  const double mx[3] = {sh[1] / n, sh[2] / n, sh[3] / n}, my[3] = {sh[4] / n, sh[5] / n, sh[6] / n};
+  __syncthreads();
+  // pass B: centred second moments  Sigma = 1/n sum (y - my)(x - mx)^T,  var_x = 1/n sum |x - mx|^2
+  double cm[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  for (int i = tid; i < M; i += 1024) {
+    double x[3], y[3];
+    if (!pair_get(s, i, x, y)) continue;
+    const double dx = y[0] - cam[0], dy = y[1] - cam[1], dz = y[2] - cam[2];
+    if (use_filter && !(sqrt(dx * dx + dy * dy + dz * dz) < med)) continue;
+    const double xc[3] = {x[0] - mx[0], x[1] - mx[1], x[2] - mx[2]};
+    const double yc[3] = {y[0] - my[0], y[1] - my[1], y[2] - my[2]};
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 3; ++c) cm[3 * r + c] += yc[r] * xc[c];
+    cm[9] += xc[0] * xc[0] + xc[1] * xc[1] + xc[2] * xc[2];
+  }
+  for (int c = 0; c < 10; ++c) {
+    const double v = block_sum(cm[c], red, tid);
+    if (tid == 0) sh[c] = v / n;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    double Sg[9], R[9];
+    for (int c = 0; c < 9; ++c) Sg[c] = sh[c];
+    const double varx = sh[9];
+    // R = U diag(1,1,det(UV^T)) V^T of Sigma = U D V^T  ==  argmax_R tr(R^T Sigma)  (rot3.h)
+    nearest_rotation_d(Sg, R);
+    double trc = 0.0;  // tr(D S) = tr(R^T Sigma)
+    for (int c = 0; c < 9; ++c) trc += R[c] * Sg[c];
+    const double sc = varx > 0.0 ? trc / varx : 1.0;
+    double t[3];
+    for (int r = 0; r < 3; ++r)
+      t[r] = my[r] - sc * (R[3 * r] * mx[0] + R[3 * r + 1] * mx[1] + R[3 * r + 2] * mx[2]);
+    out[0] = sc;
+    for (int c = 0; c < 9; ++c) out[1 + c] = R[c];
+    for (int c = 0; c < 3; ++c) out[10 + c] = t[c];
+    for (int r = 0; r < 3; ++r) {
+      for (int c = 0; c < 3; ++c) out[13 + 4 * r + c] = sc * R[3 * r + c];
+      out[13 + 4 * r + 3] = t[r];
+    }
+    out[25] = 0.0; out[26] = 0.0; out[27] = 0.0; out[28] = 1.0;
+    out[29] = n; out[30] = ncommon; out[31] = med;
+    sh[10] = sc;
+    for (int c = 0; c < 9; ++c) sh[c] = R[c];  // reuse for the residual pass
+    sh[11] = t[0]; sh[12] = t[1]; sh[13] = t[2];
+  }
+  __syncthreads();
+  double err = 0.0;
+  for (int i = tid; i < M; i += 1024) {
+    double x[3], y[3];
+    if (!pair_get(s, i, x, y)) continue;
+    const double dx = y[0] - cam[0], dy = y[1] - cam[1], dz = y[2] - cam[2];
+    if (use_filter && !(sqrt(dx * dx + dy * dy + dz * dz) < med)) continue;
+    for (int r = 0; r < 3; ++r) {
+      const double p = sh[10] * (sh[3 * r] * x[0] + sh[3 * r + 1] * x[1] + sh[3 * r + 2] * x[2]) + sh[11 + r] - y[r];
+      err += p * p;
+    }
+  }
+  const double tot = block_sum(err, red, tid);
+  if (tid == 0) out[32] = sqrt(tot / n);
+}
+
+extern "C" int pi3_sim3_umeyama(const void* pts_ref, const void* pts_qry, const int* idx, const unsigned char* w_ref,
+                                const unsigned char* w_qry, int ov, int K, const float* last_ref_pose,
+                                int use_filter, double* out33, void* stream) {
+  if (!pts_ref || !pts_qry || !idx || !last_ref_pose || !out33 || ov <= 0 || K <= 0) {
+    pi3_set_error("pi3_sim3_umeyama: bad arguments");
+    return PI3_ERR_ARG;
+  }
+  PairSrc s;
+  s.pts_ref = (const __half*)pts_ref; s.pts_qry = (const __half*)pts_qry; s.idx = idx;
+  s.w_ref = w_ref; s.w_qry = w_qry; s.ov = ov; s.K = K;
+  hipLaunchKernelGGL(sim3_umeyama_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, s, last_ref_pose, use_filter,
+                     out33);
+  return pi3_check_launch("sim3_umeyama");
+}
+
+// ---- 4. apply a 4x4 similarity (row-major doubles, device memory) to fp32 points [n][3] and cam->world poses [F][16]
+__global__ __launch_bounds__(256) void sim3_apply_kernel(const double* __restrict__ M4, float* pts, long n,
+                                                         float* poses, int F) {
+  double A[12];
+#pragma unroll
+  for (int i = 0; i < 12; ++i) A[i] = M4[i];
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  for (long j = i; j < n; j += (long)gridDim.x * 256) {
+    const double x = pts[3 * j], y = pts[3 * j + 1], z = pts[3 * j + 2];
+    pts[3 * j + 0] = (float)(A[0] * x + A[1] * y + A[2] * z + A[3]);
+    pts[3 * j + 1] = (float)(A[4] * x + A[5] * y + A[6] * z + A[7]);
+    pts[3 * j + 2] = (float)(A[8] * x + A[9] * y + A[10] * z + A[11]);
+  }
+  if (i < F) {
+    const double sc = sqrt(A[0] * A[0] + A[4] * A[4] + A[8] * A[8]);  // column norm of sR
+    float* P = poses + 16 * i;
+    double Pn[12];
+    for (int r = 0; r < 3; ++r) {
+      for (int c = 0; c < 3; ++c)
+        Pn[4 * r + c] = (A[4 * r] * P[c] + A[4 * r + 1] * P[4 + c] + A[4 * r + 2] * P[8 + c]) / sc;  // R . R_cw
+      Pn[4 * r + 3] = A[4 * r] * P[3] + A[4 * r + 1] * P[7] + A[4 * r + 2] * P[11] + A[4 * r + 3];    // sR c + t
+    }
+    for (int k = 0; k < 12; ++k) P[k] = (float)Pn[k];
+  }
+}
+
+extern "C" int pi3_sim3_apply(const double* M4_dev, float* pts, long n, float* poses, int F, void* stream) {
+  if (!M4_dev || (n > 0 && !pts) || (F > 0 && !poses) || n < 0 || F < 0 || (n == 0 && F == 0)) {
+    pi3_set_error("pi3_sim3_apply: bad arguments");
+    return PI3_ERR_ARG;
+  }
+  long work = n > F ? n : F;
+  long blocks = (work + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  if (blocks * 256 < F) blocks = (F + 255) / 256;
+  hipLaunchKernelGGL(sim3_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, M4_dev, pts, n,
+                     poses, F);
+  return pi3_check_launch("sim3_apply");
+}
+
+// ---- prefix composition G_c = G_{c-1} . T_c of 4x4 similarities (chunk-parallel alignment: every rank composes the
+// all-gathered relative transforms locally).  T, G: [n][16] row-major doubles; G_0 = T_0.
+__global__ void sim3_compose_kernel(const double* __restrict__ T, double* __restrict__ G, int n) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  double cur[16];
+  for (int i = 0; i < 16; ++i) cur[i] = T[i];
+  for (int i = 0; i < 16; ++i) G[i] = cur[i];
+  for (int c = 1; c < n; ++c) {
+    double nx[16];
+    for (int r = 0; r < 4; ++r)
+      for (int k = 0; k < 4; ++k) {
+        double acc = 0.0;
+        for (int j = 0; j < 4; ++j) acc += cur[4 * r + j] * T[16 * c + 4 * j + k];
+        nx[4 * r + k] = acc;
+      }
+    for (int i = 0; i < 16; ++i) { cur[i] = nx[i]; G[16 * c + i] = nx[i]; }
+  }
+}
+
+extern "C" int pi3_sim3_compose_prefix(const double* T, double* G, int n, void* stream) {
+  if (!T || !G || n <= 0) {
+    pi3_set_error("pi3_sim3_compose_prefix: bad arguments");
+    return PI3_ERR_ARG;
+  }
+  hipLaunchKernelGGL(sim3_compose_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, T, G, n);
+  return pi3_check_launch("sim3_compose_prefix");
+}

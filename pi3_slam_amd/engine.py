@@ -1,0 +1,303 @@
+"""Pi3Engine: the pi3 forward pass (window of frames -> dense pointmaps, confidence logits, camera poses) as a
+sequence of C-ABI kernel launches on one MI355X.
+
+Mirror of `Pi3.forward` (pi3/models/pi3.py:173-216) with the same input/output contract:
+    engine(imgs: (B, N, 3, H, W) fp32 in [0, 1]) -> {'points' (B,N,H,W,3), 'local_points' (B,N,H,W,3),
+                                                      'conf' (B,N,H,W,1) logits, 'camera_poses' (B,N,4,4)}
+all fp32, ordinary writable device tensors (callers mutate them: slam/offline_chunk_creator.py:189-192).
+
+Data layout in HBM (F = B*N frames, T = 5 + P tokens per frame, S = F*T):
+    residual stream  x      fp32 [S, D]   (the reference's residual is fp32 under bf16 autocast: LayerScale gamma is fp32)
+    normalised       xn     bf16 [S, D]   -> A operand of the next GEMM
+    packed qkv       qkv    bf16 [S, 3D]  [q | k | v], head-major inside each third; attention reads it in place
+    attention out    ao     bf16 [S, D]
+    MLP hidden       hid    bf16 [S, 4D]
+Frame attention views the rows as (F, T), global attention as (B, N*T): same buffers, no copies.
+Weights: bf16 [out][in] for every Linear that runs under autocast in the reference, fp32 for the heads the reference
+runs with autocast disabled (pi3.py:192-209), fp32 for norms / biases / LayerScale.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+from . import ops
+from .weights import IMAGE_MEAN, IMAGE_STD, Pi3Config, load_checkpoint, param_shapes, recipe_fill_device
+
+_BF16_SUFFIXES = ("attn.qkv.weight", "attn.proj.weight", "mlp.fc1.weight", "mlp.fc2.weight", "projects.weight",
+                  "linear_out.weight", "patch_embed.proj.weight")
+
+
+def _pad_rows(t: torch.Tensor, rows: int) -> torch.Tensor:
+    if t.shape[0] == rows:
+        return t.contiguous()
+    out = torch.zeros((rows,) + tuple(t.shape[1:]), device=t.device, dtype=t.dtype)
+    out[: t.shape[0]] = t
+    return out
+
+
+def bicubic_aa_taps(in_size: int, out_size: int) -> np.ndarray:
+    """Tap matrix [out_size, in_size] of F.interpolate(mode='bicubic', antialias=True, align_corners=False,
+    size=out_size) along one axis (ATen upsample_bicubic2d_aa: cubic a = -0.5, support 2*max(scale,1), weights
+    normalised per output).  Host-side constant builder; the resample itself runs in csrc/elem.hip."""
+    scale = np.float32(in_size) / np.float32(out_size)
+    support = np.float32(2.0) * scale if scale >= 1.0 else np.float32(2.0)
+    invscale = np.float32(1.0) / scale if scale >= 1.0 else np.float32(1.0)
+    a = np.float32(-0.5)
+
+    def cubic(x):
+        x = np.abs(x).astype(np.float32)
+        y = np.zeros_like(x)
+        m1 = x < 1.0
+        m2 = (x >= 1.0) & (x < 2.0)
+        y[m1] = ((a + 2.0) * x[m1] - (a + 3.0)) * x[m1] * x[m1] + 1.0
+        y[m2] = (((x[m2] - 5.0) * x[m2] + 8.0) * x[m2] - 4.0) * a
+        return y.astype(np.float32)
+
+    W = np.zeros((out_size, in_size), dtype=np.float32)
+    for i in range(out_size):
+        center = scale * np.float32(i + 0.5)
+        xmin = max(0, int(center - support + np.float32(0.5)))
+        xmax = min(in_size, int(center + support + np.float32(0.5)))
+        j = np.arange(xmin, xmax, dtype=np.float32)
+        w = cubic((j - center + np.float32(0.5)) * invscale)
+        tot = np.float32(w.sum(dtype=np.float32))
+        if tot != 0:
+            w = w / tot
+        W[i, xmin:xmax] = w
+    return W
+
+
+class Pi3Engine:
+    def __init__(self, cfg: Pi3Config = Pi3Config(), device: str = "cuda:0",
+                 state_dict: Optional[Dict[str, torch.Tensor]] = None):
+        """state_dict=None -> recipe weights generated on the device (no checkpoint exists offline)."""
+        assert cfg.dim % 128 == 0 and cfg.cam_dim % 128 == 0 and cfg.cam_dim <= 1024
+        self.cfg = cfg
+        self.device = torch.device(device)
+        torch.cuda.set_device(self.device)
+        self.w: Dict[str, torch.Tensor] = {}
+        shapes = param_shapes(cfg)
+        for name, shape in shapes.items():
+            if state_dict is None:
+                t = recipe_fill_device(name, shape, self.device)
+            else:
+                t = state_dict[name].to(self.device, dtype=torch.float32)
+                assert tuple(t.shape) == tuple(shape), f"{name}: {tuple(t.shape)} != {shape}"
+            self._install(name, t)
+        self._shape_cache = {}
+        self._buf = {}
+
+    @classmethod
+    def from_pretrained(cls, path: str, device: str = "cuda:0") -> "Pi3Engine":
+        """Local directory / file with the reference checkpoint layout (pi3.py:14-16)."""
+        return cls(Pi3Config(), device, load_checkpoint(path))
+
+    # ------------------------------------------------------------------ weights
+    def _install(self, name: str, t: torch.Tensor) -> None:
+        D = self.cfg.dim
+        if name == "encoder.patch_embed.proj.weight":
+            w = torch.zeros(D, 640, device=self.device, dtype=torch.bfloat16)
+            w[:, :588] = t.reshape(D, 588).to(torch.bfloat16)
+            self.w[name] = w
+        elif name.endswith(_BF16_SUFFIXES):
+            self.w[name] = t.to(torch.bfloat16).contiguous()
+        elif name in ("point_head.proj.weight", "conf_head.proj.weight"):
+            self.w[name] = _pad_rows(t, 640 if name.startswith("point") else 256)
+        elif name in ("point_head.proj.bias", "conf_head.proj.bias"):
+            self.w[name] = _pad_rows(t, 640 if name.startswith("point") else 256)
+        else:
+            self.w[name] = t.contiguous()
+
+    # ------------------------------------------------------------------ per-(H, W) constants
+    def _shape_consts(self, H: int, W: int):
+        key = (H, W)
+        if key in self._shape_cache:
+            return self._shape_cache[key]
+        cfg, dev = self.cfg, self.device
+        ph, pw = H // 14, W // 14
+        P = ph * pw
+        T = cfg.n_dec_reg + P
+        assert cfg.n_enc_reg + 1 == cfg.n_dec_reg, "encoder (cls + registers) and decoder registers share token slots"
+        G = cfg.pos_grid
+        pe = self.w["encoder.pos_embed"][0]  # [1 + G*G, D]
+        if ph == G and pw == G:
+            pos_patch = pe[1:].contiguous()
+        else:  # vision_transformer.py:181-213 (interpolate_offset = 0 -> explicit output size)
+            wy = torch.from_numpy(bicubic_aa_taps(G, ph)).to(dev)
+            wx = torch.from_numpy(bicubic_aa_taps(G, pw)).to(dev)
+            pos_patch = ops.resample_grid(pe[1:].reshape(G, G, cfg.dim).contiguous(), wy, wx).reshape(P, cfg.dim)
+        # cls + pos_embed[0], then the encoder registers (no positional term): vision_transformer.py:221-232
+        special_enc = torch.cat([self.w["encoder.cls_token"][0] + pe[0:1], self.w["encoder.register_tokens"][0]], 0)
+        # decoder positions: PositionGetter + 1, specials at 0 (pi3.py:146-154)
+        pos = torch.zeros(T, 2, dtype=torch.int32)
+        yy, xx = torch.meshgrid(torch.arange(ph), torch.arange(pw), indexing="ij")
+        pos[cfg.n_dec_reg:, 0] = (yy.reshape(-1) + 1).to(torch.int32)
+        pos[cfg.n_dec_reg:, 1] = (xx.reshape(-1) + 1).to(torch.int32)
+        npos = max(ph, pw) + 1
+        inv_freq = 1.0 / (cfg.rope_base ** (torch.arange(0, 32, 2).float() / 32))  # pos_embed.py:122
+        ang = torch.einsum("i,j->ij", torch.arange(npos).float(), inv_freq)
+        cs = torch.stack([ang.cos(), ang.sin()], dim=-1).contiguous()
+        consts = dict(ph=ph, pw=pw, P=P, T=T, pos_patch=pos_patch.contiguous(), special_enc=special_enc.contiguous(),
+                      pos=pos.to(dev), cs=cs.to(dev),
+                      special_dec=self.w["register_token"].reshape(cfg.n_dec_reg, cfg.dim).contiguous())
+        self._shape_cache[key] = consts
+        return consts
+
+    def _buffer(self, name: str, shape, dtype) -> torch.Tensor:
+        key = (name, tuple(shape), dtype)
+        if key not in self._buf:
+            for k in [k for k in self._buf if k[0] == name]:
+                del self._buf[k]
+            self._buf[key] = torch.empty(shape, device=self.device, dtype=dtype)
+        return self._buf[key]
+
+    # ------------------------------------------------------------------ transformer block
+    def _block(self, prefix: str, x: torch.Tensor, S: int, attn_B: int, attn_S: int, T: int, consts, rope: bool,
+               qk_norm: bool, ls: bool, bufs) -> None:
+        cfg, w = self.cfg, self.w
+        D, H = cfg.dim, cfg.heads
+        xn, qkv, ao, hid = bufs
+        ops.layernorm(x, w[f"{prefix}.norm1.weight"], w[f"{prefix}.norm1.bias"], xn, cfg.eps, rows=S)
+        fused = rope or qk_norm
+        ops.gemm(xn, w[f"{prefix}.attn.qkv.weight"], qkv, M=S, bias=w[f"{prefix}.attn.qkv.bias"],
+                 qscale=1.0 if fused else ops.QSCALE, qcols=0 if fused else D)
+        if fused:
+            ops.qknorm_rope(qkv, S, H, T, consts["pos"], consts["cs"],
+                            w.get(f"{prefix}.attn.q_norm.weight") if qk_norm else None,
+                            w.get(f"{prefix}.attn.q_norm.bias") if qk_norm else None,
+                            w.get(f"{prefix}.attn.k_norm.weight") if qk_norm else None,
+                            w.get(f"{prefix}.attn.k_norm.bias") if qk_norm else None,
+                            eps=1e-5 if qk_norm else cfg.eps, qscale=ops.QSCALE, do_rope=rope)
+        ops.attention(qkv, ao, attn_B, attn_S, H)
+        ops.gemm(ao, w[f"{prefix}.attn.proj.weight"], x, M=S, bias=w[f"{prefix}.attn.proj.bias"],
+                 gamma=w[f"{prefix}.ls1.gamma"] if ls else None, resid=x)
+        ops.layernorm(x, w[f"{prefix}.norm2.weight"], w[f"{prefix}.norm2.bias"], xn, cfg.eps, rows=S)
+        ops.gemm(xn, w[f"{prefix}.mlp.fc1.weight"], hid, M=S, bias=w[f"{prefix}.mlp.fc1.bias"], act=ops.ACT_GELU)
+        ops.gemm(hid, w[f"{prefix}.mlp.fc2.weight"], x, M=S, bias=w[f"{prefix}.mlp.fc2.bias"],
+                 gamma=w[f"{prefix}.ls2.gamma"] if ls else None, resid=x)
+
+    # ------------------------------------------------------------------ forward
+    @torch.no_grad()
+    def forward(self, imgs: torch.Tensor, return_intermediates: bool = False) -> Dict[str, torch.Tensor]:
+        cfg, w, dev = self.cfg, self.w, self.device
+        assert imgs.ndim == 5 and imgs.shape[2] == 3, "expected (B, N, 3, H, W)"
+        B, N, _, Himg, Wimg = imgs.shape
+        assert Himg % 14 == 0 and Wimg % 14 == 0, "H and W must be multiples of the patch size 14"
+        imgs = imgs.to(dev, dtype=torch.float32).contiguous()
+        c = self._shape_consts(Himg, Wimg)
+        P, T = c["P"], c["T"]
+        F = B * N
+        S = F * T
+        D = cfg.dim
+        inter = {}
+
+        x = self._buffer("x", (S, D), torch.float32)
+        xn = self._buffer("xn", (S, D), torch.bfloat16)
+        qkv = self._buffer("qkv", (S, 3 * D), torch.bfloat16)
+        ao = self._buffer("ao", (S, D), torch.bfloat16)
+        hid = self._buffer("hid", (S, 4 * D), torch.bfloat16)
+        bufs = (xn, qkv, ao, hid)
+
+        # ---- patch embed (+ cls / registers / interpolated pos-embed): vision_transformer.py:215-234
+        patches = self._buffer("patches", (F * P, 640), torch.bfloat16)
+        ops.patch_gather(imgs.view(F, 3, Himg, Wimg), patches, IMAGE_MEAN, IMAGE_STD)
+        ops.gemm(patches, w["encoder.patch_embed.proj.weight"], x, M=F * P, bias=w["encoder.patch_embed.proj.bias"],
+                 rpg=P, gstride=T, goff=cfg.n_dec_reg, addtab=c["pos_patch"])
+        ops.fill_tokens(x, F, T, 0, c["special_enc"])
+        if return_intermediates:
+            inter["tokens"] = x.clone()
+
+        # ---- encoder: 24 pre-LN blocks, frame-wise attention, LayerScale, no RoPE (dinov2/layers/block.py:88-113)
+        for i in range(cfg.enc_depth):
+            self._block(f"encoder.blocks.{i}", x, S, F, T, T, c, rope=False, qk_norm=False, ls=True, bufs=bufs)
+        # final norm; patch tokens kept, the 5 special slots become the decoder's register tokens (pi3.py:140-144)
+        hidden = self._buffer("hidden", (S, D), torch.float32)
+        ops.layernorm(x, w["encoder.norm.weight"], w["encoder.norm.bias"], hidden, cfg.eps, rows=S, T=T,
+                      nspecial=cfg.n_dec_reg, special=c["special_dec"])
+        if return_intermediates:
+            inter["enc_out"] = hidden.clone()
+
+        # ---- decoder: alternating frame / global attention (pi3.py:156-171)
+        cat = self._buffer("cat", (S, 2 * D), torch.bfloat16)
+        for i in range(cfg.dec_depth):
+            if i % 2 == 0:
+                aB, aS = F, T
+            else:
+                aB, aS = B, N * T
+            self._block(f"decoder.{i}", hidden, S, aB, aS, T, c, rope=True, qk_norm=True, ls=True, bufs=bufs)
+            if i == cfg.dec_depth - 2:
+                ops.cast_rows(hidden, cat[:, :D], rows=S, cols=D)
+            if i == cfg.dec_depth - 1:
+                ops.cast_rows(hidden, cat[:, D:], rows=S, cols=D)
+            if return_intermediates and i in (0, 1):
+                inter[f"dec{i}"] = hidden.clone()
+        if return_intermediates:
+            inter["dec_cat"] = cat.float()
+
+        # ---- three TransformerDecoder heads (transformer_head.py:48-56)
+        head_out = {}
+        for head, od in (("point_decoder", D), ("conf_decoder", D), ("camera_decoder", cfg.cam_dim)):
+            hx = self._buffer("hx", (S, D), torch.float32)
+            ops.gemm(cat, w[f"{head}.projects.weight"], hx, M=S, bias=w[f"{head}.projects.bias"])
+            for i in range(cfg.head_depth):
+                self._block(f"{head}.blocks.{i}", hx, S, F, T, T, c, rope=True, qk_norm=False, ls=False, bufs=bufs)
+            ops.cast_rows(hx, xn, rows=S, cols=D)
+            out = self._buffer(f"{head}.out", (S, od), torch.float32)
+            ops.gemm(xn, w[f"{head}.linear_out.weight"], out, M=S, bias=w[f"{head}.linear_out.bias"])
+            head_out[head] = out
+            if return_intermediates:
+                inter[head] = out.clone()
+
+        # ---- fp32 heads (autocast disabled in the reference, pi3.py:192-209)
+        pfeat = self._buffer("pfeat", (S, 640), torch.float32)
+        cfeat = self._buffer("cfeat", (S, 256), torch.float32)
+        ops.gemm(head_out["point_decoder"], w["point_head.proj.weight"], pfeat, M=S, bias=w["point_head.proj.bias"])
+        ops.gemm(head_out["conf_decoder"], w["conf_head.proj.weight"], cfeat, M=S, bias=w["conf_head.proj.bias"])
+        C = cfg.cam_dim
+        res = head_out["camera_decoder"]
+        t1 = self._buffer("cam_t1", (S, C), torch.float32)
+        t2 = self._buffer("cam_t2", (S, C), torch.float32)
+        for r in range(2):  # ResConvBlock (camera_head.py:25-30)
+            pre = f"camera_head.res_conv.{r}.res_conv"
+            ops.gemm(res, w[pre + "1.weight"], t1, M=S, bias=w[pre + "1.bias"], act=ops.ACT_RELU)
+            ops.gemm(t1, w[pre + "2.weight"], t2, M=S, bias=w[pre + "2.bias"], act=ops.ACT_RELU)
+            ops.gemm(t2, w[pre + "3.weight"], res, M=S, bias=w[pre + "3.bias"], act=ops.ACT_RELU, resid=res)
+        poses = torch.empty(F, 4, 4, device=dev, dtype=torch.float32)
+        ops.camera_tail(res, T, cfg.n_dec_reg, F, P, w, poses)
+        local_points = torch.empty(F, Himg, Wimg, 3, device=dev, dtype=torch.float32)
+        points = torch.empty(F, Himg, Wimg, 3, device=dev, dtype=torch.float32)
+        conf = torch.empty(F, Himg, Wimg, 1, device=dev, dtype=torch.float32)
+        ops.unpatchify_points(pfeat, cfeat, poses, F, Himg, Wimg, T, cfg.n_dec_reg, local_points, points, conf)
+
+        result = dict(points=points.view(B, N, Himg, Wimg, 3), local_points=local_points.view(B, N, Himg, Wimg, 3),
+                      conf=conf.view(B, N, Himg, Wimg, 1), camera_poses=poses.view(B, N, 4, 4))
+        if return_intermediates:
+            result["_intermediates"] = inter
+        return result
+
+    __call__ = forward
+
+    # algorithmic FLOPs of one forward (SURVEY.md §8d formula) — used by bench.py for the roofline line
+    def flops(self, B: int, N: int, H: int, W: int) -> Dict[str, float]:
+        cfg = self.cfg
+        D = cfg.dim
+        P = (H // 14) * (W // 14)
+        T = P + cfg.n_dec_reg
+        F = B * N
+        S = F * T
+        lin = 24.0 * D * D * S
+        frame = 4.0 * F * T * T * D
+        glob = 4.0 * B * (N * T) ** 2 * D
+        out = dict(
+            patch_embed=2.0 * F * P * 588 * D,
+            linear=(cfg.enc_depth + cfg.dec_depth + 3 * cfg.head_depth) * lin + 3 * 2.0 * 2 * D * D * S
+            + 2.0 * D * S * (2 * D + cfg.cam_dim) + 2.0 * D * (588 + 196) * F * P,
+            frame_attn=(cfg.enc_depth + cfg.dec_depth // 2 + 3 * cfg.head_depth) * frame,
+            global_attn=(cfg.dec_depth // 2) * glob,
+        )
+        out["total"] = sum(out.values())
+        return out

@@ -1,0 +1,90 @@
+"""ctypes binding of the C-ABI kernel library (include/pi3slam_hip.h).
+
+The library is the product: every arithmetic step of the hot path runs in it.  There is no CPU or eager-PyTorch
+fallback — if the shared object is missing, fails to load, or no GPU is visible, the calls raise.
+PyTorch is used only as the owner of device memory and streams: tensors are passed as raw device pointers.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpi3slam_hip.so")
+
+_vp, _i, _l, _f, _u64 = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_ulonglong
+
+# name -> argtypes; every function returns int (0 = ok) except the two noted below.  Mirrors include/pi3slam_hip.h.
+SIGNATURES = {
+    "pi3_gemm": [_vp, _l, _vp, _l, _i, _i, _i, _i, _vp, _vp, _vp, _l, _vp, _l, _i, _i, _i, _i, _i, _vp, _l, _f, _i, _vp],
+    "pi3_attention": [_vp, _vp, _vp, _l, _l, _vp, _l, _l, _i, _i, _i, _i, _vp],
+    "pi3_layernorm": [_vp, _l, _i, _i, _vp, _vp, _f, _vp, _l, _i, _i, _i, _vp, _vp],
+    "pi3_qknorm_rope": [_vp, _l, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _i, _vp],
+    "pi3_cast_rows": [_vp, _l, _vp, _l, _l, _i, _i, _vp],
+    "pi3_patch_gather": [_vp, _i, _i, _i, _vp, _i, C.POINTER(_f), C.POINTER(_f), _vp],
+    "pi3_resample_grid": [_vp, _i, _i, _i, _vp, _vp, _i, _i, _vp, _vp],
+    "pi3_fill_tokens": [_vp, _i, _i, _i, _i, _i, _vp, _vp],
+    "pi3_recipe_fill": [_vp, _l, _u64, _f, _f, _i, _vp],
+    "pi3_unpatchify_points": [_vp, _l, _vp, _l, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp],
+    "pi3_camera_tail": [_vp, _l, _l, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "pi3_compute_masks": [_vp, _vp, _i, _i, _i, _f, _f, _vp, _vp],
+    "pi3_masked_ratio_median": [_vp, _vp, _l, _vp, _l, _vp, _vp],
+    "pi3_apply_scale": [_vp, _vp, _vp, _l, _vp, _i, _vp],
+    "pi3_gather_keypoints": [_vp] * 6 + [_i] * 4 + [_vp] * 7,
+    "pi3_sim3_match_keypoints": [_vp, _vp, _i, _i, _vp, _vp],
+    "pi3_sim3_umeyama": [_vp] * 5 + [_i, _i, _vp, _i, _vp, _vp],
+    "pi3_sim3_apply": [_vp, _vp, _l, _vp, _i, _vp],
+    "pi3_sim3_compose_prefix": [_vp, _vp, _i, _vp],
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+class Pi3HipError(RuntimeError):
+    pass
+
+
+def load(require_gpu: bool = True) -> C.CDLL:
+    """Load libpi3slam_hip.so (built by `__graft_entry__.build()` / `make -C pi3_slam_amd/csrc`)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise Pi3HipError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'`. "
+                "There is no CPU fallback for the hot path.")
+        lib = C.CDLL(LIB_PATH)
+        lib.pi3_last_error.restype = C.c_char_p
+        lib.pi3_last_error.argtypes = []
+        lib.pi3_abi_version.restype = _i
+        lib.pi3_device_count.restype = _i
+        for name, argt in SIGNATURES.items():
+            if os.environ.get("PI3_DEV_PARTIAL") and not hasattr(lib, name):
+                continue  # development builds of a subset of the kernels only
+            fn = getattr(lib, name)  # AttributeError here == header/library mismatch: fail loudly
+            fn.argtypes = argt
+            fn.restype = _i
+        _lib = lib
+    if require_gpu and _lib.pi3_device_count() <= 0:
+        raise Pi3HipError("no HIP device visible: the Pi3-SLAM hot path runs only on a GPU (gfx950)")
+    return _lib
+
+
+def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise Pi3HipError("expected a device tensor")
+    return t.data_ptr()
+
+
+def stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = load(False).pi3_last_error().decode("utf-8", "replace")
+        raise Pi3HipError(f"{what or 'pi3 call'} failed (rc={rc}): {msg}")

@@ -1,0 +1,151 @@
+/* pi3slam_hip.h — C ABI of libpi3slam_hip.so: the gfx950 (MI355X) kernels of the Pi3-SLAM hot path.
+ *
+ * The reference (urbste/Pi3_SLAM) is pure Python on PyTorch; its only native FFI is the optional pybind11 module
+ * `curope` with one function rope_2d(tokens, positions, base, fwd) (pi3/models/curope/curope.cpp:49-68,
+ * kernels.cu:17-108), which its own entry points never load.  Everything else on the path is a torch operator call.
+ * This header is therefore the boundary a maintainer binds with ctypes: each entry point names
+ * the reference call site (file:line) whose arithmetic it replaces.
+ *
+ * Conventions (all entry points):
+ *   - plain pointers and sizes only; every pointer is DEVICE memory unless the name ends in `_host`;
+ *   - no allocation, no host synchronisation, no implicit stream: the caller passes a hipStream_t as `void* stream`
+ *     (0 = default stream); calls are asynchronous and re-entrant per stream;
+ *   - return 0 on success, negative on error (PI3_ERR_*); pi3_last_error() returns the thread-local message;
+ *   - row-major tensors; `ld*` / strides are in ELEMENTS; bf16 = 16-bit brain float, f16 = IEEE half;
+ *   - dtype codes: 0 = bf16, 1 = f32.
+ */
+#ifndef PI3SLAM_HIP_H
+#define PI3SLAM_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PI3_OK 0
+#define PI3_ERR_ARG (-1)
+#define PI3_ERR_LAUNCH (-2)
+#define PI3_ERR_WORKSPACE (-3)
+
+const char* pi3_last_error(void);
+int pi3_abi_version(void);
+int pi3_device_count(void);
+
+/* ---- transformer blocks -------------------------------------------------------------------------------------- */
+
+/* torch.nn.Linear with fused epilogue (pi3/models/layers/block.py:310-335, pi3/models/dinov2/layers/mlp.py:34-40,
+ * pi3/models/layers/attention.py:325,345, transformer_head.py:49,55,74, camera_head.py:26-31, patch_embed.py:75):
+ *   out[orow(m)][n] = resid[orow(m)][n] + gamma[n] * act((A[m] . W[n] + bias[n]) * (n < qcols ? qscale : 1))
+ *                     + addtab[m % rpg][n]
+ *   orow(m) = rpg ? (m / rpg) * gstride + goff + m % rpg : m.   bias/gamma/resid/addtab may be NULL.
+ * A [M][K] and W [N][K] share in_dtype (0: bf16 MFMA, 1: exact-fp32 MFMA); N % 128 == 0; K % 64 (bf16) / 32 (f32).
+ * act: 0 none, 1 GELU(erf), 2 ReLU. */
+int pi3_gemm(const void* A, long lda, const void* W, long ldw, int M, int N, int K, int in_dtype, const float* bias,
+             const float* gamma, const float* resid, long ldr, void* out, long ldo, int out_dtype, int act, int rpg,
+             int gstride, int goff, const float* addtab, long ldadd, float qscale, int qcols, void* stream);
+
+/* F.scaled_dot_product_attention, non-causal, head_dim 64 (pi3/models/layers/attention.py:102-107, 336-341).
+ * q/k/v: bf16, element (b, s, h, d) at ptr[b*batch_stride + s*tok_stride + h*64 + d]; q PRE-SCALED by
+ * 64^-0.5 * log2(e).  o: bf16 [B][S][H*64] with the given strides. */
+int pi3_attention(const void* q, const void* k, const void* v, long tok_stride, long batch_stride, void* o,
+                  long o_tok_stride, long o_batch_stride, int B, int S, int H, int head_dim, void* stream);
+
+/* nn.LayerNorm(D, eps) over rows of x (block.py:282,296; vision_transformer.py:271).  If nspecial > 0 (f32 out only),
+ * rows with (row % T) < nspecial are replaced by special[row % T][:]: Pi3.decode's register-token concat
+ * (pi3/models/pi3.py:140-144). */
+int pi3_layernorm(const float* x, long ldx, int rows, int D, const float* w, const float* b, float eps, void* out,
+                  long ldo, int out_dtype, int T, int nspecial, const float* special, void* stream);
+
+/* In place on packed qkv bf16 [rows][3][H][64]: optional LayerNorm(64) of q and k (attention.py:330), RoPE-2D
+ * (pos_embed.py:142-159 == curope.cpp:11-47; pos int32 [T][2] (y, x) indexed by row % T; cs f32 [npos][16][2] =
+ * (cos, sin) of pos * base^(-j/16)), then q *= qscale.  This is the replacement of the reference's `curope.rope_2d`. */
+int pi3_qknorm_rope(void* qkv, long rows, int H, int T, const int* pos, const float* cs, const float* qw,
+                    const float* qb, const float* kw, const float* kb, float eps, float qscale, int do_rope,
+                    void* stream);
+
+/* f32 -> bf16/f32 strided row copy (concat of the last two decoder outputs, pi3.py:168-171). */
+int pi3_cast_rows(const float* in, long ldi, void* out, long ldo, long rows, int cols, int out_dtype, void* stream);
+
+/* frames f32 [F][3][H][W] -> ImageNet-normalised (pi3.py:174) bf16 patch rows [F*P][KP], column c*196 + ky*14 + kx,
+ * zero padded to KP: the im2col of PatchEmbed's Conv2d (patch_embed.py:65,75).  mean3/std3 are HOST arrays. */
+int pi3_patch_gather(const float* img, int F, int H, int W, void* out, int KP, const float* mean3_host,
+                     const float* std3_host, void* stream);
+
+/* dst[oy][ox][:] = sum_ij wy[oy][i] wx[ox][j] src[i][j][:]: bicubic-antialias resample of pos_embed
+ * (vision_transformer.py:205-210) with host-built tap matrices. */
+int pi3_resample_grid(const float* src, int Mi, int Mj, int D, const float* wy, const float* wx, int oh, int ow,
+                      float* dst, void* stream);
+
+/* x[(f*T + t0 + t)][:] = vals[t][:] for t < nt (cls + registers, vision_transformer.py:221-232). */
+int pi3_fill_tokens(float* x, int F, int T, int D, int t0, int nt, const float* vals, void* stream);
+
+/* Recipe weights (no checkpoint exists offline): out[i] = offset + scale * u(seed, i), bit-identical to
+ * pi3_slam_amd/recipe.py. */
+int pi3_recipe_fill(void* out, long n, unsigned long long seed, float offset, float scale, int out_dtype,
+                    void* stream);
+
+/* ---- output heads --------------------------------------------------------------------------------------------- */
+
+/* LinearPts3d's pixel_shuffle + remap + unprojection (transformer_head.py:76-80, pi3.py:195-209).  Feature row of
+ * frame f, patch p is f*T + tok_off + p.  Outputs f32 [F][H][W][3], [F][H][W][3], [F][H][W][1]. */
+int pi3_unpatchify_points(const float* pfeat, long ldp, const float* cfeat, long ldc, const float* poses, int F,
+                          int H, int W, int T, int tok_off, float* local_points, float* points, float* conf,
+                          void* stream);
+
+/* CameraHead after the ResConv blocks (camera_head.py:55-93): token mean, 2x Linear+ReLU, fc_t, fc_rot, SO(3)
+ * projection -> poses f32 [F][4][4] cam->world. */
+int pi3_camera_tail(const float* feat, long ld, long frame_stride, int F, int P, int D, const float* w1,
+                    const float* b1, const float* w2, const float* b2, const float* wt, const float* bt,
+                    const float* wr, const float* br, float* poses, void* stream);
+
+/* ---- per-chunk post-processing ------------------------------------------------------------------------------- */
+
+/* masks = sigmoid(conf) > conf_thr & ~depth_edge(z, rtol) (slam/offline_chunk_creator.py:114-119,
+ * pi3/utils/geometry.py:347-375).  masks: uint8 [F][H][W]. */
+int pi3_compute_masks(const float* conf, const float* local_points, int F, int H, int W, float conf_thr, float rtol,
+                      unsigned char* masks, void* stream);
+
+/* out2[0] = lower median of (num[i] / den[i*den_stride]) over mask[i] != 0, out2[1] = count
+ * (_get_scale_factor_for_pi3, offline_chunk_creator.py:121-127). */
+int pi3_masked_ratio_median(const float* num, const float* den, long den_stride, const unsigned char* mask, long n,
+                            float* out2, void* stream);
+
+/* local_points *= s; points *= s; poses[:, :3, 3] *= s with s = *scale_dev (offline_chunk_creator.py:189-191). */
+int pi3_apply_scale(const float* scale_dev, float* local_points, float* points, long n3, float* poses, int F,
+                    void* stream);
+
+/* grid_sample of the dense maps at keypoints + fp16 pack (offline_chunk_creator.py:129-159, 231-241;
+ * utils/keypoint_extraction.py:203-229).  keypoints f32 [F][K][2] (x, y) px; images f32 [F][3][H][W] or NULL.
+ * Outputs: f16 [F][K][3], f16 [F][K][3], f16 [F][K][1], uint8 [F][K][1], f16 [F][K][3] (0..255), f16 [F][K][2]. */
+int pi3_gather_keypoints(const float* points, const float* local_points, const float* conf,
+                         const unsigned char* masks, const float* images, const float* keypoints, int F, int H,
+                         int W, int K, void* o_points, void* o_local, void* o_conf, unsigned char* o_mask,
+                         void* o_colors, void* o_kps, void* stream);
+
+/* Per-frame focal / z-shift + intrinsics (utils/camera_estimation.py:12-70, utils/geometry_torch.py:114-169,
+ * utils/geometry_numpy.py:79-96: scipy least_squares(method='lm') == MINPACK lmdif, n = 1).  uvx [W], uvy [H]: fp32
+ * normalized_view_plane_uv tables.  Outputs f32: focal [F], shift [F], (fx, fy, cx, cy) [F][4], K [F][3][3]. */
+int pi3_focal_shift(const float* local_points, const float* conf, const float* uvx, const float* uvy, int F, int H,
+                    int W, float conf_thr, float* focal, float* shift, float* fxfycxcy, float* K33, void* stream);
+
+/* ---- overlap Sim(3) alignment (utils/reconstruction_alignment.py:74-105) --------------------------------------- */
+
+/* idx[v][j] = index of the ref keypoint with bit-identical f16 (x, y) in overlap view v, or -1 (:74). */
+int pi3_sim3_match_keypoints(const void* kp_ref, const void* kp_qry, int ov, int K, int* idx, void* stream);
+
+/* Near-half filter (:78-86, use_filter != 0) + closed-form Umeyama similarity qry -> ref (:89-105).
+ * pts_*: f16 [ov][K][3]; w_*: optional uint8 validity [ov][K]; last_ref_pose: f32 [16] cam->world of the last ref view.
+ * out33 (f64): [0] s, [1..9] R, [10..12] t, [13..28] 4x4, [29] pairs used, [30] common pairs, [31] median, [32] rms. */
+int pi3_sim3_umeyama(const void* pts_ref, const void* pts_qry, const int* idx, const unsigned char* w_ref,
+                     const unsigned char* w_qry, int ov, int K, const float* last_ref_pose, int use_filter,
+                     double* out33, void* stream);
+
+/* TransformReconstruction4 (:105): points f32 [n][3] and cam->world poses f32 [F][16] in place by the f64 4x4. */
+int pi3_sim3_apply(const double* M4_dev, float* pts, long n, float* poses, int F, void* stream);
+
+/* G[c] = G[c-1] . T[c], G[0] = T[0]: prefix composition of per-chunk relative similarities ([n][16] f64). */
+int pi3_sim3_compose_prefix(const double* T, double* G, int n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PI3SLAM_HIP_H */

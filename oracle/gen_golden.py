@@ -27,6 +27,7 @@ CASES = {
     # name: (B, N, H, W)
     "pi3_tiny_a": (1, 3, 28, 42),
     "pi3_tiny_b": (1, 2, 42, 56),
+    "pi3_tiny_c": (1, 5, 56, 70),
 }
 
 
@@ -86,6 +87,30 @@ def main() -> None:
             save["i_" + k] = v2.numpy()
             d = (v2 - orc["_intermediates"][k]).abs().max().item()
             print(f"   i_{k:12s} ref-vs-oracle max|d| = {d:.3e}   (ref max {v2.abs().max().item():.3f})")
+        # Tolerance anchor: the reference's OWN bf16-autocast execution vs its fp32 execution on the same weights
+        # (what offline_chunk_creator.py:168-171 runs on a GPU).  The reference disables autocast for the heads with
+        # device_type='cuda' contexts (pi3.py:192, camera_head.py:68); map those to the CPU autocast so they are honoured.
+        orig_autocast = torch.amp.autocast
+
+        class _CpuAutocast(orig_autocast):
+            def __init__(self, device_type, *a, **k):
+                super().__init__("cpu" if device_type == "cuda" else device_type, *a, **k)
+
+        torch.amp.autocast = _CpuAutocast
+        try:
+            with torch.no_grad(), torch.autocast("cpu", dtype=torch.bfloat16):
+                ref16 = model(imgs)
+        finally:
+            torch.amp.autocast = orig_autocast
+        for k in ("points", "local_points", "conf", "camera_poses"):
+            d = (ref16[k].float() - ref[k]).abs()
+            save["bf16err_" + k] = np.array([d.mean().item(), d.max().item()], dtype=np.float64)
+            print(f"   {k:14s} reference bf16-autocast vs fp32: mean|d| {d.mean().item():.3e} max|d| {d.max().item():.3e}"
+                  f"  (dtype {ref16[k].dtype})")
+        Ra, Rb = ref16["camera_poses"][0, :, :3, :3].double(), ref["camera_poses"][0, :, :3, :3].double()
+        tr = ((Ra @ Rb.transpose(-1, -2)).diagonal(dim1=-2, dim2=-1).sum(-1) - 1) / 2
+        save["bf16err_rot_deg"] = np.array([torch.rad2deg(torch.acos(tr.clamp(-1, 1))).max().item()])
+        print("   reference bf16 rotation error (deg):", save["bf16err_rot_deg"])
         np.savez_compressed(os.path.join(out_dir, name + ".npz"), **save)
         print("   wrote", os.path.join(out_dir, name + ".npz"))
 

@@ -1,0 +1,266 @@
+"""ORACLE — test infrastructure only.  CPU restatement of the per-chunk glue between the network and the chunk file,
+and of the overlap Sim(3) alignment.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import it.
+
+Pinning: oracle/gen_golden_post.py runs the reference's own functions (slam/offline_chunk_creator.py,
+utils/keypoint_extraction.py, utils/geometry_torch.py, utils/camera_estimation.py,
+utils/reconstruction_alignment.py:create_view_graph_matches) on seeded inputs and stores the results in
+tests/golden/post_*.npz; tests/test_oracle_golden.py compares.  The Sim(3) solve itself lives in pytheia 0.2.9
+(third-party C++, absent offline): `umeyama` restates the published closed form (Umeyama 1991) and is checked by
+known-answer tests only — PARITY UNPINNED for that step.
+"""
+from __future__ import annotations
+
+from functools import partial
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+
+# ------------------------------------------------------------------------------------------------ masks & scale
+def depth_edge(depth: torch.Tensor, rtol: float, kernel_size: int = 3) -> torch.Tensor:
+    """pi3/utils/geometry.py:347-375 (mask=None, atol=None)."""
+    shape = depth.shape
+    d = depth.reshape(-1, 1, *shape[-2:])
+    diff = F.max_pool2d(d, kernel_size, stride=1, padding=kernel_size // 2) + \
+        F.max_pool2d(-d, kernel_size, stride=1, padding=kernel_size // 2)
+    edge = (diff / d).nan_to_num_() > rtol
+    return edge.reshape(*shape)
+
+
+def compute_masks(conf: torch.Tensor, local_points: torch.Tensor) -> torch.Tensor:
+    """OfflineChunkCreator._compute_masks (slam/offline_chunk_creator.py:114-119).  conf (..., H, W, 1)."""
+    masks = torch.sigmoid(conf[..., 0]) > 0.1
+    return torch.logical_and(masks, ~depth_edge(local_points[..., 2], rtol=0.03))
+
+
+def scale_factor(moge_depth: torch.Tensor, pi3_depth: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
+    """_get_scale_factor_for_pi3 (offline_chunk_creator.py:121-127): torch lower median of the masked ratio."""
+    return (moge_depth[mask] / pi3_depth[mask]).median()
+
+
+# ------------------------------------------------------------------------------------------------ keypoints
+def grid_spacing(H: int, W: int, max_kp: int) -> int:
+    """GridKeypointExtractor._calculate_grid_spacing (utils/keypoint_extraction.py:53-90)."""
+    margin = min(H, W) * 0.05
+    eh, ew = H - 2 * margin, W - 2 * margin
+    if eh <= 0 or ew <= 0:
+        return max(H, W)
+    spacing = int(np.sqrt((eh * ew) / max_kp))
+    return max(8, min(spacing, min(H, W) // 4))
+
+
+def grid_keypoints(num_frames: int, H: int, W: int, max_kp: int,
+                   generator: Optional[torch.Generator] = None) -> torch.Tensor:
+    """GridKeypointExtractor.extract (keypoint_extraction.py:92-171): (N, K, 2) float32 (x, y).  When the grid has more
+    than max_kp points the reference draws torch.randperm per frame; pass a seeded CPU generator to pin it."""
+    out = []
+    for _ in range(num_frames):
+        sp = grid_spacing(H, W, max_kp)
+        margin = min(H, W) * 0.05
+        gx = torch.arange(margin, W - margin, sp)
+        gy = torch.arange(margin, H - margin, sp)
+        if len(gx) == 0 or len(gy) == 0:
+            coords = torch.tensor([[W // 2, H // 2]], dtype=torch.float32)
+        else:
+            yy, xx = torch.meshgrid(gy, gx, indexing="ij")
+            coords = torch.stack([xx.flatten(), yy.flatten()], dim=-1)
+        if len(coords) > max_kp:
+            idx = torch.randperm(len(coords), generator=generator)[:max_kp]
+            coords = coords[idx]
+        out.append(coords)
+    return torch.stack(out, dim=0)
+
+
+def _norm_grid(keypoints: torch.Tensor, H: int, W: int) -> torch.Tensor:
+    gx = (keypoints[:, :, 0] / (W - 1)) * 2 - 1
+    gy = (keypoints[:, :, 1] / (H - 1)) * 2 - 1
+    return torch.stack([gx, gy], dim=-1).unsqueeze(1)
+
+
+def keypoint_colors(images: torch.Tensor, keypoints: torch.Tensor) -> torch.Tensor:
+    """GridKeypointExtractor._interpolate_colors (keypoint_extraction.py:203-229): (N,3,H,W),(N,K,2) -> uint8 (N,K,3)."""
+    H, W = images.shape[-2:]
+    colors = F.grid_sample(images, _norm_grid(keypoints, H, W), mode="bilinear", align_corners=False,
+                           padding_mode="border")
+    colors = colors.squeeze(2).transpose(1, 2)
+    return (colors * 255).to(torch.uint8)
+
+
+def interpolate_at_keypoints(points, local_points, conf, masks, keypoints, H, W) -> Dict[str, torch.Tensor]:
+    """_interpolate_world_points_for_keypoints (offline_chunk_creator.py:129-159) + the fp16 pack (:231-241).
+    points/local_points (N,H,W,3), conf (N,H,W,1), masks (N,H,W) bool, keypoints (N,K,2)."""
+    grid = _norm_grid(keypoints, H, W)
+    gs = partial(F.grid_sample, grid=grid, align_corners=False, padding_mode="border")
+    p = gs(points.permute(0, 3, 1, 2), mode="bilinear").squeeze(2).permute(0, 2, 1)
+    lp = gs(local_points.permute(0, 3, 1, 2), mode="bilinear").squeeze(2).permute(0, 2, 1)
+    c = gs(conf.permute(0, 3, 1, 2), mode="nearest").squeeze(2).permute(0, 2, 1)
+    m = gs(masks.unsqueeze(1).float(), mode="nearest").squeeze(2).permute(0, 2, 1).bool()
+    return dict(points=p.to(torch.float16), local_points=lp.to(torch.float16), conf=c.to(torch.float16), masks=m,
+                keypoints=keypoints.to(torch.float16))
+
+
+# ------------------------------------------------------------------------------------------------ intrinsics
+def normalized_view_plane_uv(width: int, height: int) -> torch.Tensor:
+    """utils/geometry_torch.py:39-51."""
+    ar = width / height
+    sx = ar / (1 + ar ** 2) ** 0.5
+    sy = 1 / (1 + ar ** 2) ** 0.5
+    u = torch.linspace(-sx * (width - 1) / width, sx * (width - 1) / width, width, dtype=torch.float32)
+    v = torch.linspace(-sy * (height - 1) / height, sy * (height - 1) / height, height, dtype=torch.float32)
+    u, v = torch.meshgrid(u, v, indexing="xy")
+    return torch.stack([u, v], dim=-1)
+
+
+def solve_optimal_focal_shift(uv: np.ndarray, xyz: np.ndarray) -> Tuple[np.ndarray, float]:
+    """utils/geometry_numpy.py:79-96 (scipy Levenberg-Marquardt on the shift, closed-form focal)."""
+    from scipy.optimize import least_squares
+    uv, xy, z = uv.reshape(-1, 2), xyz[..., :2].reshape(-1, 2), xyz[..., 2].reshape(-1)
+
+    def fn(shift):
+        xy_proj = xy / (z + shift)[:, None]
+        f = (xy_proj * uv).sum() / np.square(xy_proj).sum()
+        return (f * xy_proj - uv).ravel()
+
+    sol = least_squares(fn, x0=0, ftol=1e-3, method="lm")
+    shift = sol["x"].squeeze().astype(np.float32)
+    xy_proj = xy / (z + shift)[:, None]
+    focal = (xy_proj * uv).sum() / np.square(xy_proj).sum()
+    return shift, focal
+
+
+def recover_focal_shift(points: torch.Tensor, mask: torch.Tensor, size=(64, 64)):
+    """utils/geometry_torch.py:114-169.  points (N,H,W,3), mask (N,H,W) -> focal (N,), shift (N,) float32."""
+    N, H, W = points.shape[:3]
+    uv = normalized_view_plane_uv(W, H)
+    p_lr = F.interpolate(points.permute(0, 3, 1, 2), size, mode="nearest").permute(0, 2, 3, 1).numpy()
+    uv_lr = F.interpolate(uv.unsqueeze(0).permute(0, 3, 1, 2), size, mode="nearest").squeeze(0).permute(1, 2, 0).numpy()
+    m_lr = (F.interpolate(mask.to(torch.float32).unsqueeze(1), size, mode="nearest").squeeze(1) > 0).numpy()
+    focal, shift = [], []
+    for i in range(N):
+        pi, ui = p_lr[i][m_lr[i]], uv_lr[m_lr[i]]
+        if ui.shape[0] < 2:
+            focal.append(1.0)
+            shift.append(0.0)
+            continue
+        s, f = solve_optimal_focal_shift(ui, pi)
+        focal.append(float(f))
+        shift.append(float(s))
+    return torch.tensor(focal, dtype=torch.float32), torch.tensor(shift, dtype=torch.float32)
+
+
+def estimate_camera_parameters(local_points: torch.Tensor, conf: torch.Tensor) -> Dict[str, torch.Tensor]:
+    """utils/camera_estimation.py:12-70 for one chunk.  local_points (N,H,W,3), conf (N,H,W,1).  The matrix is
+    utils3d.torch.intrinsics_from_focal_center(fx, fy, cx, cy) = [[fx,0,cx],[0,fy,cy],[0,0,1]] (:56-57)."""
+    N, H, W = local_points.shape[:3]
+    masks = torch.sigmoid(conf[..., 0]) > 0.1
+    ar = W / H
+    focal, shift = recover_focal_shift(local_points, masks)
+    fx = focal / 2 * (1 + ar ** 2) ** 0.5 / ar * W
+    fy = focal / 2 * (1 + ar ** 2) ** 0.5 * H
+    cx = torch.full_like(fx, W // 2)
+    cy = torch.full_like(fy, H // 2)
+    K = torch.zeros(N, 3, 3)
+    K[:, 0, 0], K[:, 1, 1], K[:, 0, 2], K[:, 1, 2], K[:, 2, 2] = fx, fy, cx, cy, 1.0
+    return dict(intrinsics=K, focal=focal[None], shift=shift[None], fx=fx[None], fy=fy[None], cx=cx[None], cy=cy[None])
+
+
+# ------------------------------------------------------------------------------------------------ chunk layout
+def chunk_indices(n_frames: int, chunk_length: int, overlap: int) -> List[Tuple[int, int]]:
+    """ChunkImageDataset chunk list (datasets/image_datasets.py:40-47): starts 0, cl-ov, 2(cl-ov), ... while
+    start < n; a chunk is kept if it has at least 2 frames.  The loop does NOT stop at the first chunk that reaches the
+    end, so e.g. 32 frames, cl=32, ov=8 gives (0,32) and a tail (24,32) made only of overlap frames."""
+    out = []
+    start = 0
+    while start < n_frames:
+        end = min(start + chunk_length, n_frames)
+        if end - start >= 2:
+            out.append((start, end))
+        start += chunk_length - overlap
+    return out
+
+
+def create_view_graph_matches(chunk_size: int, overlap_size: int) -> List[Tuple[int, int]]:
+    """utils/reconstruction_alignment.py:16-37."""
+    return [(chunk_size - overlap_size + i, i) for i in range(overlap_size)]
+
+
+# ------------------------------------------------------------------------------------------------ Sim(3)
+def match_keypoints(kp_ref: np.ndarray, kp_qry: np.ndarray) -> np.ndarray:
+    """Common tracks by feature (reconstruction_alignment.py:74): for overlap view v and qry keypoint j the index of
+    the FIRST ref keypoint with bit-identical fp16 (x, y), else -1.  kp_*: (ov, K, 2) float16."""
+    ov, K = kp_ref.shape[:2]
+    r = kp_ref.view(np.uint16).astype(np.uint32)
+    q = kp_qry.view(np.uint16).astype(np.uint32)
+    rk = r[..., 0] | (r[..., 1] << 16)
+    qk = q[..., 0] | (q[..., 1] << 16)
+    idx = np.full((ov, K), -1, dtype=np.int32)
+    for v in range(ov):
+        first = {}
+        for j in range(K - 1, -1, -1):
+            first[int(rk[v, j])] = j
+        for j in range(K):
+            idx[v, j] = first.get(int(qk[v, j]), -1)
+    return idx
+
+
+def umeyama(x: np.ndarray, y: np.ndarray):
+    """Closed-form similarity y ~ s R x + t (Umeyama 1991), float64.  Returns s, R, t, 4x4."""
+    x, y = np.asarray(x, np.float64), np.asarray(y, np.float64)
+    mx, my = x.mean(0), y.mean(0)
+    xc, yc = x - mx, y - my
+    Sg = yc.T @ xc / len(x)
+    varx = (xc ** 2).sum() / len(x)
+    U, D, Vt = np.linalg.svd(Sg)
+    S = np.diag([1.0, 1.0, np.sign(np.linalg.det(U) * np.linalg.det(Vt))])
+    R = U @ S @ Vt
+    s = np.trace(np.diag(D) @ S) / varx
+    t = my - s * R @ mx
+    M = np.eye(4)
+    M[:3, :3], M[:3, 3] = s * R, t
+    return s, R, t, M
+
+
+def align_chunks(pts_ref: np.ndarray, pts_qry: np.ndarray, kp_ref: np.ndarray, kp_qry: np.ndarray,
+                 last_ref_pose: np.ndarray, use_filter: bool = True,
+                 w_ref: Optional[np.ndarray] = None, w_qry: Optional[np.ndarray] = None):
+    """Steps 1-3 of align_and_refine_reconstructions (reconstruction_alignment.py:74-105) on chunk-file data:
+    pts_* (ov, K, 3) float16 world points of the overlap views, kp_* (ov, K, 2) float16, last_ref_pose (4,4) float32."""
+    idx = match_keypoints(kp_ref, kp_qry)
+    ov, K = idx.shape
+    ref, qry = [], []
+    for v in range(ov):
+        for j in range(K):
+            r = idx[v, j]
+            if r < 0:
+                continue
+            if w_qry is not None and not w_qry[v, j]:
+                continue
+            if w_ref is not None and not w_ref[v, r]:
+                continue
+            ref.append(pts_ref[v, r].astype(np.float64))
+            qry.append(pts_qry[v, j].astype(np.float64))
+    ref, qry = np.array(ref).reshape(-1, 3), np.array(qry).reshape(-1, 3)
+    n_common = len(ref)
+    med = np.inf
+    if use_filter and n_common:
+        cam = last_ref_pose[:3, 3].astype(np.float64)
+        dist = np.linalg.norm(ref - cam, axis=1)
+        med = np.median(dist)
+        keep = dist < med
+        ref, qry = ref[keep], qry[keep]
+    s, R, t, M = umeyama(qry, ref)
+    rms = np.sqrt((((s * (R @ qry.T)).T + t - ref) ** 2).sum(1).mean())
+    return dict(idx=idx, s=s, R=R, t=t, M=M, n_used=len(ref), n_common=n_common, median=med, rms=rms)
+
+
+def apply_sim3(M: np.ndarray, pts: np.ndarray, poses: np.ndarray):
+    """TransformReconstruction4 (reconstruction_alignment.py:105) on points (n,3) and cam->world poses (F,4,4)."""
+    sR, t = M[:3, :3], M[:3, 3]
+    s = np.linalg.norm(sR[:, 0])
+    p2 = (sR @ pts.astype(np.float64).T).T + t
+    P2 = poses.astype(np.float64).copy()
+    P2[:, :3, :3] = (sR / s) @ poses[:, :3, :3].astype(np.float64)
+    P2[:, :3, 3] = (sR @ poses[:, :3, 3].astype(np.float64).T).T + t
+    return p2, P2

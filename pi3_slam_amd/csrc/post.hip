@@ -244,3 +244,237 @@ extern "C" int pi3_gather_keypoints(const float* points, const float* local_poin
                      (__half*)o_local, (__half*)o_conf, o_mask, (__half*)o_colors, (__half*)o_kps);
   return pi3_check_launch("gather_keypoints");
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Per-frame focal / shift recovery = estimate_camera_parameters (utils/camera_estimation.py:12-70) ->
+// recover_focal_shift (utils/geometry_torch.py:114-169) -> solve_optimal_focal_shift (utils/geometry_numpy.py:79-96).
+//   * nearest 64x64 down-sampling of local_points, uv and mask = sigmoid(conf) > 0.1 (F.interpolate 'nearest':
+//     src = floor(dst * in/out) in fp32);
+//   * scipy.optimize.least_squares(fn, x0=0, ftol=1e-3, method='lm') on the z-shift, i.e. MINPACK lmdif with n = 1,
+//     forward-difference Jacobian (epsfcn = DBL_EPSILON), diag = 1 (mode 2), factor = 100, xtol = gtol = 1e-8,
+//     maxfev = 200.  With n = 1 the QR factorisation collapses to r = |J|, q^T f = J.f / |J|, so the whole solver is
+//     a handful of fp64 reductions over <= 4096 points; residual fn(shift) = f * xy/(z+shift) - uv with the closed
+//     form f = sum(xyp.uv) / sum(xyp^2).  The 100 frames of a chunk are 100 independent workgroups instead of the
+//     reference's serial python loop (geometry_torch.py:149-161).
+//   * fx, fy, cx, cy and the 3x3 matrix (camera_estimation.py:47-57) in fp32 with the reference's operation order.
+// uvx [W], uvy [H]: the fp32 torch.linspace tables of normalized_view_plane_uv (geometry_torch.py:39-51), host built.
+// ---------------------------------------------------------------------------------------------------------------
+#define FS_N 64
+struct FsPoint { float x, y, z, u, v; };
+
+__device__ __forceinline__ double fs_block_sum(double v, double* red, int tid) {
+  v = wave_sum_f64(v);
+  __syncthreads();
+  if ((tid & 63) == 0) red[tid >> 6] = v;
+  __syncthreads();
+  return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// sums needed for the closed-form focal at a given shift
+__device__ __forceinline__ void fs_focal(const FsPoint* pts, int n, double shift, double* red, int tid, double& f) {
+  double a = 0.0, b = 0.0;
+  for (int i = tid; i < n; i += 256) {
+    const double inv = 1.0 / ((double)pts[i].z + shift);
+    const double px = pts[i].x * inv, py = pts[i].y * inv;
+    a += px * (double)pts[i].u + py * (double)pts[i].v;
+    b += px * px + py * py;
+  }
+  a = fs_block_sum(a, red, tid);
+  b = fs_block_sum(b, red, tid);
+  f = a / b;
+}
+
+__device__ __forceinline__ double fs_resnorm2(const FsPoint* pts, int n, double shift, double f, double* red,
+                                              int tid) {
+  double s = 0.0;
+  for (int i = tid; i < n; i += 256) {
+    const double inv = 1.0 / ((double)pts[i].z + shift);
+    const double ex = f * pts[i].x * inv - (double)pts[i].u, ey = f * pts[i].y * inv - (double)pts[i].v;
+    s += ex * ex + ey * ey;
+  }
+  return fs_block_sum(s, red, tid);
+}
+
+__global__ __launch_bounds__(256) void focal_shift_kernel(const float* __restrict__ local_points,
+                                                          const float* __restrict__ conf,
+                                                          const float* __restrict__ uvx,
+                                                          const float* __restrict__ uvy, int H, int W, float conf_thr,
+                                                          float* __restrict__ o_focal, float* __restrict__ o_shift,
+                                                          float* __restrict__ o_fxfycxcy, float* __restrict__ o_K) {
+  __shared__ FsPoint pts[FS_N * FS_N];
+  __shared__ double red[4];
+  __shared__ int s_n;
+  __shared__ int woff[5];
+  const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const long fo = (long)f * H * W;
+  const float sy = (float)H / (float)FS_N, sx = (float)W / (float)FS_N;
+  // ordered compaction (row-major like numpy boolean indexing) so the point order, hence the summation order inside a
+  // thread's strided subset, is deterministic
+  if (tid == 0) s_n = 0;
+  __syncthreads();
+  for (int base = 0; base < FS_N * FS_N; base += 256) {
+    const int k = base + tid;
+    const int i = k / FS_N, j = k - i * FS_N;
+    const int yy = min((int)floorf(i * sy), H - 1), xx = min((int)floorf(j * sx), W - 1);
+    const long p = fo + (long)yy * W + xx;
+    const bool ok = (1.0f / (1.0f + expf(-conf[p]))) > conf_thr;
+    const unsigned long long bal = __ballot(ok);
+    const int before = __popcll(bal & ((1ull << lane) - 1ull));
+    if (lane == 0) woff[wave + 1] = __popcll(bal);
+    __syncthreads();
+    if (tid == 0) {
+      woff[0] = s_n;
+      for (int w = 1; w <= 4; ++w) woff[w] += woff[w - 1];
+      s_n = woff[4];
+    }
+    __syncthreads();
+    if (ok) {
+      FsPoint q;
+      q.x = local_points[3 * p]; q.y = local_points[3 * p + 1]; q.z = local_points[3 * p + 2];
+      q.u = uvx[xx]; q.v = uvy[yy];
+      pts[woff[wave] + before] = q;
+    }
+    __syncthreads();
+  }
+  const int n = s_n;
+  double x = 0.0, focal = 1.0;
+  if (n >= 2) {
+    const double epsmch = 2.220446049250313e-16, ftol = 1e-3, xtol = 1e-8, gtol = 1e-8, factor = 100.0;
+    const double p1 = 0.1, p5 = 0.5, p25 = 0.25, p75 = 0.75, p0001 = 1e-4, dwarf = 2.2250738585072014e-308;
+    double fx_; fs_focal(pts, n, x, red, tid, fx_);
+    double fnorm = sqrt(fs_resnorm2(pts, n, x, fx_, red, tid));
+    int nfev = 1, iter = 1, info = 0;
+    double par = 0.0, delta = 0.0, xnorm = 0.0;
+    const int maxfev = 200;
+    while (info == 0) {
+      // forward-difference Jacobian column J = (fn(x+h) - fn(x)) / h
+      const double eps = sqrt(epsmch);
+      double h = eps * fabs(x);
+      if (h == 0.0) h = eps;
+      double fh; fs_focal(pts, n, x + h, red, tid, fh);
+      ++nfev;
+      double jj = 0.0, jf = 0.0;
+      for (int i = tid; i < n; i += 256) {
+        const double inv0 = 1.0 / ((double)pts[i].z + x), inv1 = 1.0 / ((double)pts[i].z + (x + h));
+        const double e0x = fx_ * pts[i].x * inv0 - (double)pts[i].u, e0y = fx_ * pts[i].y * inv0 - (double)pts[i].v;
+        const double e1x = fh * pts[i].x * inv1 - (double)pts[i].u, e1y = fh * pts[i].y * inv1 - (double)pts[i].v;
+        const double jx = (e1x - e0x) / h, jy = (e1y - e0y) / h;
+        jj += jx * jx + jy * jy;
+        jf += jx * e0x + jy * e0y;
+      }
+      jj = fs_block_sum(jj, red, tid);
+      jf = fs_block_sum(jf, red, tid);
+      const double r = sqrt(jj);                       // |R| of the 1-column QR; acnorm
+      const double qtf = r != 0.0 ? jf / r : 0.0;      // |q^T f|-signed so that qtf / r == J.f / |J|^2
+      if (iter == 1) {
+        xnorm = fabs(x);
+        delta = factor * xnorm;
+        if (delta == 0.0) delta = factor;
+      }
+      double gnorm = 0.0;
+      if (fnorm != 0.0 && r != 0.0) gnorm = fabs(r * (qtf / fnorm) / r);
+      if (gnorm <= gtol) { info = 4; break; }
+      double ratio = 0.0;
+      do {
+        // ---- lmpar, n = 1, diag = 1
+        double p = r != 0.0 ? qtf / r : 0.0;          // Gauss-Newton step (to be negated)
+        {
+          double dxnorm = fabs(p), fp = dxnorm - delta;
+          int it = 0;
+          if (fp <= p1 * delta) {
+            par = 0.0;
+          } else {
+            double parl = 0.0;
+            if (r != 0.0) { const double t = (1.0) / r; const double tn = fabs(t); parl = ((fp / delta) / tn) / tn; }
+            const double gn = fabs(r * qtf);
+            double paru = gn / delta;
+            if (paru == 0.0) paru = dwarf / fmin(delta, p1);
+            par = fmax(par, parl);
+            par = fmin(par, paru);
+            if (par == 0.0) par = gn / dxnorm;
+            for (;;) {
+              ++it;
+              if (par == 0.0) par = fmax(dwarf, 0.001 * paru);
+              const double sd = sqrt(r * r + par);     // R of [r; sqrt(par)]
+              p = r * qtf / (sd * sd);
+              dxnorm = fabs(p);
+              const double tmp = fp;
+              fp = dxnorm - delta;
+              if (fabs(fp) <= p1 * delta || (parl == 0.0 && fp <= tmp && tmp < 0.0) || it == 10) break;
+              const double w = (1.0) / sd;             // diag * (wa2 / dxnorm) solved with R^T: |.| = 1 / sd
+              const double parc = ((fp / delta) / w) / w;
+              if (fp > 0.0) parl = fmax(parl, par);
+              if (fp < 0.0) paru = fmin(paru, par);
+              par = fmax(parl, par + parc);
+            }
+          }
+        }
+        const double step = -p;
+        const double xnew = x + step;
+        const double pnorm = fabs(step);
+        if (iter == 1) delta = fmin(delta, pnorm);
+        double fnew; fs_focal(pts, n, xnew, red, tid, fnew);
+        const double fnorm1 = sqrt(fs_resnorm2(pts, n, xnew, fnew, red, tid));
+        ++nfev;
+        double actred = -1.0;
+        if (p1 * fnorm1 < fnorm) { const double q = fnorm1 / fnorm; actred = 1.0 - q * q; }
+        const double temp1 = fabs(r * step) / fnorm, temp2 = sqrt(par) * pnorm / fnorm;
+        const double prered = temp1 * temp1 + temp2 * temp2 / p5;
+        const double dirder = -(temp1 * temp1 + temp2 * temp2);
+        ratio = prered != 0.0 ? actred / prered : 0.0;
+        if (ratio <= p25) {
+          double temp = actred >= 0.0 ? p5 : p5 * dirder / (dirder + p5 * actred);
+          if (p1 * fnorm1 >= fnorm || temp < p1) temp = p1;
+          delta = temp * fmin(delta, pnorm / p1);
+          par = par / temp;
+        } else if (par == 0.0 || ratio >= p75) {
+          delta = pnorm / p5;
+          par = p5 * par;
+        }
+        if (ratio >= p0001) {
+          x = xnew; fx_ = fnew; xnorm = fabs(x); fnorm = fnorm1; ++iter;
+        }
+        if (fabs(actred) <= ftol && prered <= ftol && p5 * ratio <= 1.0) info = 1;
+        if (delta <= xtol * xnorm) info = 2;
+        if (fabs(actred) <= ftol && prered <= ftol && p5 * ratio <= 1.0 && info == 2) info = 3;
+        if (info != 0) break;
+        if (nfev >= maxfev) info = 5;
+        if (fabs(actred) <= epsmch && prered <= epsmch && p5 * ratio <= 1.0) info = 6;
+        if (delta <= epsmch * xnorm) info = 7;
+        if (gnorm <= epsmch) info = 8;
+        if (info != 0) break;
+      } while (ratio < p0001);
+    }
+    // optim_shift is cast to float32 BEFORE the final focal evaluation (geometry_numpy.py:91-94)
+    const float xs = (float)x;
+    fs_focal(pts, n, (double)xs, red, tid, focal);
+    x = (double)xs;
+  } else {
+    x = 0.0; focal = 1.0;  // geometry_torch.py:152-155
+  }
+  if (tid == 0) {
+    const float fo32 = (float)focal;
+    o_focal[f] = fo32;
+    o_shift[f] = (float)x;
+    const double ar = (double)W / (double)H;
+    const float c1 = (float)sqrt(1.0 + ar * ar), arf = (float)ar;
+    const float fxv = (((fo32 / 2.0f) * c1) / arf) * (float)W;   // camera_estimation.py:47
+    const float fyv = ((fo32 / 2.0f) * c1) * (float)H;           // :48
+    const float cxv = (float)(W / 2), cyv = (float)(H / 2);      // :51-52 (integer halves)
+    o_fxfycxcy[4 * f + 0] = fxv; o_fxfycxcy[4 * f + 1] = fyv; o_fxfycxcy[4 * f + 2] = cxv; o_fxfycxcy[4 * f + 3] = cyv;
+    float* K = o_K + 9 * f;
+    K[0] = fxv; K[1] = 0.f; K[2] = cxv; K[3] = 0.f; K[4] = fyv; K[5] = cyv; K[6] = 0.f; K[7] = 0.f; K[8] = 1.f;
+  }
+}
+
+extern "C" int pi3_focal_shift(const float* local_points, const float* conf, const float* uvx, const float* uvy,
+                               int F, int H, int W, float conf_thr, float* focal, float* shift, float* fxfycxcy,
+                               float* K33, void* stream) {
+  if (!local_points || !conf || !uvx || !uvy || !focal || !shift || !fxfycxcy || !K33 || F <= 0 || H <= 0 || W <= 0) {
+    pi3_set_error("pi3_focal_shift: bad arguments");
+    return PI3_ERR_ARG;
+  }
+  hipLaunchKernelGGL(focal_shift_kernel, dim3(F), dim3(256), 0, (hipStream_t)stream, local_points, conf, uvx, uvy, H,
+                     W, conf_thr, focal, shift, fxfycxcy, K33);
+  return pi3_check_launch("focal_shift");
+}

@@ -157,7 +157,7 @@ class Pi3Engine:
 
     # ------------------------------------------------------------------ transformer block
     def _block(self, prefix: str, x: torch.Tensor, S: int, attn_B: int, attn_S: int, T: int, consts, rope: bool,
-               qk_norm: bool, ls: bool, bufs) -> None:
+               qk_norm: bool, ls: bool, bufs, attn_events: Optional[list] = None) -> None:
         cfg, w = self.cfg, self.w
         D, H = cfg.dim, cfg.heads
         xn, qkv, ao, hid = bufs
@@ -172,7 +172,14 @@ class Pi3Engine:
                             w.get(f"{prefix}.attn.k_norm.weight") if qk_norm else None,
                             w.get(f"{prefix}.attn.k_norm.bias") if qk_norm else None,
                             eps=1e-5 if qk_norm else cfg.eps, qscale=ops.QSCALE, do_rope=rope)
-        ops.attention(qkv, ao, attn_B, attn_S, H)
+        if attn_events is not None:  # bench.py: HIP events on the launch stream around the dominant kernel
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            ops.attention(qkv, ao, attn_B, attn_S, H)
+            e1.record()
+            attn_events.append((e0, e1))
+        else:
+            ops.attention(qkv, ao, attn_B, attn_S, H)
         ops.gemm(ao, w[f"{prefix}.attn.proj.weight"], x, M=S, bias=w[f"{prefix}.attn.proj.bias"],
                  gamma=w[f"{prefix}.ls1.gamma"] if ls else None, resid=x)
         ops.layernorm(x, w[f"{prefix}.norm2.weight"], w[f"{prefix}.norm2.bias"], xn, cfg.eps, rows=S)
@@ -182,7 +189,8 @@ class Pi3Engine:
 
     # ------------------------------------------------------------------ forward
     @torch.no_grad()
-    def forward(self, imgs: torch.Tensor, return_intermediates: bool = False) -> Dict[str, torch.Tensor]:
+    def forward(self, imgs: torch.Tensor, return_intermediates: bool = False,
+                global_attn_events: Optional[list] = None) -> Dict[str, torch.Tensor]:
         cfg, w, dev = self.cfg, self.w, self.device
         assert imgs.ndim == 5 and imgs.shape[2] == 3, "expected (B, N, 3, H, W)"
         B, N, _, Himg, Wimg = imgs.shape
@@ -228,7 +236,8 @@ class Pi3Engine:
                 aB, aS = F, T
             else:
                 aB, aS = B, N * T
-            self._block(f"decoder.{i}", hidden, S, aB, aS, T, c, rope=True, qk_norm=True, ls=True, bufs=bufs)
+            self._block(f"decoder.{i}", hidden, S, aB, aS, T, c, rope=True, qk_norm=True, ls=True, bufs=bufs,
+                        attn_events=global_attn_events if i % 2 == 1 else None)
             if i == cfg.dec_depth - 2:
                 ops.cast_rows(hidden, cat[:, :D], rows=S, cols=D)
             if i == cfg.dec_depth - 1:

@@ -34,6 +34,7 @@ SIGNATURES = {
     "pi3_masked_ratio_median": [_vp, _vp, _l, _vp, _l, _vp, _vp],
     "pi3_apply_scale": [_vp, _vp, _vp, _l, _vp, _i, _vp],
     "pi3_gather_keypoints": [_vp] * 6 + [_i] * 4 + [_vp] * 7,
+    "pi3_focal_shift": [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp],
     "pi3_sim3_match_keypoints": [_vp, _vp, _i, _i, _vp, _vp],
     "pi3_sim3_umeyama": [_vp] * 5 + [_i, _i, _vp, _i, _vp, _vp],
     "pi3_sim3_apply": [_vp, _vp, _l, _vp, _i, _vp],

@@ -164,3 +164,131 @@ def camera_tail(feat: torch.Tensor, T: int, tok_off: int, F: int, P: int, w: dic
                              g("camera_head.fc_rot.weight"), g("camera_head.fc_rot.bias"),
                              poses.data_ptr(), _L.stream_ptr())
     _L.check(rc, "pi3_camera_tail")
+
+
+# ----------------------------------------------------------------------------------------------- post-processing
+def compute_masks(conf: torch.Tensor, local_points: torch.Tensor, conf_thr: float = 0.1,
+                  rtol: float = 0.03) -> torch.Tensor:
+    """conf [F,H,W,1] or [F,H,W], local_points [F,H,W,3] (f32, contiguous) -> uint8 mask [F,H,W]."""
+    lib = _L.load()
+    F, H, W = local_points.shape[:3]
+    assert conf.is_contiguous() and local_points.is_contiguous() and conf.numel() == F * H * W
+    out = torch.empty(F, H, W, device=conf.device, dtype=torch.uint8)
+    rc = lib.pi3_compute_masks(conf.data_ptr(), local_points.data_ptr(), F, H, W, float(conf_thr), float(rtol),
+                               out.data_ptr(), _L.stream_ptr())
+    _L.check(rc, "pi3_compute_masks")
+    return out
+
+
+def masked_ratio_median(num: torch.Tensor, den: torch.Tensor, den_stride: int, mask: torch.Tensor,
+                        n: int) -> torch.Tensor:
+    """-> device tensor [median, count] (f32).  den is addressed as den_ptr[i * den_stride]."""
+    lib = _L.load()
+    assert num.dtype == torch.float32 and den.dtype == torch.float32 and mask.dtype == torch.uint8
+    out = torch.empty(2, device=num.device, dtype=torch.float32)
+    rc = lib.pi3_masked_ratio_median(num.data_ptr(), den.data_ptr(), den_stride, mask.data_ptr(), n, out.data_ptr(),
+                                     _L.stream_ptr())
+    _L.check(rc, "pi3_masked_ratio_median")
+    return out
+
+
+def apply_scale(scale_dev: torch.Tensor, local_points: torch.Tensor, points: torch.Tensor,
+                poses: torch.Tensor) -> None:
+    lib = _L.load()
+    assert local_points.is_contiguous() and points.is_contiguous() and poses.is_contiguous()
+    F = poses.numel() // 16
+    rc = lib.pi3_apply_scale(scale_dev.data_ptr(), local_points.data_ptr(), points.data_ptr(), local_points.numel(),
+                             poses.data_ptr(), F, _L.stream_ptr())
+    _L.check(rc, "pi3_apply_scale")
+
+
+def gather_keypoints(points, local_points, conf, masks, images, keypoints):
+    """Dense maps [F,H,W,*] + keypoints f32 [F,K,2] -> dict of packed per-keypoint tensors (fp16 / bool)."""
+    lib = _L.load()
+    F, H, W = points.shape[:3]
+    K = keypoints.shape[1]
+    dev = points.device
+    for t in (points, local_points, conf, masks, keypoints):
+        assert t.is_contiguous()
+    assert keypoints.dtype == torch.float32 and masks.dtype == torch.uint8
+    o_points = torch.empty(F, K, 3, device=dev, dtype=torch.float16)
+    o_local = torch.empty(F, K, 3, device=dev, dtype=torch.float16)
+    o_conf = torch.empty(F, K, 1, device=dev, dtype=torch.float16)
+    o_mask = torch.empty(F, K, 1, device=dev, dtype=torch.uint8)
+    o_kps = torch.empty(F, K, 2, device=dev, dtype=torch.float16)
+    o_colors = torch.empty(F, K, 3, device=dev, dtype=torch.float16) if images is not None else None
+    if images is not None:
+        assert images.is_contiguous() and images.dtype == torch.float32 and tuple(images.shape) == (F, 3, H, W)
+    rc = lib.pi3_gather_keypoints(points.data_ptr(), local_points.data_ptr(), conf.data_ptr(), masks.data_ptr(),
+                                  _L.ptr(images), keypoints.data_ptr(), F, H, W, K, o_points.data_ptr(),
+                                  o_local.data_ptr(), o_conf.data_ptr(), o_mask.data_ptr(), _L.ptr(o_colors),
+                                  o_kps.data_ptr(), _L.stream_ptr())
+    _L.check(rc, "pi3_gather_keypoints")
+    return dict(points=o_points, local_points=o_local, conf=o_conf, masks=o_mask.bool(), colors=o_colors,
+                keypoints=o_kps)
+
+
+# ----------------------------------------------------------------------------------------------- Sim(3) alignment
+def sim3_match_keypoints(kp_ref: torch.Tensor, kp_qry: torch.Tensor) -> torch.Tensor:
+    """kp_*: f16 [ov, K, 2] -> int32 [ov, K] (index into the ref view's keypoints or -1)."""
+    lib = _L.load()
+    assert kp_ref.dtype == torch.float16 and kp_qry.dtype == torch.float16
+    assert kp_ref.is_contiguous() and kp_qry.is_contiguous() and kp_ref.shape == kp_qry.shape
+    ov, K = kp_ref.shape[:2]
+    idx = torch.empty(ov, K, device=kp_ref.device, dtype=torch.int32)
+    rc = lib.pi3_sim3_match_keypoints(kp_ref.data_ptr(), kp_qry.data_ptr(), ov, K, idx.data_ptr(), _L.stream_ptr())
+    _L.check(rc, "pi3_sim3_match_keypoints")
+    return idx
+
+
+def sim3_umeyama(pts_ref: torch.Tensor, pts_qry: torch.Tensor, idx: torch.Tensor, last_ref_pose: torch.Tensor,
+                 w_ref: Optional[torch.Tensor] = None, w_qry: Optional[torch.Tensor] = None,
+                 use_filter: bool = True) -> torch.Tensor:
+    """-> f64 device tensor [33]: s, R(9), t(3), M(16), n_used, n_common, median, rms."""
+    lib = _L.load()
+    assert pts_ref.dtype == torch.float16 and pts_qry.dtype == torch.float16 and idx.dtype == torch.int32
+    assert pts_ref.is_contiguous() and pts_qry.is_contiguous() and idx.is_contiguous()
+    assert last_ref_pose.dtype == torch.float32 and last_ref_pose.is_contiguous()
+    ov, K = idx.shape
+    out = torch.empty(33, device=idx.device, dtype=torch.float64)
+    rc = lib.pi3_sim3_umeyama(pts_ref.data_ptr(), pts_qry.data_ptr(), idx.data_ptr(), _L.ptr(w_ref), _L.ptr(w_qry),
+                              ov, K, last_ref_pose.data_ptr(), int(use_filter), out.data_ptr(), _L.stream_ptr())
+    _L.check(rc, "pi3_sim3_umeyama")
+    return out
+
+
+def sim3_apply(M4: torch.Tensor, pts: Optional[torch.Tensor], poses: Optional[torch.Tensor]) -> None:
+    lib = _L.load()
+    assert M4.dtype == torch.float64 and M4.numel() >= 16
+    n = 0 if pts is None else pts.numel() // 3
+    F = 0 if poses is None else poses.numel() // 16
+    rc = lib.pi3_sim3_apply(M4.data_ptr(), _L.ptr(pts), n, _L.ptr(poses), F, _L.stream_ptr())
+    _L.check(rc, "pi3_sim3_apply")
+
+
+def sim3_compose_prefix(T: torch.Tensor) -> torch.Tensor:
+    lib = _L.load()
+    assert T.dtype == torch.float64 and T.is_contiguous()
+    n = T.numel() // 16
+    G = torch.empty_like(T)
+    rc = lib.pi3_sim3_compose_prefix(T.data_ptr(), G.data_ptr(), n, _L.stream_ptr())
+    _L.check(rc, "pi3_sim3_compose_prefix")
+    return G
+
+
+def focal_shift(local_points: torch.Tensor, conf: torch.Tensor, uvx: torch.Tensor, uvy: torch.Tensor,
+                conf_thr: float = 0.1):
+    """local_points [F,H,W,3], conf [F,H,W,(1)] f32 -> dict(focal [F], shift [F], fxfycxcy [F,4], intrinsics [F,3,3])."""
+    lib = _L.load()
+    F, H, W = local_points.shape[:3]
+    assert local_points.is_contiguous() and conf.is_contiguous() and uvx.numel() == W and uvy.numel() == H
+    dev = local_points.device
+    focal = torch.empty(F, device=dev, dtype=torch.float32)
+    shift = torch.empty(F, device=dev, dtype=torch.float32)
+    fxy = torch.empty(F, 4, device=dev, dtype=torch.float32)
+    K = torch.empty(F, 3, 3, device=dev, dtype=torch.float32)
+    rc = lib.pi3_focal_shift(local_points.data_ptr(), conf.data_ptr(), uvx.data_ptr(), uvy.data_ptr(), F, H, W,
+                             float(conf_thr), focal.data_ptr(), shift.data_ptr(), fxy.data_ptr(), K.data_ptr(),
+                             _L.stream_ptr())
+    _L.check(rc, "pi3_focal_shift")
+    return dict(focal=focal, shift=shift, fxfycxcy=fxy, intrinsics=K)

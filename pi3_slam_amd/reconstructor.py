@@ -1,0 +1,194 @@
+"""OfflineReconstructor: mirror of slam/offline_reconstructor.py (same constructor, run(), input layout
+<chunk_dir>/chunks/chunk_*.pt + chunk_metadata.json, outputs final_points.ply / final_camera_poses.ply /
+trajectory_tum.txt) for the part of stage 2 that is on the hot path: progressive overlap Sim(3) alignment of the
+chunks (offline_reconstructor.py:93-133 -> utils/reconstruction_alignment.py:74-105).
+
+What the reference additionally does through pytheia/Ceres — per-chunk bundle adjustment
+(utils/chunk_reconstruction.py:192-219) and the prior-constrained BA after each alignment
+(reconstruction_alignment.py:107-171) — is third-party C++ outside this path and is not done here, so
+trajectories equal the reference's only up to those refinements.
+"""
+from __future__ import annotations
+
+import glob
+import json
+import os
+import struct
+import time
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+
+from .alignment import align_and_refine_reconstructions, create_view_graph_matches
+
+
+def _view_name(p) -> str:
+    """image_paths entries are str, 1-lists or 1-tuples depending on the DataLoader collate/pin path."""
+    while isinstance(p, (list, tuple)):
+        p = p[0] if p else "frame"
+    return os.path.basename(str(p))
+
+
+def write_ply(points: np.ndarray, colors: np.ndarray, path: str) -> None:
+    """Binary little-endian PLY with float xyz + uchar rgb (the layout pi3/utils/basic.py:377-460 writes)."""
+    points = np.asarray(points, np.float32).reshape(-1, 3)
+    colors = np.asarray(colors, np.float32).reshape(-1, 3)
+    if colors.size and colors.max() <= 1.0:
+        colors = colors * 255.0
+    rgb = np.clip(colors, 0, 255).astype(np.uint8)
+    with open(path, "wb") as f:
+        f.write((f"ply\nformat binary_little_endian 1.0\nelement vertex {len(points)}\nproperty float x\n"
+                 "property float y\nproperty float z\nproperty uchar red\nproperty uchar green\n"
+                 "property uchar blue\nend_header\n").encode())
+        rec = np.empty(len(points), dtype=[("xyz", "<f4", 3), ("rgb", "u1", 3)])
+        rec["xyz"], rec["rgb"] = points, rgb
+        f.write(rec.tobytes())
+
+
+class OfflineReconstructor:
+    def __init__(self, chunk_dir: str, output_dir: str, chunk_length: Optional[int] = None,
+                 overlap: Optional[int] = None, max_observations_per_track: int = 5, save_per_chunk: bool = False,
+                 use_inverse_depth: bool = False, device: str = "cuda:0"):
+        self.chunk_dir, self.output_dir = chunk_dir, output_dir
+        loaded_cl = loaded_ov = None
+        try:  # offline_reconstructor.py:32-46
+            meta_path = os.path.join(self.chunk_dir, "chunk_metadata.json")
+            if os.path.exists(meta_path):
+                with open(meta_path) as f:
+                    meta = json.load(f)
+                loaded_cl = int(meta.get("chunk_length")) if meta.get("chunk_length") is not None else None
+                loaded_ov = int(meta.get("overlap")) if meta.get("overlap") is not None else None
+        except Exception:  # noqa: BLE001
+            pass
+        self.chunk_length = int(chunk_length) if chunk_length is not None else (loaded_cl or 100)
+        self.overlap = int(overlap) if overlap is not None else (loaded_ov or 10)
+        self.max_observations_per_track = max_observations_per_track
+        self.save_per_chunk = save_per_chunk
+        self.use_inverse_depth = use_inverse_depth
+        self.device = device
+        os.makedirs(self.output_dir, exist_ok=True)
+        self.recon_dir = os.path.join(self.output_dir, "reconstructions")
+        os.makedirs(self.recon_dir, exist_ok=True)
+        self.reconstructions: List[Dict] = []   # chunk dicts, transformed in place into the global frame
+        self.alignment_infos: List[Optional[Dict]] = []
+
+    def _load_chunks(self) -> List[str]:
+        files = sorted(glob.glob(os.path.join(self.chunk_dir, "chunks", "chunk_*.pt")))
+        if not files:
+            raise FileNotFoundError(f"No chunk_*.pt files found in {self.chunk_dir}")
+        return files
+
+    def _align_last_two(self) -> Optional[Dict]:
+        if len(self.reconstructions) < 2:
+            return None
+        matches = create_view_graph_matches(self.chunk_length, self.overlap)
+        ok, info = align_and_refine_reconstructions(self.reconstructions[-2], self.reconstructions[-1], matches,
+                                                    device=self.device)
+        if not ok:
+            print(f"   ❌ Alignment failed for chunk {len(self.reconstructions) - 1}")
+            return None
+        return info
+
+    def run(self) -> None:
+        chunk_files = self._load_chunks()
+        print(f"🔄 Reconstructing {len(chunk_files)} chunks from {self.chunk_dir}")
+        for idx, path in enumerate(chunk_files):
+            print(f"\n📦 Loading {os.path.basename(path)} ({idx + 1}/{len(chunk_files)})")
+            data: Dict = torch.load(path, map_location="cpu", weights_only=False)
+            t0 = time.time()
+            self.reconstructions.append(data)
+            if idx > 0:
+                print("   🔗 Aligning with previous reconstruction...")
+                self.alignment_infos.append(self._align_last_two())
+            dt = max(1e-6, time.time() - t0)
+            n = int(data["camera_poses"].shape[0])
+            print(f"   ⏱️ Reconstruction: {dt:.3f}s for {n} frames  ->  {n / dt:.2f} FPS")
+            if self.save_per_chunk:
+                self._save_chunk(data, idx)
+        if not self.reconstructions:
+            return
+        try:
+            pts, cols = self._extract_points_colors()
+            if pts.size > 0:
+                write_ply(pts, cols if cols.size else np.ones_like(pts), os.path.join(self.output_dir, "final_points.ply"))
+        except Exception as e:  # noqa: BLE001
+            print(f"❌ Failed to save final PLY: {e}")
+        try:
+            pos, _, _ = self._extract_camera_positions()
+            if pos:
+                cam = np.asarray(pos, np.float32)
+                write_ply(cam, np.tile(np.array([[1.0, 0.0, 0.0]], np.float32), (len(cam), 1)),
+                          os.path.join(self.output_dir, "final_camera_poses.ply"))
+        except Exception as e:  # noqa: BLE001
+            print(f"❌ Failed to save camera trajectory PLY: {e}")
+        try:
+            self._save_trajectory_tum(os.path.join(self.output_dir, "trajectory_tum.txt"), integer_timestamp=True)
+        except Exception as e:  # noqa: BLE001
+            print(f"❌ Failed to save TUM trajectory: {e}")
+
+    def _save_chunk(self, data: Dict, idx: int) -> None:
+        try:
+            m = data["masks"].reshape(-1).numpy() if "masks" in data else slice(None)
+            write_ply(data["points"].float().reshape(-1, 3).numpy()[m],
+                      np.full((int(np.sum(m)) if not isinstance(m, slice) else data["points"].numel() // 3, 3), 255.0),
+                      os.path.join(self.recon_dir, f"chunk_{idx:06d}.ply"))
+        except Exception as e:  # noqa: BLE001
+            print(f"   ❌ Failed to save recon {idx}: {e}")
+
+    def _extract_points_colors(self) -> Tuple[np.ndarray, np.ndarray]:
+        """offline_reconstructor.py:170-193: every track of every chunk (no de-duplication)."""
+        pts, cols = [], []
+        for d in self.reconstructions:
+            if "keypoints" not in d:
+                continue
+            pts.append(d["points"].float().reshape(-1, 3).numpy())
+            if "colors" in d and d["colors"] is not None:
+                cols.append(d["colors"].float().reshape(-1, 3).numpy())
+        if not pts:
+            return np.array([]), np.array([])
+        P = np.concatenate(pts, 0)
+        C = np.concatenate(cols, 0) if cols else np.array([])
+        if C.size > 0 and C.max() > 1.0:
+            C = C / 255.0
+        return P.astype(np.float32), C.astype(np.float32)
+
+    def _extract_camera_positions(self):
+        positions, orientations, names = [], [], []
+        for d in self.reconstructions:
+            poses = d["camera_poses"].float().numpy()
+            paths = d.get("image_paths") or [f"frame_{i}" for i in range(len(poses))]
+            for i, P in enumerate(poses):
+                positions.append(P[:3, 3].astype(np.float32))
+                orientations.append(P[:3, :3].astype(np.float32))
+                names.append(_view_name(paths[i]) if i < len(paths) else f"view_{i}")
+        return positions, orientations, names
+
+    def _build_full_camera_trajectory(self):
+        """First occurrence of each view name wins (offline_reconstructor.py:218-229)."""
+        positions, orientations, names = self._extract_camera_positions()
+        seen, traj, rots = set(), [], []
+        for name, pos, R in zip(names, positions, orientations):
+            if name in seen:
+                continue
+            seen.add(name)
+            traj.append(pos)
+            rots.append(R)
+        return traj, rots
+
+    def _save_trajectory_tum(self, save_path: str, integer_timestamp: bool = True) -> None:
+        """TUM format of offline_reconstructor.py:231-255 ("{i} {x:.6f} ... {qw:.6f}")."""
+        from scipy.spatial.transform import Rotation
+        traj, rots = self._build_full_camera_trajectory()
+        if not traj:
+            print("No camera trajectory available to save from reconstructions")
+            return
+        os.makedirs(os.path.dirname(save_path) or ".", exist_ok=True)
+        with open(save_path, "w") as f:
+            f.write("# timestamp tx ty tz qx qy qz qw\n")
+            for i, (pos, R) in enumerate(zip(traj, rots)):
+                x, y, z = pos
+                qx, qy, qz, qw = Rotation.from_matrix(R.astype(np.float64)).as_quat()
+                ts = f"{i}" if integer_timestamp else f"{float(i):.9f}"
+                f.write(f"{ts} {x:.6f} {y:.6f} {z:.6f} {qx:.6f} {qy:.6f} {qz:.6f} {qw:.6f}\n")
+        print(f"✅ Saved trajectory with {len(traj)} poses to: {save_path}")

@@ -1,0 +1,63 @@
+"""The C-ABI shared library loads (no GPU needed) and exports every symbol include/pi3slam_hip.h declares."""
+import ctypes
+import os
+import re
+
+from conftest import ROOT
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "pi3slam_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(pi3_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_exported(built_lib):
+    syms = _declared_symbols()
+    assert len(syms) >= 20
+    dll = ctypes.CDLL(built_lib)
+    missing = [s for s in syms if not hasattr(dll, s)]
+    assert not missing, f"declared in the header but not exported: {missing}"
+
+
+def test_ctypes_table_matches_header(built_lib):
+    from pi3_slam_amd import lib
+    declared = set(_declared_symbols()) - {"pi3_last_error", "pi3_abi_version", "pi3_device_count"}
+    assert declared == set(lib.SIGNATURES), (declared ^ set(lib.SIGNATURES))
+    # arity of every binding == number of parameters in the header prototype
+    text = open(os.path.join(ROOT, "include", "pi3slam_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    for name, argt in lib.SIGNATURES.items():
+        m = re.search(r"\b" + name + r"\s*\((.*?)\)\s*;", text, flags=re.S)
+        assert m, name
+        nparams = len([p for p in m.group(1).split(",") if p.strip()])
+        assert nparams == len(argt), (name, nparams, len(argt))
+
+
+def test_loads_without_gpu_and_reports_version(built_lib):
+    from pi3_slam_amd import lib
+    dll = lib.load(require_gpu=False)
+    assert dll.pi3_abi_version() == 1
+    assert dll.pi3_device_count() >= 0
+    assert isinstance(dll.pi3_last_error(), bytes)
+
+
+def test_product_path_fails_loudly_without_gpu(built_lib):
+    """No CPU fallback: on a box without a GPU the op layer must raise, not compute."""
+    import pytest
+    import torch
+    from pi3_slam_amd import lib
+    if lib.load(require_gpu=False).pi3_device_count() > 0:
+        pytest.skip("a GPU is visible")
+    with pytest.raises(lib.Pi3HipError):
+        lib.load(require_gpu=True)
+
+
+def test_product_does_not_import_oracle():
+    """The oracle is test infrastructure: nothing under pi3_slam_amd/ may import it."""
+    pkg = os.path.join(ROOT, "pi3_slam_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f

@@ -1,0 +1,114 @@
+"""CPU: host-side logic of the product (no kernels): chunk layout, grid keypoints, target size, recipe, taps,
+boundary packing — against the oracle / reference vectors."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+from oracle import post_ref
+from pi3_slam_amd import recipe
+from pi3_slam_amd.alignment import create_view_graph_matches
+from pi3_slam_amd.engine import bicubic_aa_taps
+from pi3_slam_amd.image_io import chunk_indices, target_size_for
+from pi3_slam_amd.keypoints import GridKeypointExtractor, create_keypoint_extractor
+from pi3_slam_amd.weights import Pi3Config, param_shapes
+
+
+def test_chunk_layout_and_view_graph_match_reference_vectors():
+    g = np.load(os.path.join(GOLDEN, "post_layout.npz"))
+    for k in g.files:
+        parts = k.split("_")
+        if parts[0] == "chunks":
+            n, cl, ov = map(int, parts[1:])
+            assert np.array_equal(np.array(chunk_indices(n, cl, ov)).reshape(-1, 2), g[k]), k
+        else:
+            cl, ov = map(int, parts[1:])
+            assert np.array_equal(np.array(create_view_graph_matches(cl, ov)).reshape(-1, 2), g[k]), k
+
+
+def test_quirk_tail_chunk_of_overlap_frames_only():
+    assert chunk_indices(32, 32, 8) == [(0, 32), (24, 32)]
+    assert len(chunk_indices(1000, 100, 20)) == 13 and chunk_indices(1000, 100, 20)[-1] == (960, 1000)
+    assert len(chunk_indices(4000, 100, 20)) == 50
+    assert chunk_indices(1, 100, 20) == []                            # a single frame is dropped (< 2 frames)
+
+
+@pytest.mark.parametrize("name,max_kp,seed,tag", [("post_a", 4096, None, "full"), ("post_a", 12, 1234, "sub"),
+                                                  ("post_b", 4096, None, "full"), ("post_b", 12, 1234, "sub")])
+def test_grid_keypoints_bit_exact(name, max_kp, seed, tag):
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    N, H, W = g["shape"]
+    ext = GridKeypointExtractor(max_num_keypoints=max_kp, seed=seed)
+    kp = ext.extract(torch.zeros(int(N), 3, int(H), int(W)))["keypoints"]
+    assert kp.dtype == torch.float32 and np.array_equal(kp.numpy(), g[f"kp_{tag}"])
+
+
+def test_keypoint_factory_and_north_star_grid():
+    ext = create_keypoint_extractor("aliked", 200)      # falls back to grid like the reference when lightglue is absent
+    assert isinstance(ext, GridKeypointExtractor)
+    assert ext._calculate_grid_spacing(308, 406) == 22 and GridKeypointExtractor(400)._calculate_grid_spacing(308, 406) == 16
+    out = ext.extract(torch.zeros(2, 3, 308, 406))
+    assert out["keypoints"].shape == (2, 200, 2) and out["descriptors"].shape == (2, 200, 128)
+    assert float(out["descriptors"].abs().sum()) == 0 and float(out["scores"].min()) == 1
+    with pytest.raises(ValueError):
+        create_keypoint_extractor("sift", 10)
+
+
+def test_target_size_rule():
+    assert target_size_for(640, 480, 127500) == (308, 406)
+    assert target_size_for(512, 384, 127500) == (308, 406)
+    assert target_size_for(256, 192, 127500) == (308, 406)
+    assert target_size_for(752, 480, 127500) == (280, 448)
+
+
+def test_recipe_is_deterministic_and_name_keyed():
+    a = recipe.recipe_tensor("decoder.0.attn.qkv.weight", (7, 5), 0.0, 1.0)
+    b = recipe.recipe_tensor("decoder.0.attn.qkv.weight", (7, 5), 0.0, 1.0)
+    c = recipe.recipe_tensor("decoder.1.attn.qkv.weight", (7, 5), 0.0, 1.0)
+    assert np.array_equal(a, b) and not np.array_equal(a, c)
+    assert a.dtype == np.float32 and np.abs(a).max() < 1.0
+    assert recipe.fnv1a64("") == 0xCBF29CE484222325 and recipe.fnv1a64("a") == 0xAF63DC4C8601EC8C
+    # chunked generation == one-shot generation
+    u = recipe.recipe_unit(123, 1000)
+    assert np.array_equal(u[100:200], recipe.recipe_unit(123, 100, 100))
+
+
+def test_param_inventory_default_config():
+    shapes = param_shapes(Pi3Config())
+    assert len(shapes) == 1208
+    assert sum(int(np.prod(s)) for s in shapes.values()) == 958696732      # measured on the reference
+    for name, shape in shapes.items():
+        recipe.recipe_params(name, shape)
+
+
+def test_bicubic_antialias_taps_match_torch():
+    torch.manual_seed(0)
+    for (i, oh, ow) in [(37, 22, 29), (5, 2, 3), (37, 40, 45), (37, 20, 32)]:
+        x = torch.randn(1, 3, i, i)
+        ref = torch.nn.functional.interpolate(x, size=(oh, ow), mode="bicubic", antialias=True)[0]
+        wy, wx = torch.from_numpy(bicubic_aa_taps(i, oh)), torch.from_numpy(bicubic_aa_taps(i, ow))
+        mine = torch.einsum("yi,cij,xj->cyx", wy, x[0], wx)
+        assert float((ref - mine).abs().max()) < 5e-6
+
+
+def test_boundary_pack_roundtrip():
+    from pi3_slam_amd.dist import pack_boundary, unpack_boundary
+    N, K, ov = 7, 5, 3
+    ch = dict(points=torch.randn(N, K, 3).half(), keypoints=(torch.rand(N, K, 2) * 300).half(),
+              masks=torch.rand(N, K, 1) > 0.5, camera_poses=torch.randn(N, 4, 4))
+    b = unpack_boundary(pack_boundary(ch, ov, K), ov, K)
+    assert b["n_frames"] == N
+    assert torch.equal(b["head"]["points"], ch["points"][:ov]) and torch.equal(b["tail"]["points"], ch["points"][-ov:])
+    assert torch.equal(b["head"]["keypoints"], ch["keypoints"][:ov])
+    assert torch.equal(b["tail"]["masks"], ch["masks"][-ov:]) and torch.equal(b["last_pose"], ch["camera_poses"][-1])
+
+
+def test_match_keypoints_oracle():
+    kp = (torch.rand(3, 6, 2) * 100).half().numpy()
+    perm = np.array([2, 0, 5, 1, 4, 3])
+    q = kp[:, perm].copy()
+    q[1, 2] = [999.0, 999.0]
+    idx = post_ref.match_keypoints(kp, q)
+    assert np.array_equal(idx[0], perm) and idx[1, 2] == -1 and np.array_equal(idx[2], perm)

@@ -1,0 +1,89 @@
+"""CPU: the oracle restatements against the vectors produced by the REAL reference (oracle/gen_golden*.py).
+This is what pins the oracle; the GPU tests then compare the HIP path with the oracle / the same vectors."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+from oracle import pi3_ref, post_ref
+from oracle.gen_golden import CASES, golden_images
+from oracle.gen_golden_post import CASES as POST_CASES, synthetic_chunk
+from pi3_slam_amd.weights import Pi3Config, recipe_state_dict_cpu
+
+
+@pytest.fixture(scope="module")
+def full_sd():
+    return recipe_state_dict_cpu(Pi3Config())   # 958.7 M parameters, ~1 min of numpy
+
+
+@pytest.mark.parametrize("name", ["pi3_tiny_a", "pi3_tiny_b"])
+def test_pi3_oracle_matches_reference_vectors(full_sd, name):
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    B, N, H, W = CASES[name]
+    out = pi3_ref.pi3_forward(full_sd, golden_images(name, B, N, H, W), Pi3Config(), return_intermediates=True)
+    for k in ("points", "local_points", "conf", "camera_poses"):
+        np.testing.assert_allclose(out[k].numpy(), g[k], rtol=1e-4, atol=2e-5, err_msg=k)
+    for k in g.files:
+        if k.startswith("i_"):
+            np.testing.assert_allclose(out["_intermediates"][k[2:]].numpy(), g[k], rtol=1e-4, atol=5e-5, err_msg=k)
+
+
+@pytest.mark.parametrize("name", list(POST_CASES))
+def test_post_oracle_matches_reference_vectors(name):
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    N, H, W = POST_CASES[name]
+    d = synthetic_chunk(name, N, H, W)
+    masks = post_ref.compute_masks(d["conf"], d["local_points"])
+    assert np.array_equal(masks.numpy(), g["masks"])
+    s = post_ref.scale_factor(d["moge_depth"], d["local_points"][0][..., 2], masks[0])
+    assert np.float32(s.item()) == g["scale"]
+    for tag, max_kp, seed in (("full", 4096, None), ("sub", 12, 1234)):
+        gen = torch.Generator().manual_seed(seed) if seed is not None else None
+        kp = post_ref.grid_keypoints(N, H, W, max_kp, gen)
+        assert np.array_equal(kp.numpy(), g[f"kp_{tag}"]), "keypoints must be bit-exact"
+        it = post_ref.interpolate_at_keypoints(d["points"], d["local_points"], d["conf"], masks, kp, H, W)
+        assert np.array_equal(it["points"].numpy(), g[f"ipoints_{tag}"])
+        assert np.array_equal(it["local_points"].numpy(), g[f"ilocal_{tag}"])
+        assert np.array_equal(it["conf"].numpy(), g[f"iconf_{tag}"])
+        assert np.array_equal(it["masks"].numpy(), g[f"imasks_{tag}"])
+        assert np.array_equal(post_ref.keypoint_colors(d["images"], kp).numpy(), g[f"colors_{tag}"])
+    conf_masks = torch.sigmoid(d["conf"][..., 0]) > 0.1
+    focal, shift = post_ref.recover_focal_shift(d["local_points"], conf_masks)
+    np.testing.assert_allclose(focal.numpy(), g["focal"], rtol=1e-6)
+    np.testing.assert_allclose(shift.numpy(), g["shift"], rtol=1e-6, atol=1e-7)
+
+
+def test_layout_oracle_matches_reference_vectors():
+    g = np.load(os.path.join(GOLDEN, "post_layout.npz"))
+    for k in g.files:
+        parts = k.split("_")
+        if parts[0] == "chunks":
+            n, cl, ov = map(int, parts[1:])
+            assert np.array_equal(np.array(post_ref.chunk_indices(n, cl, ov)).reshape(-1, 2), g[k]), k
+        else:
+            cl, ov = map(int, parts[1:])
+            assert np.array_equal(np.array(post_ref.create_view_graph_matches(cl, ov)).reshape(-1, 2), g[k]), k
+
+
+def test_umeyama_known_answers():
+    """Sim(3) closed form: exact recovery of a known similarity, reflection handling, noise robustness.
+    (No reference vector exists for this step — pytheia is absent — so these are known-answer tests.)"""
+    rng = np.random.default_rng(1)
+    x = rng.standard_normal((500, 3)) * 2.0
+    ang = 0.7
+    R = np.array([[np.cos(ang), -np.sin(ang), 0], [np.sin(ang), np.cos(ang), 0], [0, 0, 1.0]])
+    R = R @ np.array([[1, 0, 0], [0, np.cos(0.3), -np.sin(0.3)], [0, np.sin(0.3), np.cos(0.3)]])
+    s, t = 1.7, np.array([0.3, -2.0, 5.0])
+    y = s * (R @ x.T).T + t
+    s2, R2, t2, M = post_ref.umeyama(x, y)
+    assert abs(s2 - s) < 1e-12 and np.abs(R2 - R).max() < 1e-12 and np.abs(t2 - t).max() < 1e-11
+    y_noisy = y + 1e-3 * rng.standard_normal(y.shape)
+    s3, R3, t3, _ = post_ref.umeyama(x, y_noisy)
+    assert abs(s3 - s) < 1e-3 and np.abs(R3 - R).max() < 1e-3
+    # planar, mirrored data must still return a proper rotation
+    xp = x.copy(); xp[:, 2] = 0
+    yp = xp.copy(); yp[:, 0] *= -1
+    _, Rp, _, _ = post_ref.umeyama(xp, yp)
+    assert abs(np.linalg.det(Rp) - 1.0) < 1e-9

@@ -1,0 +1,246 @@
+"""GPU parity of the per-chunk post-processing and the Sim(3) alignment kernels against the oracle and the vectors
+produced by the reference's own functions (tests/golden/post_*.npz).  Integer / index / boolean outputs are bit-exact;
+fp16-packed values must equal the reference's fp16 values except where an fp32 ulp flips the fp16 rounding (bounded)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev(built_lib):
+    assert torch.cuda.is_available()
+    from pi3_slam_amd import lib
+    lib.load(require_gpu=True)
+    return torch.device("cuda:0")
+
+
+def _case(name):
+    from oracle.gen_golden_post import CASES, synthetic_chunk
+    N, H, W = CASES[name]
+    return np.load(os.path.join(GOLDEN, name + ".npz")), synthetic_chunk(name, N, H, W), (N, H, W)
+
+
+def _fp16_close(a, b, max_ulp=1, max_frac=2e-3):
+    """fp16 tensors equal up to max_ulp fp16 ulps, and different in at most max_frac of the elements."""
+    ai = a.cpu().view(torch.int16).to(torch.int32)
+    bi = b.cpu().view(torch.int16).to(torch.int32)
+    d = (ai - bi).abs()
+    return int(d.max()) <= max_ulp and float((d > 0).float().mean()) <= max_frac
+
+
+@pytest.mark.parametrize("name", ["post_a", "post_b"])
+def test_masks_scale_gather_against_reference_vectors(dev, name):
+    from pi3_slam_amd import ops
+    g, d, (N, H, W) = _case(name)
+    lp, conf, pts = d["local_points"].to(dev), d["conf"].to(dev), d["points"].to(dev)
+    masks = ops.compute_masks(conf, lp)
+    assert np.array_equal(masks.bool().cpu().numpy(), g["masks"]), "masks must be bit-exact on this fixture"
+    med = ops.masked_ratio_median(d["moge_depth"].to(dev), lp[0][..., 2], 3, masks[0].contiguous(), H * W)
+    assert np.float32(med[0].item()) == g["scale"] and int(med[1].item()) == int(g["masks"][0].sum())
+    for tag in ("full", "sub"):
+        kp = torch.from_numpy(g[f"kp_{tag}"]).to(dev)
+        out = ops.gather_keypoints(pts, lp, conf, masks, d["images"].to(dev), kp)
+        assert np.array_equal(out["masks"].cpu().numpy(), g[f"imasks_{tag}"])                   # nearest: exact
+        assert np.array_equal(out["conf"].cpu().numpy(), g[f"iconf_{tag}"])                     # nearest: exact
+        assert np.array_equal(out["keypoints"].cpu().numpy(), g[f"kp_{tag}"].astype(np.float16))
+        assert _fp16_close(out["points"], torch.from_numpy(g[f"ipoints_{tag}"]))
+        assert _fp16_close(out["local_points"], torch.from_numpy(g[f"ilocal_{tag}"]))
+        col = out["colors"].cpu().float().numpy()
+        ref = g[f"colors_{tag}"].astype(np.float32)
+        assert np.abs(col - ref).max() <= 1.0 and (col != ref).mean() < 5e-3                    # uint8 truncation edge
+
+
+def test_masks_edge_cases(dev):
+    from oracle import post_ref
+    from pi3_slam_amd import ops
+    torch.manual_seed(3)
+    F, H, W = 2, 9, 11
+    lp = torch.rand(F, H, W, 3) + 0.5
+    lp[0, 0, 0, 2] = 0.0                # z = 0 -> ratio inf -> nan_to_num -> edge
+    lp[0, 4, 4, 2] = float("nan")
+    lp[1, H - 1, W - 1, 2] = 10.0       # border pixel: only valid neighbours take part
+    conf = torch.randn(F, H, W, 1) * 3
+    got = ops.compute_masks(conf.to(dev), lp.to(dev)).bool().cpu()
+    assert torch.equal(got, post_ref.compute_masks(conf, lp))
+
+
+def test_ratio_median_semantics(dev):
+    from pi3_slam_amd import ops
+    torch.manual_seed(0)
+    for n in (1, 2, 7, 1000, 125048):
+        num, den = torch.rand(n) + 0.1, torch.rand(n) + 0.1
+        mask = torch.rand(n) > 0.3
+        mask[0] = True
+        ref = (num[mask] / den[mask]).median()          # torch: LOWER median
+        got = ops.masked_ratio_median(num.to(dev), den.to(dev), 1, mask.to(dev).view(torch.uint8), n).cpu()
+        assert got[0].item() == ref.item() and int(got[1]) == int(mask.sum())
+    num = torch.tensor([1.0, float("inf"), 3.0, -2.0, 5.0])
+    got = ops.masked_ratio_median(num.to(dev), torch.ones(5, device=dev), 1, torch.ones(5, device=dev, dtype=torch.uint8), 5)
+    assert got[0].item() == 3.0
+    got = ops.masked_ratio_median(num.to(dev), torch.ones(5, device=dev), 1, torch.zeros(5, device=dev, dtype=torch.uint8), 5)
+    assert np.isnan(got[0].item()) and got[1].item() == 0         # empty selection: NaN + count 0
+    num[2] = float("nan")
+    got = ops.masked_ratio_median(num.to(dev), torch.ones(5, device=dev), 1, torch.ones(5, device=dev, dtype=torch.uint8), 5)
+    assert np.isnan(got[0].item())                                # NaN propagates like torch.median
+
+
+def test_apply_scale(dev):
+    from pi3_slam_amd import ops
+    lp, pts, poses = torch.rand(2, 5, 7, 3, device=dev), torch.rand(2, 5, 7, 3, device=dev), torch.rand(2, 4, 4, device=dev)
+    lp0, pts0, poses0 = lp.clone(), pts.clone(), poses.clone()
+    ops.apply_scale(torch.tensor([1.37], device=dev), lp, pts, poses)
+    assert torch.equal(lp, lp0 * 1.37) and torch.equal(pts, pts0 * 1.37)
+    exp = poses0.clone(); exp[:, :3, 3] *= 1.37
+    assert torch.equal(poses, exp)
+
+
+@pytest.mark.parametrize("name", ["post_a", "post_b"])
+def test_focal_shift_against_scipy_lm_vectors(dev, name):
+    """The device LM restates MINPACK lmdif (what scipy's method='lm' runs); the reference stops at ftol = 1e-3, so
+    the iterate sequence must be the same, not just the optimum: focal/shift agree to 1e-5 relative."""
+    from pi3_slam_amd import ops
+    from pi3_slam_amd.chunk_creator import _uv_tables
+    g, d, (N, H, W) = _case(name)
+    uvx, uvy = _uv_tables(H, W, dev)
+    r = ops.focal_shift(d["local_points"].to(dev), d["conf"].to(dev), uvx, uvy)
+    np.testing.assert_allclose(r["focal"].cpu().numpy(), g["focal"], rtol=1e-5)
+    np.testing.assert_allclose(r["shift"].cpu().numpy(), g["shift"], rtol=1e-5, atol=1e-6)
+    from oracle import post_ref
+    ref = post_ref.estimate_camera_parameters(d["local_points"], d["conf"])
+    np.testing.assert_allclose(r["intrinsics"].cpu().numpy(), ref["intrinsics"].numpy(), rtol=1e-5)
+    assert torch.equal(r["fxfycxcy"][:, 2].cpu(), ref["cx"][0]) and torch.equal(r["fxfycxcy"][:, 3].cpu(), ref["cy"][0])
+
+
+def test_focal_shift_degenerate_mask(dev):
+    from pi3_slam_amd import ops
+    from pi3_slam_amd.chunk_creator import _uv_tables
+    H, W = 28, 42
+    uvx, uvy = _uv_tables(H, W, dev)
+    lp = torch.rand(1, H, W, 3, device=dev) + 1
+    conf = torch.full((1, H, W, 1), -20.0, device=dev)           # nothing passes sigmoid > 0.1
+    r = ops.focal_shift(lp, conf, uvx, uvy)
+    assert r["focal"].item() == 1.0 and r["shift"].item() == 0.0  # geometry_torch.py:152-155
+
+
+def _two_chunks(ov=6, K=40, noise=1e-3, seed=1, permute=False):
+    rng = np.random.default_rng(seed)
+    world = rng.standard_normal((ov, K, 3)) * 2 + np.array([0, 0, 5.0])
+    ang = 0.4
+    R = np.array([[np.cos(ang), 0, np.sin(ang)], [0, 1, 0], [-np.sin(ang), 0, np.cos(ang)]])
+    s, t = 1.3, np.array([0.5, -0.2, 1.0])
+    qry = ((world - t) @ R) / s + noise * rng.standard_normal(world.shape)       # world = s R qry + t
+    kp = (rng.random((ov, K, 2)) * 300).astype(np.float16)
+    kq = kp.copy()
+    pq = qry.astype(np.float16)
+    if permute:
+        perm = rng.permutation(K)
+        kq, pq = kq[:, perm], pq[:, perm]
+        kq[0, 3] = [1234.0, 1234.0]           # one unmatched keypoint
+    pose = np.eye(4, dtype=np.float32); pose[:3, 3] = [0.1, 0.0, 0.3]
+    return world.astype(np.float16), pq, kp, kq, pose, (s, R, t)
+
+
+@pytest.mark.parametrize("permute,use_filter", [(False, True), (True, True), (True, False)])
+def test_sim3_against_oracle(dev, permute, use_filter):
+    from oracle import post_ref
+    from pi3_slam_amd import ops
+    pr, pq, kr, kq, pose, (s, R, t) = _two_chunks(permute=permute)
+    ref = post_ref.align_chunks(pr, pq, kr, kq, pose, use_filter)
+    idx = ops.sim3_match_keypoints(torch.from_numpy(kr).to(dev), torch.from_numpy(kq).to(dev))
+    assert np.array_equal(idx.cpu().numpy(), ref["idx"]), "match indices must be bit-exact"
+    out = ops.sim3_umeyama(torch.from_numpy(pr).to(dev), torch.from_numpy(pq).to(dev), idx,
+                           torch.from_numpy(pose).to(dev), None, None, use_filter).cpu().numpy()
+    assert int(out[29]) == ref["n_used"] and int(out[30]) == ref["n_common"]
+    if use_filter:
+        assert out[31] == ref["median"]                      # exact order statistics (np.median)
+    np.testing.assert_allclose(out[0], ref["s"], rtol=1e-12)
+    np.testing.assert_allclose(out[1:10].reshape(3, 3), ref["R"], atol=1e-12)
+    np.testing.assert_allclose(out[10:13], ref["t"], atol=1e-11)
+    np.testing.assert_allclose(out[13:29].reshape(4, 4), ref["M"], atol=1e-11)
+    np.testing.assert_allclose(out[32], ref["rms"], rtol=1e-9)
+    assert abs(out[0] - s) < 5e-3 and np.abs(out[1:10].reshape(3, 3) - R).max() < 5e-3      # recovers the truth
+
+
+def test_sim3_apply_and_prefix(dev):
+    from oracle import post_ref
+    from pi3_slam_amd import ops
+    rng = np.random.default_rng(0)
+    _, _, _, _, _, (s, R, t) = _two_chunks()
+    M = np.eye(4); M[:3, :3] = s * R; M[:3, 3] = t
+    pts = rng.standard_normal((1000, 3)).astype(np.float32)
+    poses = np.tile(np.eye(4, dtype=np.float32), (5, 1, 1)); poses[:, :3, 3] = rng.standard_normal((5, 3))
+    p_ref, P_ref = post_ref.apply_sim3(M, pts, poses)
+    pd, Pd = torch.from_numpy(pts).to(dev), torch.from_numpy(poses).to(dev)
+    ops.sim3_apply(torch.from_numpy(M).to(dev), pd, Pd)
+    np.testing.assert_allclose(pd.cpu().numpy(), p_ref, rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(Pd.cpu().numpy(), P_ref, rtol=1e-6, atol=1e-6)
+    T = np.stack([np.eye(4), M, M, np.linalg.inv(M)]).reshape(4, 16)
+    G = ops.sim3_compose_prefix(torch.from_numpy(T).to(dev)).cpu().numpy().reshape(4, 4, 4)
+    np.testing.assert_allclose(G[2], M @ M, rtol=1e-12)
+    np.testing.assert_allclose(G[3], M, rtol=1e-10, atol=1e-12)
+
+
+def test_alignment_is_similarity_equivariant(dev):
+    """Chunk-parallel == sequential for the closed-form step: aligning to a transformed reference composes."""
+    from pi3_slam_amd import ops
+    pr, pq, kr, kq, pose, _ = _two_chunks(noise=1e-3)
+    rng = np.random.default_rng(5)
+    ang = 1.1
+    Rg = np.array([[np.cos(ang), -np.sin(ang), 0], [np.sin(ang), np.cos(ang), 0], [0, 0, 1.0]])
+    G = np.eye(4); G[:3, :3] = 2.0 * Rg; G[:3, 3] = [3.0, -1.0, 0.5]
+    def solve(pref, posem):
+        idx = ops.sim3_match_keypoints(torch.from_numpy(kr).to(dev), torch.from_numpy(kq).to(dev))
+        return ops.sim3_umeyama(torch.from_numpy(pref).to(dev), torch.from_numpy(pq).to(dev), idx,
+                                torch.from_numpy(posem).to(dev), None, None, True).cpu().numpy()
+    a = solve(pr, pose)
+    pr_g = ((G[:3, :3] @ pr.astype(np.float64).reshape(-1, 3).T).T + G[:3, 3]).reshape(pr.shape).astype(np.float16)
+    pose_g = pose.copy(); pose_g[:3, 3] = G[:3, :3] @ pose[:3, 3] + G[:3, 3]
+    b = solve(pr_g, pose_g)
+    np.testing.assert_allclose(b[13:29].reshape(4, 4), G @ a[13:29].reshape(4, 4), rtol=2e-2, atol=2e-2)   # fp16 re-rounding of the transformed reference
+
+
+def test_offline_reconstructor_roundtrip(dev, tmp_path):
+    """chunk files -> OfflineReconstructor.run(): overlapping chunks that differ by known similarities come back on
+    one trajectory; TUM file format and first-occurrence de-duplication as offline_reconstructor.py:218-255."""
+    import json
+    from pi3_slam_amd.reconstructor import OfflineReconstructor
+    rng = np.random.default_rng(0)
+    cl, ov, K, nchunks = 8, 3, 30, 3
+    n_frames = cl + (nchunks - 1) * (cl - ov)
+    gt_pos = np.stack([np.array([0.1 * i, 0.02 * i, 0.0]) for i in range(n_frames)])
+    world_pts = {i: rng.standard_normal((K, 3)) + np.array([0.1 * i, 0, 4.0]) for i in range(n_frames)}
+    kp = (rng.random((K, 2)) * 300).astype(np.float16)
+    os.makedirs(tmp_path / "chunks")
+    for c in range(nchunks):
+        start = c * (cl - ov)
+        ang, s = 0.3 * c, 1.0 + 0.2 * c
+        R = np.array([[np.cos(ang), -np.sin(ang), 0], [np.sin(ang), np.cos(ang), 0], [0, 0, 1.0]])
+        t = np.array([0.5 * c, -0.3 * c, 0.1 * c])
+        inv = lambda X: ((X - t) @ R) / s                        # chunk frame = S^-1 (world)
+        poses = np.tile(np.eye(4, dtype=np.float32), (cl, 1, 1))
+        pts = np.zeros((cl, K, 3), np.float16)
+        for j in range(cl):
+            poses[j, :3, :3] = R.T
+            poses[j, :3, 3] = inv(gt_pos[start + j])
+            pts[j] = inv(world_pts[start + j])
+        torch.save({"points": torch.from_numpy(pts), "keypoints": torch.from_numpy(np.tile(kp, (cl, 1, 1))),
+                    "masks": torch.ones(cl, K, 1, dtype=torch.bool), "colors": torch.full((cl, K, 3), 128.0).half(),
+                    "camera_poses": torch.from_numpy(poses), "image_paths": [[f"img_{start + j:04d}.png"] for j in range(cl)],
+                    "original_width": 406, "original_height": 308, "chunk_index": c},
+                   tmp_path / "chunks" / f"chunk_{c:06d}.pt")
+    json.dump({"chunk_length": cl, "overlap": ov, "target_size": [308, 406]}, open(tmp_path / "chunk_metadata.json", "w"))
+    rec = OfflineReconstructor(str(tmp_path), str(tmp_path / "out"))
+    assert rec.chunk_length == cl and rec.overlap == ov
+    rec.run()
+    lines = open(tmp_path / "out" / "trajectory_tum.txt").read().strip().split("\n")
+    assert lines[0] == "# timestamp tx ty tz qx qy qz qw" and len(lines) == n_frames + 1
+    traj = np.array([[float(v) for v in l.split()[1:4]] for l in lines[1:]])
+    assert np.abs(traj - gt_pos).max() < 2e-2                    # chunk 0 is the world frame; fp16 point storage
+    assert [l.split()[0] for l in lines[1:4]] == ["0", "1", "2"]
+    assert os.path.exists(tmp_path / "out" / "final_points.ply") and os.path.exists(tmp_path / "out" / "final_camera_poses.ply")

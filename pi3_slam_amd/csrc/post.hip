@@ -21,6 +21,7 @@ __global__ __launch_bounds__(256) void masks_kernel(const float* __restrict__ co
   const int y = (int)((i / W) % H);
   const float z = lp[3 * i + 2];
   float mx = z, mn = z;
+  bool anynan = isnan(z);  // max_pool2d propagates NaN (a NaN in the window wins), fmaxf would drop it
 #pragma unroll
   for (int dy = -1; dy <= 1; ++dy)
 #pragma unroll
@@ -30,9 +31,10 @@ __global__ __launch_bounds__(256) void masks_kernel(const float* __restrict__ co
         const float v = lp[3 * (i + (long)dy * W + dx) + 2];
         mx = fmaxf(mx, v);
         mn = fminf(mn, v);
+        anynan = anynan || isnan(v);
       }
     }
-  float ratio = (mx + (-mn)) / z;
+  float ratio = anynan ? __uint_as_float(0x7fc00000u) : (mx + (-mn)) / z;
   if (isnan(ratio)) ratio = 0.f;
   else if (isinf(ratio)) ratio = ratio > 0.f ? FLT_MAX : -FLT_MAX;
   const bool edge = ratio > rtol;

@@ -2,18 +2,18 @@
 // (pi3_slam_amd/weights.py: recipe_tensor).  There are no pretrained checkpoints offline, so parity
 // fixtures, tests and the bench all use weights regenerated from (parameter name -> seed, offset, scale).
 //   z = seed + (i + 1) * 0x9E3779B97F4A7C15;  splitmix64 finaliser;  u = z >> 40 (24 bits)
-//   value = offset + scale * (u * 2^-23 - 1)        (separately rounded fp32 multiply and add, no FMA)
+//   value = (float)((double)offset + (double)scale * (u * 2^-23 - 1))
+// The product of two fp32 values is exact in fp64, so the result does not depend on whether the compiler contracts
+// the multiply-add: one fp64 rounding of the sum, one fp64 -> fp32 rounding, identical in numpy and on the device.
 #include "common.h"
 
 __device__ __forceinline__ float recipe_value(uint64_t seed, uint64_t i, float offset, float scale) {
-#pragma clang fp contract(off)  // numpy rounds the multiply and the add separately; an FMA here would differ
   uint64_t z = seed + (i + 1) * 0x9E3779B97F4A7C15ull;
   z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
   z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
   z = z ^ (z >> 31);
   const float f = (float)(uint32_t)(z >> 40) * 1.1920928955078125e-07f - 1.0f;  // exact
-  const float prod = scale * f;
-  return offset + prod;
+  return (float)((double)offset + (double)scale * (double)f);
 }
 
 template <bool OUT_BF16>

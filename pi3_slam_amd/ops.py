@@ -232,8 +232,8 @@ def gather_keypoints(points, local_points, conf, masks, images, keypoints):
 def sim3_match_keypoints(kp_ref: torch.Tensor, kp_qry: torch.Tensor) -> torch.Tensor:
     """kp_*: f16 [ov, K, 2] -> int32 [ov, K] (index into the ref view's keypoints or -1)."""
     lib = _L.load()
-    assert kp_ref.dtype == torch.float16 and kp_qry.dtype == torch.float16
-    assert kp_ref.is_contiguous() and kp_qry.is_contiguous() and kp_ref.shape == kp_qry.shape
+    assert kp_ref.dtype == torch.float16 and kp_qry.dtype == torch.float16 and kp_ref.shape == kp_qry.shape
+    kp_ref, kp_qry = kp_ref.contiguous(), kp_qry.contiguous()
     ov, K = kp_ref.shape[:2]
     idx = torch.empty(ov, K, device=kp_ref.device, dtype=torch.int32)
     rc = lib.pi3_sim3_match_keypoints(kp_ref.data_ptr(), kp_qry.data_ptr(), ov, K, idx.data_ptr(), _L.stream_ptr())
@@ -247,8 +247,9 @@ def sim3_umeyama(pts_ref: torch.Tensor, pts_qry: torch.Tensor, idx: torch.Tensor
     """-> f64 device tensor [33]: s, R(9), t(3), M(16), n_used, n_common, median, rms."""
     lib = _L.load()
     assert pts_ref.dtype == torch.float16 and pts_qry.dtype == torch.float16 and idx.dtype == torch.int32
-    assert pts_ref.is_contiguous() and pts_qry.is_contiguous() and idx.is_contiguous()
-    assert last_ref_pose.dtype == torch.float32 and last_ref_pose.is_contiguous()
+    pts_ref, pts_qry, idx = pts_ref.contiguous(), pts_qry.contiguous(), idx.contiguous()
+    assert last_ref_pose.dtype == torch.float32
+    last_ref_pose = last_ref_pose.contiguous()
     ov, K = idx.shape
     out = torch.empty(33, device=idx.device, dtype=torch.float64)
     rc = lib.pi3_sim3_umeyama(pts_ref.data_ptr(), pts_qry.data_ptr(), idx.data_ptr(), _L.ptr(w_ref), _L.ptr(w_qry),

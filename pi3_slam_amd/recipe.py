@@ -2,7 +2,7 @@
 
 There are no pretrained checkpoints offline, so every parity fixture and the bench use weights that
 are regenerated from a recipe instead of stored: value[i] = offset + scale * u(seed(name), i), where u is a
-counter-based splitmix64 stream mapped to [-1, 1).  `recipe_tensor` (numpy, integer ops + two fp32 roundings) and
+counter-based splitmix64 stream mapped to [-1, 1).  `recipe_tensor` (numpy, integer ops + one fp64 multiply-add) and
 `pi3_recipe_fill` (csrc/recipe.hip) produce identical bits; tests/test_recipe.py checks that.
 
 (offset, scale) depend only on the parameter's role, chosen so that activations stay O(1) through 75 blocks while
@@ -46,7 +46,9 @@ def recipe_tensor(name: str, shape, offset: float, scale: float) -> np.ndarray:
     for s in range(0, n, step):
         m = min(step, n - s)
         u = recipe_unit(seed, m, s)
-        out[s:s + m] = np.float32(offset) + np.float32(scale) * u
+        # fp32 x fp32 is exact in fp64: no dependence on FMA contraction (matches csrc/recipe.hip bit for bit)
+        out[s:s + m] = (np.float64(np.float32(offset)) + np.float64(np.float32(scale)) * u.astype(np.float64)
+                        ).astype(np.float32)
     return out.reshape(shape)
 
 

@@ -123,9 +123,46 @@ int pi3_gather_keypoints(const float* points, const float* local_points, const f
 
 /* Per-frame focal / z-shift + intrinsics (utils/camera_estimation.py:12-70, utils/geometry_torch.py:114-169,
  * utils/geometry_numpy.py:79-96: scipy least_squares(method='lm') == MINPACK lmdif, n = 1).  uvx [W], uvy [H]: fp32
- * normalized_view_plane_uv tables.  Outputs f32: focal [F], shift [F], (fx, fy, cx, cy) [F][4], K [F][3][3]. */
-int pi3_focal_shift(const float* local_points, const float* conf, const float* uvx, const float* uvy, int F, int H,
-                    int W, float conf_thr, float* focal, float* shift, float* fxfycxcy, float* K33, void* stream);
+ * normalized_view_plane_uv tables.  Pixel validity: mask8 (uint8, if not NULL) else sigmoid(conf) > conf_thr.  Outputs f32: focal [F], shift [F], (fx, fy, cx, cy) [F][4], K [F][3][3]. */
+int pi3_focal_shift(const float* local_points, const float* conf, const unsigned char* mask8, const float* uvx,
+                    const float* uvy, int F, int H, int W, float conf_thr, float* focal, float* shift,
+                    float* fxfycxcy, float* K33, void* stream);
+
+/* ---- MoGe-2 metric-scale forward (moge/model/v2.py:128-290, moge/model/modules.py:18-254) ------------------------ */
+
+/* nn.Conv2d(C, N, 3, padding=1, padding_mode='replicate') as an implicit GEMM on a bf16 NHWC image [B][H][W][ldc]
+ * (C % 64 == 0); wgt bf16 [N][9*C] with k = (ky*3+kx)*C + ci; out rows = pixels; epilogue bias / resid / act. */
+int pi3_conv3x3(const void* img, long ldc, int B, int H, int W, int C, const void* wgt, int N, const float* bias,
+                const float* resid, long ldr, void* out, long ldo, int out_dtype, int act, void* stream);
+
+/* nn.GroupNorm(G, C) statistics of x f32 [B][HW][ldx] -> stats f64 [B][G][2] (sum, sum of squares). */
+int pi3_groupnorm_stats(const float* x, long ldx, int B, int HW, int C, int G, double* stats, void* stream);
+
+/* GroupNorm affine + activation (0 none, 2 ReLU) -> bf16 NHWC staging image [B][HW][ldo], channels [C, Cpad) zeroed. */
+int pi3_groupnorm_apply(const float* x, long ldx, int B, int HW, int C, int Cpad, int G, const double* stats,
+                        const float* gamma, const float* beta, float eps, int act, void* out, long ldo, void* stream);
+
+/* ConvTranspose2d(k=2, s=2) scatter: g f32 [B*H*W][(dy*2+dx)*Cs + co] -> bf16 NHWC [B][2H][2W][ldo]. */
+int pi3_convt_scatter(const float* g, long ldg, int B, int H, int W, int Cout, int Cs, int Cpad, void* out, long ldo,
+                      void* stream);
+
+/* x[b][y][x][c] (+)= w[c][wofs] * uvx[x] + w[c][wofs+1] * uvy[y] + bias[c]: 1x1 conv of the UV planes (v2.py:141-147). */
+int pi3_uv_affine(float* x, long ldx, int B, int H, int W, int C, const float* w, long ldw, int wofs,
+                  const float* bias, const float* uvx, const float* uvy, int accumulate, void* stream);
+
+/* Separable resize with host-built tap tables (ys/xs int32 [o][2] = start,count; yw/xw f32 [o][8]); generic strides. */
+int pi3_resize_taps(const float* src, long sc, long sy, long sx, int C, const int* ys, const float* yw, const int* xs,
+                    const float* xw, int oh, int ow, float* dst, long dc, long dy, long dx, void* stream);
+
+/* y = act(W x + b) for a single vector (scale_head MLP, modules.py:184-192). */
+int pi3_dense_vec(const float* x, const float* Wt, const float* b, int K, int N, int act, float* y, void* stream);
+
+/* In-place point remap (0 linear, 1 exp, 2 sinh, 3 sinh_exp) + binary mask = sigmoid(logit) > 0.5 (v2.py:160-170, 241). */
+int pi3_moge_remap(float* pts, const float* mask_logit, long n, int remap, unsigned char* mask, void* stream);
+
+/* depth = z + *shift; mask &= depth > 0; depth *= exp(*log_scale); depth = mask ? depth : inf (v2.py:255-274). */
+int pi3_moge_depth(const float* pts, const float* shift, const float* log_scale, unsigned char* mask, long n,
+                   float* depth, void* stream);
 
 /* ---- overlap Sim(3) alignment (utils/reconstruction_alignment.py:74-105) --------------------------------------- */
 

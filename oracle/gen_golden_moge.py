@@ -1,0 +1,108 @@
+"""ORACLE tooling — generates tests/golden/moge_*.npz by running the REAL MoGeModel class (imported from
+/root/reference; build container only) with the synthetic model_config + recipe weights of pi3_slam_amd/moge.py.
+
+The reference imports `utils3d` (third-party, not vendored, absent offline) for two helpers used in infer(): they are
+restated here from their call sites (moge/model/v2.py:253, 263); `cv2` (imported by moge/utils/geometry_numpy.py, never
+called on this path) gets an empty placeholder module.
+
+    python oracle/gen_golden_moge.py
+"""
+from __future__ import annotations
+
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"
+sys.path.insert(0, REPO)
+
+from pi3_slam_amd.moge import SYNTHETIC_CONFIG, recipe_state_dict_cpu  # noqa: E402
+from pi3_slam_amd.recipe import fnv1a64, recipe_unit  # noqa: E402
+
+CASES = {  # name: (H, W, resolution_level)
+    "moge_small": (84, 112, 0),
+    "moge_chunk": (308, 406, 9),      # the pipeline's frame size and default resolution level
+}
+
+
+def moge_image(name: str, H: int, W: int) -> torch.Tensor:
+    u = recipe_unit(fnv1a64("golden.moge." + name), 3 * H * W).reshape(3, H, W)
+    yy = np.linspace(0, 1, H, dtype=np.float32)[None, :, None]
+    xx = np.linspace(0, 1, W, dtype=np.float32)[None, None, :]
+    img = 0.45 + 0.2 * u + 0.25 * np.sin(6.0 * xx + 2.0 * yy) * np.cos(3.0 * yy)
+    return torch.from_numpy(np.clip(img, 0, 1).astype(np.float32))
+
+
+def _install_placeholders():
+    u3 = types.ModuleType("utils3d")
+    u3t = types.ModuleType("utils3d.torch")
+
+    def intrinsics_from_focal_center(fx, fy, cx, cy):
+        fx, fy = torch.as_tensor(fx, dtype=torch.float32), torch.as_tensor(fy, dtype=torch.float32)
+        K = torch.zeros(*fx.shape, 3, 3, dtype=fx.dtype)
+        K[..., 0, 0], K[..., 1, 1], K[..., 0, 2], K[..., 1, 2], K[..., 2, 2] = fx, fy, cx, cy, 1.0
+        return K
+
+    def depth_to_points(depth, intrinsics=None, **kw):
+        H, W = depth.shape[-2:]
+        u = (torch.arange(W, dtype=depth.dtype) + 0.5) / W
+        v = (torch.arange(H, dtype=depth.dtype) + 0.5) / H
+        u, v = torch.meshgrid(u, v, indexing="xy")
+        fx, fy = intrinsics[..., 0, 0, None, None], intrinsics[..., 1, 1, None, None]
+        cx, cy = intrinsics[..., 0, 2, None, None], intrinsics[..., 1, 2, None, None]
+        return torch.stack([(u - cx) / fx * depth, (v - cy) / fy * depth, depth], dim=-1)
+
+    u3t.intrinsics_from_focal_center = intrinsics_from_focal_center
+    u3t.depth_to_points = depth_to_points
+    u3.torch = u3t
+    sys.modules["utils3d"], sys.modules["utils3d.torch"] = u3, u3t
+    sys.modules.setdefault("cv2", types.ModuleType("cv2"))
+
+
+def main() -> None:
+    _install_placeholders()
+    sys.path.insert(0, REF)
+    from moge.model.v2 import MoGeModel
+    from oracle import moge_ref
+
+    sd = recipe_state_dict_cpu(SYNTHETIC_CONFIG)
+    model = MoGeModel(**SYNTHETIC_CONFIG).eval()
+    missing, unexpected = model.load_state_dict(sd, strict=False)
+    assert not missing and not unexpected, (missing, unexpected)
+    out_dir = os.path.join(REPO, "tests", "golden")
+    for name, (H, W, level) in CASES.items():
+        img = moge_image(name, H, W)
+        ref = model.infer(img, resolution_level=level, use_fp16=False)
+        lo, hi = SYNTHETIC_CONFIG["num_tokens_range"]
+        ntok = int(lo + (level / 9) * (hi - lo))
+        with torch.no_grad():
+            fwd = model.forward(img[None], num_tokens=ntok)
+        orc = moge_ref.moge_infer(sd, SYNTHETIC_CONFIG, img, level)
+        m = ref["mask"]
+        print(f"{name}: mask frac {m.float().mean().item():.3f}  depth median {ref['depth'][m].median().item():.4f}  "
+              f"metric_scale {fwd['metric_scale'].item():.4f}")
+        print("   oracle vs reference: depth max|d| on mask",
+              (orc["depth"][m] - ref["depth"][m]).abs().max().item(), " mask equal:", bool(torch.equal(orc["mask"], m)),
+              " points_affine max|d|", (orc["points_affine"] - fwd["points"][0]).abs().max().item())
+        # reference fp16-autocast execution (what the pipeline runs on a GPU) is not available on CPU for convs in
+        # every torch build; the anchor for the tolerance is therefore the bf16 CPU autocast of the same forward
+        with torch.no_grad(), torch.autocast("cpu", dtype=torch.bfloat16):
+            f16 = model.forward(img[None], num_tokens=ntok)
+        dz = (f16["points"][0, ..., 2].float() - fwd["points"][0, ..., 2]).abs()
+        print(f"   reference bf16-autocast vs fp32 on affine z: mean {dz.mean().item():.3e} max {dz.max().item():.3e}")
+        save = dict(shape=np.array([H, W, level]), depth=ref["depth"].numpy(), mask=np.packbits(m.numpy()),
+                    points_affine_z=fwd["points"][0, ..., 2].numpy(), mask_prob=fwd["mask"][0].numpy(),
+                    metric_scale=fwd["metric_scale"].numpy(), intrinsics=ref["intrinsics"].numpy(),
+                    bf16err_z=np.array([dz.mean().item(), dz.max().item()]))
+        if H * W < 20000:
+            save["points_affine"] = fwd["points"][0].numpy()
+        np.savez_compressed(os.path.join(out_dir, name + ".npz"), **save)
+        print("   wrote", name)
+
+
+if __name__ == "__main__":
+    main()

@@ -25,6 +25,9 @@ struct GemmParams {
   int rpg, gstride, goff;    // row remap: orow = (m / rpg) * gstride + goff + (m % rpg); rpg == 0 -> orow = m
   const float* addtab; long ldadd;  // optional f32 table [rpg][ldadd], row (m % rpg), added after everything else
   float qscale; int qcols;   // columns n < qcols are multiplied by qscale (softmax scale folded into q)
+  // implicit-GEMM 3x3 convolution, replicate padding (moge/model/modules.py:47-60): A is an NHWC image
+  // [B][cH][cW][cC] (cC % 64 == 0), row m = pixel, K = 9 * cC with k = (ky*3 + kx) * cC + ci; cW == 0 -> plain GEMM
+  int cH, cW, cC;
 };
 
 #define BM 128
@@ -47,7 +50,34 @@ __device__ __forceinline__ void stage_tile(const char* gbase, long ld_bytes, int
   }
 }
 
-template <bool IS_BF16, bool OUT_BF16, int ACT>
+// A-operand staging for the 3x3 convolution: the K-step t covers one tap and one 64-channel block; the source row of
+// tile row r is the replicate-clamped neighbour pixel of pixel (row0 + r).
+__device__ __forceinline__ void stage_tile_conv(const GemmParams& p, int row0, int t, char* lds_tile, int wave,
+                                                int lane) {
+  const int cblocks = p.cC >> 6;
+  const int tap = t / cblocks, c0 = (t - tap * cblocks) << 6;
+  const int ky = tap / 3 - 1, kx = tap - (tap / 3) * 3 - 1;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int seg = wave * 4 + i;
+    const int row = seg * 8 + (lane >> 3);
+    const int pos = lane & 7;
+    const int c = pos ^ ((row >> 1) & 7);
+    int m = row0 + row;
+    m = m < p.M ? m : p.M - 1;
+    const int x = m % p.cW;
+    const int by = m / p.cW;  // b * cH + y
+    const int y = by % p.cH;
+    int yy = y + ky, xx = x + kx;
+    yy = yy < 0 ? 0 : (yy >= p.cH ? p.cH - 1 : yy);
+    xx = xx < 0 ? 0 : (xx >= p.cW ? p.cW - 1 : xx);
+    const long pix = (long)(by - y + yy) * p.cW + xx;
+    const char* src = (const char*)p.A + (pix * p.lda + c0) * 2 + c * 16;
+    __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(lds_tile + seg * 1024), 16, 0, 0);
+  }
+}
+
+template <bool IS_BF16, bool OUT_BF16, int ACT, bool CONV = false>
 __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -82,7 +112,8 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmParams p) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  stage_tile<ESZ>(Ab, lda_b, bm * BM, p.M, 0, LDS_A(0), wave, lane);
+  if constexpr (CONV) stage_tile_conv(p, bm * BM, 0, LDS_A(0), wave, lane);
+  else stage_tile<ESZ>(Ab, lda_b, bm * BM, p.M, 0, LDS_A(0), wave, lane);
   stage_tile<ESZ>(Wb, ldw_b, bn * BN, p.N, 0, LDS_W(0), wave, lane);
   __syncthreads();  // drains the LDS-DMA (vmcnt(0)) and publishes the tile
 
@@ -93,7 +124,8 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmParams p) {
   int cur = 0;
   for (int t = 0; t < nk; ++t) {
     if (t + 1 < nk) {
-      stage_tile<ESZ>(Ab, lda_b, bm * BM, p.M, (long)(t + 1) * 128, LDS_A(cur ^ 1), wave, lane);
+      if constexpr (CONV) stage_tile_conv(p, bm * BM, t + 1, LDS_A(cur ^ 1), wave, lane);
+      else stage_tile<ESZ>(Ab, lda_b, bm * BM, p.M, (long)(t + 1) * 128, LDS_A(cur ^ 1), wave, lane);
       stage_tile<ESZ>(Wb, ldw_b, bn * BN, p.N, (long)(t + 1) * 128, LDS_W(cur ^ 1), wave, lane);
     }
     const char* la = LDS_A(cur) + (wm * 64 + frow) * 128;
@@ -187,13 +219,13 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmParams p) {
   }
 }
 
-template <bool IS_BF16, bool OUT_BF16, int ACT>
+template <bool IS_BF16, bool OUT_BF16, int ACT, bool CONV = false>
 static int launch_gemm(const GemmParams& p, hipStream_t stream) {
   const int nbm = (p.M + BM - 1) / BM, nbn = p.N / BN;
-  auto kern = gemm_tn_kernel<IS_BF16, OUT_BF16, ACT>;
+  auto kern = gemm_tn_kernel<IS_BF16, OUT_BF16, ACT, CONV>;
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES);
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES);
     attr_set = true;
   }
   hipLaunchKernelGGL(kern, dim3(nbm * nbn), dim3(256), 4 * TILE_BYTES, stream, p);
@@ -220,6 +252,7 @@ extern "C" int pi3_gemm(const void* A, long lda, const void* W, long ldw, int M,
   p.bias = bias; p.gamma = gamma; p.resid = resid; p.ldr = ldr; p.out = out; p.ldo = ldo;
   p.rpg = rpg; p.gstride = gstride; p.goff = goff; p.addtab = addtab; p.ldadd = ldadd;
   p.qscale = qscale; p.qcols = qcols;
+  p.cH = 0; p.cW = 0; p.cC = 0;
   hipStream_t s = (hipStream_t)stream;
 #define GEMM_CASE(INB, OUTB, ACTV) \
   if ((in_dtype == 0) == INB && (out_dtype == 0) == OUTB && act == ACTV) return launch_gemm<INB, OUTB, ACTV>(p, s);
@@ -232,5 +265,30 @@ extern "C" int pi3_gemm(const void* A, long lda, const void* W, long ldw, int M,
   GEMM_CASE(false, true, 0)
 #undef GEMM_CASE
   pi3_set_error("pi3_gemm: unsupported (in_dtype=%d,out_dtype=%d,act=%d) combination", in_dtype, out_dtype, act);
+  return PI3_ERR_ARG;
+}
+
+// 3x3 convolution, stride 1, replicate padding, as an implicit GEMM on an NHWC bf16 image (nn.Conv2d(..., 3, padding=1,
+// padding_mode='replicate') in moge/model/modules.py:47-60,146-164).  img: bf16 [B][H][W][ldc] with C % 64 == 0 used
+// channels; wgt: bf16 [N][9*C], k = (ky*3 + kx)*C + ci; out rows = pixels.  Epilogue as pi3_gemm (bias, resid, act).
+extern "C" int pi3_conv3x3(const void* img, long ldc, int B, int H, int W, int C, const void* wgt, int N,
+                           const float* bias, const float* resid, long ldr, void* out, long ldo, int out_dtype, int act,
+                           void* stream) {
+  if (!img || !wgt || !out || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C % 64) || N <= 0 || (N % BN) || (ldc % 8) ||
+      ((uintptr_t)img & 15) || ((uintptr_t)wgt & 15) || ((uintptr_t)out & 15) || (ldo % 4) || act < 0 || act > 2 ||
+      (long)B * H * W > 0x7fffffffL) {
+    pi3_set_error("pi3_conv3x3: bad arguments B=%d H=%d W=%d C=%d N=%d (C %% 64 == 0, N %% 128 == 0)", B, H, W, C, N);
+    return PI3_ERR_ARG;
+  }
+  GemmParams p;
+  p.A = img; p.lda = ldc; p.W = wgt; p.ldw = 9L * C; p.M = B * H * W; p.N = N; p.K = 9 * C;
+  p.bias = bias; p.gamma = nullptr; p.resid = resid; p.ldr = ldr; p.out = out; p.ldo = ldo;
+  p.rpg = 0; p.gstride = 0; p.goff = 0; p.addtab = nullptr; p.ldadd = 0; p.qscale = 1.f; p.qcols = 0;
+  p.cH = H; p.cW = W; p.cC = C;
+  hipStream_t s = (hipStream_t)stream;
+  if (out_dtype == 0 && act == 0) return launch_gemm<true, true, 0, true>(p, s);
+  if (out_dtype == 1 && act == 0) return launch_gemm<true, false, 0, true>(p, s);
+  if (out_dtype == 0 && act == 2) return launch_gemm<true, true, 2, true>(p, s);
+  pi3_set_error("pi3_conv3x3: unsupported (out_dtype=%d, act=%d)", out_dtype, act);
   return PI3_ERR_ARG;
 }

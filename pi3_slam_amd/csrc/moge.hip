@@ -1,0 +1,306 @@
+// MoGe-2 metric-scale forward (moge/model/v2.py:128-290, moge/model/modules.py:18-254): the kernels that are not
+// shared with the pi3 transformer path.  Activations of the conv pyramid live in HBM as NHWC fp32 ("x") plus a bf16
+// NHWC staging image per convolution input (channel stride padded to a multiple of 64, pad = 0) so that 3x3
+// replicate-padded convolutions run as implicit GEMMs on the MFMA path (pi3_conv3x3 in gemm.hip) and 1x1 convolutions
+// as plain pi3_gemm calls.  Everything here is HBM-bound row / pixel work.
+#include "common.h"
+#include <float.h>
+
+// ---------------------------------------------------------------------------------------------------------------
+// GroupNorm statistics (nn.GroupNorm(G, C), modules.py:47-56: G = C/32 'group_norm' or G = 1 'layer_norm').
+// x: f32 [B][HW][ldx]; stats: f64 [B][G][2] (sum, sum of squares), must be zeroed by the caller.
+// A wave walks pixels; lane l owns channels l, l+64, ... (a fixed group per (lane, j)), fp32 partials per pixel chunk,
+// fp64 across chunks, LDS f64 atomics per block, one global f64 atomic per (block, group).
+// ---------------------------------------------------------------------------------------------------------------
+#define GN_MAXJ 16  // C <= 1024
+__global__ __launch_bounds__(256) void groupnorm_stats_kernel(const float* __restrict__ x, long ldx, int HW, int C,
+                                                              int G, double* __restrict__ stats) {
+  __shared__ double acc[2 * 64];  // G <= 64 groups per sample handled (C <= 1024, cpg >= 16)
+  const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int cpg = C / G;
+  for (int i = tid; i < 2 * G; i += 256) acc[i] = 0.0;
+  __syncthreads();
+  const int nj = (C + 63) >> 6;
+  double s[GN_MAXJ], q[GN_MAXJ];
+#pragma unroll
+  for (int j = 0; j < GN_MAXJ; ++j) { s[j] = 0.0; q[j] = 0.0; }
+  const int per_block = (HW + gridDim.x - 1) / gridDim.x;
+  const int p0 = blockIdx.x * per_block, p1 = min(HW, p0 + per_block);
+  const float* xb = x + (long)b * HW * ldx;
+  for (int pc = p0 + wave * 64; pc < p1; pc += 256) {   // chunks of 64 pixels per wave: fp32 partials inside a chunk
+    float fs[GN_MAXJ], fq[GN_MAXJ];
+#pragma unroll
+    for (int j = 0; j < GN_MAXJ; ++j) { fs[j] = 0.f; fq[j] = 0.f; }
+    const int pe = min(p1, pc + 64);
+    for (int p = pc; p < pe; ++p) {
+      const float* row = xb + (long)p * ldx;
+#pragma unroll
+      for (int j = 0; j < GN_MAXJ; ++j) {
+        const int c = lane + 64 * j;
+        if (j < nj && c < C) {
+          const float v = row[c];
+          fs[j] += v;
+          fq[j] += v * v;
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < GN_MAXJ; ++j) { s[j] += (double)fs[j]; q[j] += (double)fq[j]; }
+  }
+#pragma unroll
+  for (int j = 0; j < GN_MAXJ; ++j) {
+    const int c = lane + 64 * j;
+    if (j < nj && c < C) {
+      const int g = c / cpg;
+      atomicAdd(&acc[2 * g], s[j]);
+      atomicAdd(&acc[2 * g + 1], q[j]);
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < 2 * G; i += 256) atomicAdd(&stats[(long)b * 2 * G + i], acc[i]);
+}
+
+extern "C" int pi3_groupnorm_stats(const float* x, long ldx, int B, int HW, int C, int G, double* stats,
+                                   void* stream) {
+  if (!x || !stats || B <= 0 || HW <= 0 || C <= 0 || G <= 0 || (C % G) || C > 64 * GN_MAXJ || G > 64) {
+    pi3_set_error("pi3_groupnorm_stats: bad arguments C=%d G=%d", C, G);
+    return PI3_ERR_ARG;
+  }
+  (void)hipMemsetAsync(stats, 0, sizeof(double) * 2 * G * B, (hipStream_t)stream);
+  int bx = (HW + 1023) / 1024;
+  if (bx > 1024) bx = 1024;
+  hipLaunchKernelGGL(groupnorm_stats_kernel, dim3(bx, B), dim3(256), 0, (hipStream_t)stream, x, ldx, HW, C, G, stats);
+  return pi3_check_launch("groupnorm_stats");
+}
+
+// y = act((x - mean_g) * rstd_g * gamma_c + beta_c) -> bf16 NHWC staging image [B][HW][ldo], channels [C, Cpad) = 0.
+// act: 0 none, 2 ReLU (same codes as pi3_gemm).  eps = 1e-5 (nn.GroupNorm default).
+__global__ __launch_bounds__(256) void groupnorm_apply_kernel(const float* __restrict__ x, long ldx, int HW, int C,
+                                                              int Cpad, int G, const double* __restrict__ stats,
+                                                              const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, float eps, int act,
+                                                              bf16_t* __restrict__ out, long ldo, long total) {
+  const int cpg = C / G;
+  const int cv = Cpad >> 1;  // two channels per thread
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int c = (int)(i % cv) * 2;
+    const long bp = i / cv;  // b * HW + p
+    const int b = (int)(bp / HW);
+    float y[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int cc = c + e;
+      if (cc < C) {
+        const int g = cc / cpg;
+        const double n = (double)cpg * (double)HW;
+        const double mean = stats[((long)b * G + g) * 2] / n;
+        const double var = stats[((long)b * G + g) * 2 + 1] / n - mean * mean;
+        const float rstd = (float)(1.0 / sqrt((var > 0.0 ? var : 0.0) + (double)eps));
+        float v = (x[bp * ldx + cc] - (float)mean) * rstd * gamma[cc] + beta[cc];
+        if (act == 2) v = fmaxf(v, 0.f);
+        y[e] = v;
+      } else {
+        y[e] = 0.f;
+      }
+    }
+    *(uint32_t*)(out + bp * ldo + c) = pack_bf16x2(y[0], y[1]);
+  }
+}
+
+extern "C" int pi3_groupnorm_apply(const float* x, long ldx, int B, int HW, int C, int Cpad, int G,
+                                   const double* stats, const float* gamma, const float* beta, float eps, int act,
+                                   void* out, long ldo, void* stream) {
+  if (!x || !stats || !gamma || !beta || !out || C <= 0 || Cpad < C || (Cpad % 2) || (ldo % 2) || (C % G)) {
+    pi3_set_error("pi3_groupnorm_apply: bad arguments");
+    return PI3_ERR_ARG;
+  }
+  const long total = (long)B * HW * (Cpad / 2);
+  long blocks = (total + 255) / 256;
+  if (blocks > 256 * 32) blocks = 256 * 32;
+  hipLaunchKernelGGL(groupnorm_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, ldx, HW, C,
+                     Cpad, G, stats, gamma, beta, eps, act, (bf16_t*)out, ldo, total);
+  return pi3_check_launch("groupnorm_apply");
+}
+
+// ConvTranspose2d(k=2, s=2) second half (modules.py:160-163): the GEMM produced g[pixel][(dy*2+dx)*Cs + co] (f32, bias
+// included); scatter to the 2x up-sampled bf16 NHWC staging image out[b][2y+dy][2x+dx][co], pad channels = 0.
+__global__ __launch_bounds__(256) void convt_scatter_kernel(const float* __restrict__ g, long ldg, int B, int H, int W,
+                                                            int Cout, int Cs, int Cpad, bf16_t* __restrict__ out,
+                                                            long ldo, long total) {
+  const int cv = Cpad >> 1;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int c = (int)(i % cv) * 2;
+    const long op = i / cv;  // output pixel index over [B][2H][2W]
+    const int ox = (int)(op % (2 * W));
+    const long r = op / (2 * W);
+    const int oy = (int)(r % (2 * H));
+    const int b = (int)(r / (2 * H));
+    const long ip = ((long)b * H + (oy >> 1)) * W + (ox >> 1);
+    const int q = (oy & 1) * 2 + (ox & 1);
+    const float a = c < Cout ? g[ip * ldg + (long)q * Cs + c] : 0.f;
+    const float bb = (c + 1) < Cout ? g[ip * ldg + (long)q * Cs + c + 1] : 0.f;
+    *(uint32_t*)(out + op * ldo + c) = pack_bf16x2(a, bb);
+  }
+}
+
+extern "C" int pi3_convt_scatter(const float* g, long ldg, int B, int H, int W, int Cout, int Cs, int Cpad, void* out,
+                                 long ldo, void* stream) {
+  if (!g || !out || B <= 0 || H <= 0 || W <= 0 || Cout <= 0 || Cs < Cout || Cpad < Cout || (Cpad % 2) || (ldo % 2)) {
+    pi3_set_error("pi3_convt_scatter: bad arguments");
+    return PI3_ERR_ARG;
+  }
+  const long total = (long)B * 4 * H * W * (Cpad / 2);
+  long blocks = (total + 255) / 256;
+  if (blocks > 256 * 32) blocks = 256 * 32;
+  hipLaunchKernelGGL(convt_scatter_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g, ldg, B, H, W,
+                     Cout, Cs, Cpad, (bf16_t*)out, ldo, total);
+  return pi3_check_launch("convt_scatter");
+}
+
+// 1x1 convolution of the 2-channel UV map (v2.py:141-147 concat + modules.py:214 input block), fused:
+// x[b][y][x][c] (+)= w[c][wofs] * u[x] + w[c][wofs+1] * v[y] + bias[c];  w row stride ldw.  accumulate != 0 adds.
+__global__ __launch_bounds__(256) void uv_affine_kernel(float* __restrict__ x, long ldx, int H, int W, int C,
+                                                        const float* __restrict__ w, long ldw, int wofs,
+                                                        const float* __restrict__ bias, const float* __restrict__ uvx,
+                                                        const float* __restrict__ uvy, int accumulate, long total) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int c = (int)(i % C);
+    const long p = i / C;
+    const int px = (int)(p % W);
+    const int py = (int)((p / W) % H);
+    float v = w[(long)c * ldw + wofs] * uvx[px] + w[(long)c * ldw + wofs + 1] * uvy[py];
+    if (bias) v += bias[c];
+    float* dst = x + p * ldx + c;
+    *dst = accumulate ? (*dst + v) : v;
+  }
+}
+
+extern "C" int pi3_uv_affine(float* x, long ldx, int B, int H, int W, int C, const float* w, long ldw, int wofs,
+                             const float* bias, const float* uvx, const float* uvy, int accumulate, void* stream) {
+  if (!x || !w || !uvx || !uvy || B <= 0 || H <= 0 || W <= 0 || C <= 0) {
+    pi3_set_error("pi3_uv_affine: bad arguments");
+    return PI3_ERR_ARG;
+  }
+  const long total = (long)B * H * W * C;
+  long blocks = (total + 255) / 256;
+  if (blocks > 256 * 32) blocks = 256 * 32;
+  hipLaunchKernelGGL(uv_affine_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, ldx, H, W, C, w,
+                     ldw, wofs, bias, uvx, uvy, accumulate, total);
+  return pi3_check_launch("uv_affine");
+}
+
+// Separable resize with host-built tap tables (F.interpolate bilinear, antialias or not: modules.py:121, v2.py:157).
+// src element (c, y, x) at src[c*sc + y*sy + x*sx]; dst likewise.  Table per output index: start, count, weights[MT].
+#define RS_MT 8
+__global__ __launch_bounds__(256) void resize_taps_kernel(const float* __restrict__ src, long sc, long sy, long sx,
+                                                          int C, const int* __restrict__ ys,
+                                                          const float* __restrict__ yw, const int* __restrict__ xs,
+                                                          const float* __restrict__ xw, int oh, int ow,
+                                                          float* __restrict__ dst, long dc, long dy, long dx,
+                                                          long total) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int ox = (int)(i % ow);
+    const int oy = (int)((i / ow) % oh);
+    const int c = (int)(i / ((long)ow * oh));
+    const int y0 = ys[2 * oy], yn = ys[2 * oy + 1], x0 = xs[2 * ox], xn = xs[2 * ox + 1];
+    float acc = 0.f;
+    for (int a = 0; a < yn; ++a) {
+      float rowacc = 0.f;
+      const float* row = src + (long)c * sc + (long)(y0 + a) * sy;
+      for (int b = 0; b < xn; ++b) rowacc += xw[ox * RS_MT + b] * row[(long)(x0 + b) * sx];
+      acc += yw[oy * RS_MT + a] * rowacc;
+    }
+    dst[(long)c * dc + (long)oy * dy + (long)ox * dx] = acc;
+  }
+}
+
+extern "C" int pi3_resize_taps(const float* src, long sc, long sy, long sx, int C, const int* ys, const float* yw,
+                               const int* xs, const float* xw, int oh, int ow, float* dst, long dc, long dy, long dx,
+                               void* stream) {
+  if (!src || !ys || !yw || !xs || !xw || !dst || C <= 0 || oh <= 0 || ow <= 0) {
+    pi3_set_error("pi3_resize_taps: bad arguments");
+    return PI3_ERR_ARG;
+  }
+  const long total = (long)C * oh * ow;
+  long blocks = (total + 255) / 256;
+  if (blocks > 256 * 32) blocks = 256 * 32;
+  hipLaunchKernelGGL(resize_taps_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, src, sc, sy, sx, C,
+                     ys, yw, xs, xw, oh, ow, dst, dc, dy, dx, total);
+  return pi3_check_launch("resize_taps");
+}
+
+// y = act(W x + b) for one vector (scale_head MLP on the class token, modules.py:184-192).  One workgroup.
+__global__ __launch_bounds__(256) void dense_vec_kernel(const float* __restrict__ x, const float* __restrict__ Wt,
+                                                        const float* __restrict__ b, int K, int N, int act,
+                                                        float* __restrict__ y) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int j = wave; j < N; j += 4) {
+    float acc = 0.f;
+    for (int k = lane; k < K; k += 64) acc += Wt[(long)j * K + k] * x[k];
+    acc = wave_sum(acc);
+    if (lane == 0) {
+      float v = acc + (b ? b[j] : 0.f);
+      y[j] = act == 2 ? fmaxf(v, 0.f) : v;
+    }
+  }
+}
+
+extern "C" int pi3_dense_vec(const float* x, const float* Wt, const float* b, int K, int N, int act, float* y,
+                             void* stream) {
+  if (!x || !Wt || !y || K <= 0 || N <= 0) {
+    pi3_set_error("pi3_dense_vec: bad arguments");
+    return PI3_ERR_ARG;
+  }
+  hipLaunchKernelGGL(dense_vec_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, x, Wt, b, K, N, act, y);
+  return pi3_check_launch("dense_vec");
+}
+
+// v2.py:160-170 on the resized maps: points (HW x 3 f32, in place) remapped ('linear' 0, 'exp' 1, 'sinh' 2,
+// 'sinh_exp' 3), mask logit -> sigmoid -> binary (> 0.5) uint8.
+__global__ __launch_bounds__(256) void moge_remap_kernel(float* __restrict__ pts, const float* __restrict__ mlogit,
+                                                         long n, int remap, uint8_t* __restrict__ mask) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float x = pts[3 * i], y = pts[3 * i + 1], z = pts[3 * i + 2];
+  if (remap == 1) { z = expf(z); x *= z; y *= z; }
+  else if (remap == 2) { x = sinhf(x); y = sinhf(y); z = sinhf(z); }
+  else if (remap == 3) { x = sinhf(x); y = sinhf(y); z = expf(z); }
+  pts[3 * i] = x; pts[3 * i + 1] = y; pts[3 * i + 2] = z;
+  if (mask) mask[i] = mlogit ? ((1.0f / (1.0f + expf(-mlogit[i]))) > 0.5f ? 1 : 0) : 1;
+}
+
+extern "C" int pi3_moge_remap(float* pts, const float* mask_logit, long n, int remap, unsigned char* mask,
+                              void* stream) {
+  if (!pts || n <= 0 || remap < 0 || remap > 3) {
+    pi3_set_error("pi3_moge_remap: bad arguments");
+    return PI3_ERR_ARG;
+  }
+  hipLaunchKernelGGL(moge_remap_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, pts,
+                     mask_logit, n, remap, mask);
+  return pi3_check_launch("moge_remap");
+}
+
+// v2.py:255-274: depth = (z + shift); mask &= depth > 0; depth *= metric_scale; depth = mask ? depth : +inf.
+// shift, log_scale: device scalars (log_scale = scale_head output before exp, or NULL).
+__global__ __launch_bounds__(256) void moge_depth_kernel(const float* __restrict__ pts, const float* __restrict__ shift,
+                                                         const float* __restrict__ log_scale, uint8_t* __restrict__ mask,
+                                                         long n, float* __restrict__ depth) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float d = pts[3 * i + 2] + shift[0];
+  const bool ok = mask[i] && d > 0.f;
+  mask[i] = ok ? 1 : 0;
+  if (log_scale) d *= expf(log_scale[0]);
+  depth[i] = ok ? d : INFINITY;
+}
+
+extern "C" int pi3_moge_depth(const float* pts, const float* shift, const float* log_scale, unsigned char* mask, long n,
+                              float* depth, void* stream) {
+  if (!pts || !shift || !mask || !depth || n <= 0) {
+    pi3_set_error("pi3_moge_depth: bad arguments");
+    return PI3_ERR_ARG;
+  }
+  hipLaunchKernelGGL(moge_depth_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, pts,
+                     shift, log_scale, mask, n, depth);
+  return pi3_check_launch("moge_depth");
+}

@@ -299,6 +299,7 @@ __device__ __forceinline__ double fs_resnorm2(const FsPoint* pts, int n, double 
 
 __global__ __launch_bounds__(256) void focal_shift_kernel(const float* __restrict__ local_points,
                                                           const float* __restrict__ conf,
+                                                          const uint8_t* __restrict__ mask8,
                                                           const float* __restrict__ uvx,
                                                           const float* __restrict__ uvy, int H, int W, float conf_thr,
                                                           float* __restrict__ o_focal, float* __restrict__ o_shift,
@@ -319,7 +320,7 @@ __global__ __launch_bounds__(256) void focal_shift_kernel(const float* __restric
     const int i = k / FS_N, j = k - i * FS_N;
     const int yy = min((int)floorf(i * sy), H - 1), xx = min((int)floorf(j * sx), W - 1);
     const long p = fo + (long)yy * W + xx;
-    const bool ok = (1.0f / (1.0f + expf(-conf[p]))) > conf_thr;
+    const bool ok = mask8 ? (mask8[p] != 0) : ((1.0f / (1.0f + expf(-conf[p]))) > conf_thr);
     const unsigned long long bal = __ballot(ok);
     const int before = __popcll(bal & ((1ull << lane) - 1ull));
     if (lane == 0) woff[wave + 1] = __popcll(bal);
@@ -469,14 +470,16 @@ __global__ __launch_bounds__(256) void focal_shift_kernel(const float* __restric
   }
 }
 
-extern "C" int pi3_focal_shift(const float* local_points, const float* conf, const float* uvx, const float* uvy,
-                               int F, int H, int W, float conf_thr, float* focal, float* shift, float* fxfycxcy,
-                               float* K33, void* stream) {
-  if (!local_points || !conf || !uvx || !uvy || !focal || !shift || !fxfycxcy || !K33 || F <= 0 || H <= 0 || W <= 0) {
+// Validity of a pixel: mask8 != NULL ? mask8[p] != 0 : sigmoid(conf[p]) > conf_thr (MoGe passes its own binary mask,
+// moge/model/v2.py:241; the pi3 path uses the confidence, utils/camera_estimation.py:37).
+extern "C" int pi3_focal_shift(const float* local_points, const float* conf, const unsigned char* mask8,
+                               const float* uvx, const float* uvy, int F, int H, int W, float conf_thr, float* focal,
+                               float* shift, float* fxfycxcy, float* K33, void* stream) {
+  if (!local_points || (!conf && !mask8) || !uvx || !uvy || !focal || !shift || !fxfycxcy || !K33 || F <= 0 || H <= 0 || W <= 0) {
     pi3_set_error("pi3_focal_shift: bad arguments");
     return PI3_ERR_ARG;
   }
-  hipLaunchKernelGGL(focal_shift_kernel, dim3(F), dim3(256), 0, (hipStream_t)stream, local_points, conf, uvx, uvy, H,
-                     W, conf_thr, focal, shift, fxfycxcy, K33);
+  hipLaunchKernelGGL(focal_shift_kernel, dim3(F), dim3(256), 0, (hipStream_t)stream, local_points, conf, mask8, uvx,
+                     uvy, H, W, conf_thr, focal, shift, fxfycxcy, K33);
   return pi3_check_launch("focal_shift");
 }

@@ -25,6 +25,7 @@ import numpy as np
 import torch
 
 from . import ops
+from .vit import run_block
 from .weights import IMAGE_MEAN, IMAGE_STD, Pi3Config, load_checkpoint, param_shapes, recipe_fill_device
 
 _BF16_SUFFIXES = ("attn.qkv.weight", "attn.proj.weight", "mlp.fc1.weight", "mlp.fc2.weight", "projects.weight",
@@ -158,34 +159,8 @@ class Pi3Engine:
     # ------------------------------------------------------------------ transformer block
     def _block(self, prefix: str, x: torch.Tensor, S: int, attn_B: int, attn_S: int, T: int, consts, rope: bool,
                qk_norm: bool, ls: bool, bufs, attn_events: Optional[list] = None) -> None:
-        cfg, w = self.cfg, self.w
-        D, H = cfg.dim, cfg.heads
-        xn, qkv, ao, hid = bufs
-        ops.layernorm(x, w[f"{prefix}.norm1.weight"], w[f"{prefix}.norm1.bias"], xn, cfg.eps, rows=S)
-        fused = rope or qk_norm
-        ops.gemm(xn, w[f"{prefix}.attn.qkv.weight"], qkv, M=S, bias=w[f"{prefix}.attn.qkv.bias"],
-                 qscale=1.0 if fused else ops.QSCALE, qcols=0 if fused else D)
-        if fused:
-            ops.qknorm_rope(qkv, S, H, T, consts["pos"], consts["cs"],
-                            w.get(f"{prefix}.attn.q_norm.weight") if qk_norm else None,
-                            w.get(f"{prefix}.attn.q_norm.bias") if qk_norm else None,
-                            w.get(f"{prefix}.attn.k_norm.weight") if qk_norm else None,
-                            w.get(f"{prefix}.attn.k_norm.bias") if qk_norm else None,
-                            eps=1e-5 if qk_norm else cfg.eps, qscale=ops.QSCALE, do_rope=rope)
-        if attn_events is not None:  # bench.py: HIP events on the launch stream around the dominant kernel
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            ops.attention(qkv, ao, attn_B, attn_S, H)
-            e1.record()
-            attn_events.append((e0, e1))
-        else:
-            ops.attention(qkv, ao, attn_B, attn_S, H)
-        ops.gemm(ao, w[f"{prefix}.attn.proj.weight"], x, M=S, bias=w[f"{prefix}.attn.proj.bias"],
-                 gamma=w[f"{prefix}.ls1.gamma"] if ls else None, resid=x)
-        ops.layernorm(x, w[f"{prefix}.norm2.weight"], w[f"{prefix}.norm2.bias"], xn, cfg.eps, rows=S)
-        ops.gemm(xn, w[f"{prefix}.mlp.fc1.weight"], hid, M=S, bias=w[f"{prefix}.mlp.fc1.bias"], act=ops.ACT_GELU)
-        ops.gemm(hid, w[f"{prefix}.mlp.fc2.weight"], x, M=S, bias=w[f"{prefix}.mlp.fc2.bias"],
-                 gamma=w[f"{prefix}.ls2.gamma"] if ls else None, resid=x)
+        run_block(self.w, prefix, x, S, attn_B, attn_S, T, self.cfg.heads, bufs, rope=rope, qk_norm=qk_norm, ls=ls,
+                  eps=self.cfg.eps, pos=consts["pos"], cs=consts["cs"], attn_events=attn_events)
 
     # ------------------------------------------------------------------ forward
     @torch.no_grad()

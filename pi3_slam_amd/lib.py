@@ -34,7 +34,16 @@ SIGNATURES = {
     "pi3_masked_ratio_median": [_vp, _vp, _l, _vp, _l, _vp, _vp],
     "pi3_apply_scale": [_vp, _vp, _vp, _l, _vp, _i, _vp],
     "pi3_gather_keypoints": [_vp] * 6 + [_i] * 4 + [_vp] * 7,
-    "pi3_focal_shift": [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp],
+    "pi3_focal_shift": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp],
+    "pi3_conv3x3": [_vp, _l, _i, _i, _i, _i, _vp, _i, _vp, _vp, _l, _vp, _l, _i, _i, _vp],
+    "pi3_groupnorm_stats": [_vp, _l, _i, _i, _i, _i, _vp, _vp],
+    "pi3_groupnorm_apply": [_vp, _l, _i, _i, _i, _i, _i, _vp, _vp, _vp, _f, _i, _vp, _l, _vp],
+    "pi3_convt_scatter": [_vp, _l, _i, _i, _i, _i, _i, _i, _vp, _l, _vp],
+    "pi3_uv_affine": [_vp, _l, _i, _i, _i, _i, _vp, _l, _i, _vp, _vp, _vp, _i, _vp],
+    "pi3_resize_taps": [_vp, _l, _l, _l, _i, _vp, _vp, _vp, _vp, _i, _i, _vp, _l, _l, _l, _vp],
+    "pi3_dense_vec": [_vp, _vp, _vp, _i, _i, _i, _vp, _vp],
+    "pi3_moge_remap": [_vp, _vp, _l, _i, _vp, _vp],
+    "pi3_moge_depth": [_vp, _vp, _vp, _vp, _l, _vp, _vp],
     "pi3_sim3_match_keypoints": [_vp, _vp, _i, _i, _vp, _vp],
     "pi3_sim3_umeyama": [_vp] * 5 + [_i, _i, _vp, _i, _vp, _vp],
     "pi3_sim3_apply": [_vp, _vp, _l, _vp, _i, _vp],

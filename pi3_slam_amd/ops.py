@@ -277,19 +277,95 @@ def sim3_compose_prefix(T: torch.Tensor) -> torch.Tensor:
     return G
 
 
-def focal_shift(local_points: torch.Tensor, conf: torch.Tensor, uvx: torch.Tensor, uvy: torch.Tensor,
-                conf_thr: float = 0.1):
-    """local_points [F,H,W,3], conf [F,H,W,(1)] f32 -> dict(focal [F], shift [F], fxfycxcy [F,4], intrinsics [F,3,3])."""
+def focal_shift(local_points: torch.Tensor, conf: Optional[torch.Tensor], uvx: torch.Tensor, uvy: torch.Tensor,
+                conf_thr: float = 0.1, mask: Optional[torch.Tensor] = None):
+    """local_points [F,H,W,3], conf [F,H,W,(1)] f32 (or mask uint8 [F,H,W]) -> dict(focal [F], shift [F],
+    fxfycxcy [F,4], intrinsics [F,3,3])."""
     lib = _L.load()
     F, H, W = local_points.shape[:3]
-    assert local_points.is_contiguous() and conf.is_contiguous() and uvx.numel() == W and uvy.numel() == H
+    assert local_points.is_contiguous() and uvx.numel() == W and uvy.numel() == H
+    assert (conf is not None and conf.is_contiguous()) or (mask is not None and mask.is_contiguous())
     dev = local_points.device
     focal = torch.empty(F, device=dev, dtype=torch.float32)
     shift = torch.empty(F, device=dev, dtype=torch.float32)
     fxy = torch.empty(F, 4, device=dev, dtype=torch.float32)
     K = torch.empty(F, 3, 3, device=dev, dtype=torch.float32)
-    rc = lib.pi3_focal_shift(local_points.data_ptr(), conf.data_ptr(), uvx.data_ptr(), uvy.data_ptr(), F, H, W,
+    rc = lib.pi3_focal_shift(local_points.data_ptr(), _L.ptr(conf), _L.ptr(mask), uvx.data_ptr(), uvy.data_ptr(), F, H, W,
                              float(conf_thr), focal.data_ptr(), shift.data_ptr(), fxy.data_ptr(), K.data_ptr(),
                              _L.stream_ptr())
     _L.check(rc, "pi3_focal_shift")
     return dict(focal=focal, shift=shift, fxfycxcy=fxy, intrinsics=K)
+
+
+# ----------------------------------------------------------------------------------------------- MoGe conv pyramid
+def conv3x3(img: torch.Tensor, H: int, W: int, C: int, wgt: torch.Tensor, bias: Optional[torch.Tensor],
+            out: torch.Tensor, resid: Optional[torch.Tensor] = None, act: int = ACT_NONE) -> torch.Tensor:
+    """img bf16 NHWC [H*W, ldc] (one image), wgt bf16 [N, 9*C]; out [H*W, >=N] f32/bf16."""
+    lib = _L.load()
+    assert img.dtype == torch.bfloat16 and wgt.dtype == torch.bfloat16 and wgt.shape[1] == 9 * C
+    rc = lib.pi3_conv3x3(img.data_ptr(), img.stride(0), 1, H, W, C, wgt.data_ptr(), wgt.shape[0], _L.ptr(bias),
+                         _L.ptr(resid), resid.stride(0) if resid is not None else 0, out.data_ptr(), out.stride(0),
+                         _dt(out), act, _L.stream_ptr())
+    _L.check(rc, "pi3_conv3x3")
+    return out
+
+
+def groupnorm_stats(x: torch.Tensor, HW: int, C: int, G: int, stats: torch.Tensor) -> None:
+    lib = _L.load()
+    assert x.dtype == torch.float32 and stats.dtype == torch.float64 and stats.numel() >= 2 * G
+    rc = lib.pi3_groupnorm_stats(x.data_ptr(), x.stride(0), 1, HW, C, G, stats.data_ptr(), _L.stream_ptr())
+    _L.check(rc, "pi3_groupnorm_stats")
+
+
+def groupnorm_apply(x, HW, C, Cpad, G, stats, gamma, beta, eps, act, out) -> None:
+    lib = _L.load()
+    assert out.dtype == torch.bfloat16 and out.shape[1] >= Cpad
+    rc = lib.pi3_groupnorm_apply(x.data_ptr(), x.stride(0), 1, HW, C, Cpad, G, stats.data_ptr(), gamma.data_ptr(),
+                                 beta.data_ptr(), float(eps), act, out.data_ptr(), out.stride(0), _L.stream_ptr())
+    _L.check(rc, "pi3_groupnorm_apply")
+
+
+def convt_scatter(g: torch.Tensor, H: int, W: int, Cout: int, Cs: int, Cpad: int, out: torch.Tensor) -> None:
+    lib = _L.load()
+    assert g.dtype == torch.float32 and out.dtype == torch.bfloat16
+    rc = lib.pi3_convt_scatter(g.data_ptr(), g.stride(0), 1, H, W, Cout, Cs, Cpad, out.data_ptr(), out.stride(0),
+                               _L.stream_ptr())
+    _L.check(rc, "pi3_convt_scatter")
+
+
+def uv_affine(x, H, W, C, w, wofs, bias, uvx, uvy, accumulate: bool) -> None:
+    lib = _L.load()
+    assert x.dtype == torch.float32 and w.dtype == torch.float32 and w.stride(1) == 1
+    rc = lib.pi3_uv_affine(x.data_ptr(), x.stride(0), 1, H, W, C, w.data_ptr(), w.stride(0), wofs, _L.ptr(bias),
+                           uvx.data_ptr(), uvy.data_ptr(), int(accumulate), _L.stream_ptr())
+    _L.check(rc, "pi3_uv_affine")
+
+
+def resize_taps(src, sstr, C, ys, yw, xs, xw, oh, ow, dst, dstr) -> None:
+    lib = _L.load()
+    assert src.dtype == torch.float32 and dst.dtype == torch.float32 and ys.dtype == torch.int32
+    rc = lib.pi3_resize_taps(src.data_ptr(), sstr[0], sstr[1], sstr[2], C, ys.data_ptr(), yw.data_ptr(),
+                             xs.data_ptr(), xw.data_ptr(), oh, ow, dst.data_ptr(), dstr[0], dstr[1], dstr[2],
+                             _L.stream_ptr())
+    _L.check(rc, "pi3_resize_taps")
+
+
+def dense_vec(x, W, b, act, y) -> None:
+    lib = _L.load()
+    assert W.dtype == torch.float32 and W.is_contiguous() and x.is_contiguous()
+    rc = lib.pi3_dense_vec(x.data_ptr(), W.data_ptr(), _L.ptr(b), W.shape[1], W.shape[0], act, y.data_ptr(),
+                           _L.stream_ptr())
+    _L.check(rc, "pi3_dense_vec")
+
+
+def moge_remap(pts, mask_logit, n, remap, mask) -> None:
+    lib = _L.load()
+    rc = lib.pi3_moge_remap(pts.data_ptr(), _L.ptr(mask_logit), n, remap, mask.data_ptr(), _L.stream_ptr())
+    _L.check(rc, "pi3_moge_remap")
+
+
+def moge_depth(pts, shift, log_scale, mask, n, depth) -> None:
+    lib = _L.load()
+    rc = lib.pi3_moge_depth(pts.data_ptr(), shift.data_ptr(), _L.ptr(log_scale), mask.data_ptr(), n,
+                            depth.data_ptr(), _L.stream_ptr())
+    _L.check(rc, "pi3_moge_depth")

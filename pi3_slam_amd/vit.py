@@ -1,0 +1,44 @@
+"""One pre-LN transformer block as a sequence of C-ABI launches, shared by the pi3 network (encoder / decoder / heads,
+pi3/models/layers/block.py:310-335, pi3/models/dinov2/layers/block.py:88-113) and the MoGe DINOv2 encoder
+(moge/model/dinov2/layers/block.py).  Buffers: xn bf16 [S, D], qkv bf16 [S, 3D], ao bf16 [S, D], hid bf16 [S, 4D]."""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import torch
+
+from . import ops
+
+
+def run_block(w: Dict[str, torch.Tensor], prefix: str, x: torch.Tensor, S: int, attn_B: int, attn_S: int, T: int,
+              heads: int, bufs, *, rope: bool = False, qk_norm: bool = False, ls: bool = True, eps: float = 1e-6,
+              pos: Optional[torch.Tensor] = None, cs: Optional[torch.Tensor] = None,
+              attn_events: Optional[list] = None) -> None:
+    """x (fp32 residual stream [S, D]) is updated in place."""
+    D = heads * 64
+    xn, qkv, ao, hid = bufs
+    ops.layernorm(x, w[f"{prefix}.norm1.weight"], w[f"{prefix}.norm1.bias"], xn, eps, rows=S)
+    fused = rope or qk_norm
+    ops.gemm(xn, w[f"{prefix}.attn.qkv.weight"], qkv, M=S, bias=w[f"{prefix}.attn.qkv.bias"],
+             qscale=1.0 if fused else ops.QSCALE, qcols=0 if fused else D)
+    if fused:
+        ops.qknorm_rope(qkv, S, heads, T, pos, cs,
+                        w.get(f"{prefix}.attn.q_norm.weight") if qk_norm else None,
+                        w.get(f"{prefix}.attn.q_norm.bias") if qk_norm else None,
+                        w.get(f"{prefix}.attn.k_norm.weight") if qk_norm else None,
+                        w.get(f"{prefix}.attn.k_norm.bias") if qk_norm else None,
+                        eps=1e-5 if qk_norm else eps, qscale=ops.QSCALE, do_rope=rope)
+    if attn_events is not None:  # bench.py: HIP events on the launch stream around the dominant kernel
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        ops.attention(qkv, ao, attn_B, attn_S, heads)
+        e1.record()
+        attn_events.append((e0, e1))
+    else:
+        ops.attention(qkv, ao, attn_B, attn_S, heads)
+    ops.gemm(ao, w[f"{prefix}.attn.proj.weight"], x, M=S, bias=w[f"{prefix}.attn.proj.bias"],
+             gamma=w[f"{prefix}.ls1.gamma"] if ls else None, resid=x)
+    ops.layernorm(x, w[f"{prefix}.norm2.weight"], w[f"{prefix}.norm2.bias"], xn, eps, rows=S)
+    ops.gemm(xn, w[f"{prefix}.mlp.fc1.weight"], hid, M=S, bias=w[f"{prefix}.mlp.fc1.bias"], act=ops.ACT_GELU)
+    ops.gemm(hid, w[f"{prefix}.mlp.fc2.weight"], x, M=S, bias=w[f"{prefix}.mlp.fc2.bias"],
+             gamma=w[f"{prefix}.ls2.gamma"] if ls else None, resid=x)

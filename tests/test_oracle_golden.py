@@ -87,3 +87,21 @@ def test_umeyama_known_answers():
     yp = xp.copy(); yp[:, 0] *= -1
     _, Rp, _, _ = post_ref.umeyama(xp, yp)
     assert abs(np.linalg.det(Rp) - 1.0) < 1e-9
+
+
+@pytest.mark.parametrize("name", ["moge_small", "moge_chunk"])
+def test_moge_oracle_matches_reference_vectors(name):
+    """MoGe-2 restatement vs the real MoGeModel class (synthetic model_config + recipe weights)."""
+    from oracle import moge_ref
+    from oracle.gen_golden_moge import CASES as MCASES, moge_image
+    from pi3_slam_amd.moge import SYNTHETIC_CONFIG, recipe_state_dict_cpu
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    H, W, level = MCASES[name]
+    out = moge_ref.moge_infer(recipe_state_dict_cpu(SYNTHETIC_CONFIG), SYNTHETIC_CONFIG, moge_image(name, H, W), level)
+    mask = np.unpackbits(g["mask"])[: H * W].reshape(H, W).astype(bool)
+    assert np.array_equal(out["mask"].numpy(), mask)
+    np.testing.assert_allclose(out["points_affine"][..., 2].numpy(), g["points_affine_z"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(out["depth"].numpy()[mask], g["depth"][mask], rtol=1e-4, atol=1e-5)
+    assert np.all(np.isinf(out["depth"].numpy()[~mask]))
+    np.testing.assert_allclose(out["metric_scale"].numpy(), g["metric_scale"][0], rtol=1e-5)
+    np.testing.assert_allclose(out["intrinsics"].numpy(), g["intrinsics"], rtol=1e-4)

@@ -35,7 +35,7 @@ def cpu_baseline(engine_cfg, n_frames: int = 2):
     for name, shape in param_shapes(engine_cfg).items():
         sd[name] = recipe_fill_device(name, shape, "cuda:0").cpu()
     imgs = torch.rand(1, n_frames, 3, H, W)
-    threads = min(torch.get_num_threads(), len(os.sched_getaffinity(0)))
+    threads = min(torch.get_num_threads(), len(os.sched_getaffinity(0)), 16)  # the GPU box grants 16 cores per GPU
     torch.set_num_threads(threads)
     t0 = time.perf_counter()
     pi3_ref.pi3_forward(sd, imgs, engine_cfg)

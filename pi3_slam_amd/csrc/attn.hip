@@ -105,85 +105,86 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
   const int vin_l = (vcol_l & 7) * 2;              // byte inside the chunk (0 or 8)
   const int vswz = ((vrow_l >> 1) & 1) << 2;       // rows R0+q: bit 1 of the row; 32kt+16s2(+8) never touch bit 1
 
-  for (int t = 0; t < nt; ++t) {
-    const int buf = t & 1;
-    if (t + 1 < nt) { ATT_LOAD(t + 1) }
-
-    // ---- S^T = K . Q^T
-    f32x16 sc[2];
-    sc[0] = (f32x16)(0.f);
-    sc[1] = (f32x16)(0.f);
-    const char* kl = lds + buf * 8192 + krow_off;
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      const int off = ((2 * s + h) ^ kswz) << 4;
-      const bf16x8 a0 = *(const bf16x8*)(kl + off);
-      const bf16x8 a1 = *(const bf16x8*)(kl + 32 * 128 + off);
-      sc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, qf[s], sc[0], 0, 0, 0);
-      sc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, qf[s], sc[1], 0, 0, 0);
-    }
-    if (t == nt - 1 && (S & (ATT_KT - 1))) {
-      const int kb = t * ATT_KT + 4 * h;
-#pragma unroll
-      for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const int key = kb + 32 * kt + (i & 3) + 8 * (i >> 2);
-          if (key >= S) sc[kt][i] = -INFINITY;
-        }
-    }
-
-    // ---- online softmax (query on the lane; the other half-wave holds the other 32 keys of the same query)
-    float tmax = sc[0][0];
-#pragma unroll
-    for (int i = 1; i < 16; ++i) tmax = fmaxf(tmax, sc[0][i]);
-#pragma unroll
-    for (int i = 0; i < 16; ++i) tmax = fmaxf(tmax, sc[1][i]);
-    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-    if (!__all(tmax <= m + RESCALE_THR)) {
-      const float mn = fmaxf(m, tmax);
-      const float alpha = __builtin_amdgcn_exp2f(m - mn);
-      l *= alpha;
-      o[0] *= alpha;
-      o[1] *= alpha;
-      m = mn;
-    }
-    bf16x8 pf[2][2];
-    float psum = 0.f;
-#pragma unroll
-    for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const float pv = __builtin_amdgcn_exp2f(sc[kt][8 * s2 + j] - m);
-          psum += pv;
-          pf[kt][s2][j] = (bf16_t)pv;
-        }
-    l += psum;
-
-    // ---- O^T += V^T . P^T
-    const char* vl = lds + 16384 + buf * 8192;
-#pragma unroll
-    for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2) {
-        const int row0 = 32 * kt + 16 * s2 + vrow_l;
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt) {
-          const int ch = (4 * dt + vch_l) ^ vswz;
-          const char* a = vl + row0 * 128 + (ch << 4) + vin_l;
-          const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-              (__attribute__((address_space(3))) bf16x4*)LDS_PTR(a));
-          const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-              (__attribute__((address_space(3))) bf16x4*)LDS_PTR(a + 8 * 128));
-          o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cat4(lo, hi), pf[kt][s2], o[dt], 0, 0, 0);
-        }
-      }
-
-    if (t + 1 < nt) { ATT_WRITE(buf ^ 1) }
-    __syncthreads();
+  // One KV tile.  LAST = the final tile of the sweep (tail keys masked, nothing left to prefetch); every other tile
+  // runs the branch-free body so the O accumulators stay in place across iterations.
+#define ATT_TILE(T, LAST)                                                                                           \
+  {                                                                                                                 \
+    const int buf = (T) & 1;                                                                                        \
+    if (!(LAST)) { ATT_LOAD((T) + 1) }                                                                              \
+    f32x16 sc[2];                                                                                                   \
+    const char* kl = lds + buf * 8192 + krow_off;                                                                   \
+    {                                                                                                               \
+      const int off = (h ^ kswz) << 4;                                                                              \
+      const bf16x8 a0 = *(const bf16x8*)(kl + off);                                                                 \
+      const bf16x8 a1 = *(const bf16x8*)(kl + 32 * 128 + off);                                                      \
+      sc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, qf[0], (f32x16)(0.f), 0, 0, 0);                           \
+      sc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, qf[0], (f32x16)(0.f), 0, 0, 0);                           \
+    }                                                                                                               \
+    _Pragma("unroll") for (int s = 1; s < 4; ++s) {                                                                 \
+      const int off = ((2 * s + h) ^ kswz) << 4;                                                                    \
+      const bf16x8 a0 = *(const bf16x8*)(kl + off);                                                                 \
+      const bf16x8 a1 = *(const bf16x8*)(kl + 32 * 128 + off);                                                      \
+      sc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, qf[s], sc[0], 0, 0, 0);                                   \
+      sc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, qf[s], sc[1], 0, 0, 0);                                   \
+    }                                                                                                               \
+    if ((LAST) && (S & (ATT_KT - 1))) {                                                                             \
+      const int kb = (T) * ATT_KT + 4 * h;                                                                          \
+      _Pragma("unroll") for (int kt = 0; kt < 2; ++kt)                                                              \
+      _Pragma("unroll") for (int i = 0; i < 16; ++i) {                                                              \
+        const int key = kb + 32 * kt + (i & 3) + 8 * (i >> 2);                                                      \
+        if (key >= S) sc[kt][i] = -INFINITY;                                                                        \
+      }                                                                                                             \
+    }                                                                                                               \
+    /* online softmax: query on the lane; the other half-wave holds the other 32 keys of the same query */          \
+    float tmax = sc[0][0];                                                                                          \
+    _Pragma("unroll") for (int i = 1; i < 16; ++i) tmax = fmaxf(tmax, sc[0][i]);                                    \
+    _Pragma("unroll") for (int i = 0; i < 16; ++i) tmax = fmaxf(tmax, sc[1][i]);                                    \
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));                                                                   \
+    if (!__all(tmax <= m + RESCALE_THR)) {                                                                          \
+      const float mn = fmaxf(m, tmax);                                                                              \
+      const float alpha = __builtin_amdgcn_exp2f(m - mn);                                                           \
+      l *= alpha;                                                                                                   \
+      o[0] *= alpha;                                                                                                \
+      o[1] *= alpha;                                                                                                \
+      m = mn;                                                                                                       \
+    }                                                                                                               \
+    bf16x8 pf[2][2];                                                                                                \
+    float psum = 0.f;                                                                                               \
+    _Pragma("unroll") for (int kt = 0; kt < 2; ++kt)                                                                \
+    _Pragma("unroll") for (int s2 = 0; s2 < 2; ++s2) {                                                              \
+      u32x4 pw;                                                                                                     \
+      _Pragma("unroll") for (int jj = 0; jj < 4; ++jj) {                                                            \
+        const float p0 = __builtin_amdgcn_exp2f(sc[kt][8 * s2 + 2 * jj] - m);                                       \
+        const float p1 = __builtin_amdgcn_exp2f(sc[kt][8 * s2 + 2 * jj + 1] - m);                                   \
+        psum += p0 + p1;                                                                                            \
+        pw[jj] = pack_bf16x2(p0, p1);                                                                               \
+      }                                                                                                             \
+      pf[kt][s2] = __builtin_bit_cast(bf16x8, pw);                                                                  \
+    }                                                                                                               \
+    l += psum;                                                                                                      \
+    /* O^T += V^T . P^T */                                                                                          \
+    const char* vl = lds + 16384 + buf * 8192;                                                                      \
+    _Pragma("unroll") for (int kt = 0; kt < 2; ++kt)                                                                \
+    _Pragma("unroll") for (int s2 = 0; s2 < 2; ++s2) {                                                              \
+      const int row0 = 32 * kt + 16 * s2 + vrow_l;                                                                  \
+      _Pragma("unroll") for (int dt = 0; dt < 2; ++dt) {                                                            \
+        const int ch = (4 * dt + vch_l) ^ vswz;                                                                     \
+        const char* a = vl + row0 * 128 + (ch << 4) + vin_l;                                                        \
+        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(                                                 \
+            (__attribute__((address_space(3))) bf16x4*)LDS_PTR(a));                                                 \
+        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(                                                 \
+            (__attribute__((address_space(3))) bf16x4*)LDS_PTR(a + 8 * 128));                                       \
+        o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cat4(lo, hi), pf[kt][s2], o[dt], 0, 0, 0);                  \
+      }                                                                                                             \
+    }                                                                                                               \
+    if (!(LAST)) {                                                                                                  \
+      ATT_WRITE(buf ^ 1)                                                                                            \
+      __syncthreads();                                                                                              \
+    }                                                                                                               \
   }
+
+  for (int t = 0; t < nt - 1; ++t) ATT_TILE(t, false)
+  ATT_TILE(nt - 1, true)
 
   // ---- finalize: O[q][d] = O^T[d][q] / l
   const float lt = l + __shfl_xor(l, 32, 64);

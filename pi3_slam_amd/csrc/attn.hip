@@ -16,9 +16,12 @@
 //                             exactly that row order.  No cross-lane movement of P, and the query stays on the lane,
 //                             so max / sum / rescale are per-lane scalars (one half-wave exchange for the max).
 //   K/V tiles are register-staged (global_load_dwordx4 issued before the tile's math, ds_write_b128 after it) into a
-//   2-deep LDS ring with one barrier per tile.  The running max is only raised when a tile's max exceeds it by more
-//   than RESCALE_THR (exp2 domain), which removes the O rescale from almost every tile.
+//   2-deep LDS ring with one barrier per tile.  The running max m is only raised when a tile's max exceeds it by more
+//   than RESCALE_THR (exp2 domain), which removes the O rescale from almost every tile.  -m lives in a 16-register
+//   vector that is the C operand of each tile's first MFMA, so the scores come out of the matrix pipe already shifted
+//   (s - m) and the softmax needs no per-element subtraction: p = exp2(acc).
 #include "common.h"
+#include <stdlib.h>
 
 struct AttnParams {
   const bf16_t* q; const bf16_t* k; const bf16_t* v;
@@ -36,7 +39,8 @@ __device__ __forceinline__ bf16x8 cat4(bf16x4 a, bf16x4 b) {
   return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
-__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
+template <int MIN_WAVES>
+__global__ __launch_bounds__(256, MIN_WAVES) void attn_fwd_kernel(AttnParams p) {
   __shared__ __attribute__((aligned(16))) char lds[32768];  // K ring [2][64][128 B] then V ring [2][64][128 B]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
@@ -58,7 +62,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
   f32x16 o[2];
   o[0] = (f32x16)(0.f);
   o[1] = (f32x16)(0.f);
-  float m = -INFINITY, l = 0.f;
+  float l = 0.f;
+  f32x16 negm = (f32x16)(0.f);  // -m replicated: C operand of each tile's first S^T MFMA
 
   const int nt = (S + ATT_KT - 1) / ATT_KT;
   const bf16_t* kbase = p.k + (long)b * p.batch_stride + head * 64;
@@ -107,7 +112,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
 
   // One KV tile.  LAST = the final tile of the sweep (tail keys masked, nothing left to prefetch); every other tile
   // runs the branch-free body so the O accumulators stay in place across iterations.
-#define ATT_TILE(T, LAST)                                                                                           \
+#define ATT_TILE(T, FIRST, LAST)                                                                                          \
   {                                                                                                                 \
     const int buf = (T) & 1;                                                                                        \
     if (!(LAST)) { ATT_LOAD((T) + 1) }                                                                              \
@@ -117,8 +122,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
       const int off = (h ^ kswz) << 4;                                                                              \
       const bf16x8 a0 = *(const bf16x8*)(kl + off);                                                                 \
       const bf16x8 a1 = *(const bf16x8*)(kl + 32 * 128 + off);                                                      \
-      sc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, qf[0], (f32x16)(0.f), 0, 0, 0);                           \
-      sc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, qf[0], (f32x16)(0.f), 0, 0, 0);                           \
+      sc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, qf[0], negm, 0, 0, 0);                                    \
+      sc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, qf[0], negm, 0, 0, 0);                                    \
     }                                                                                                               \
     _Pragma("unroll") for (int s = 1; s < 4; ++s) {                                                                 \
       const int off = ((2 * s + h) ^ kswz) << 4;                                                                    \
@@ -135,18 +140,31 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
         if (key >= S) sc[kt][i] = -INFINITY;                                                                        \
       }                                                                                                             \
     }                                                                                                               \
-    /* online softmax: query on the lane; the other half-wave holds the other 32 keys of the same query */          \
+    /* online softmax: query on the lane; the other half-wave holds the other 32 keys of the same query.        */  \
+    /* sc already holds s - m (m = 0 before the first tile).                                                     */  \
     float tmax = sc[0][0];                                                                                          \
     _Pragma("unroll") for (int i = 1; i < 16; ++i) tmax = fmaxf(tmax, sc[0][i]);                                    \
     _Pragma("unroll") for (int i = 0; i < 16; ++i) tmax = fmaxf(tmax, sc[1][i]);                                    \
     tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));                                                                   \
-    if (!__all(tmax <= m + RESCALE_THR)) {                                                                          \
-      const float mn = fmaxf(m, tmax);                                                                              \
-      const float alpha = __builtin_amdgcn_exp2f(m - mn);                                                           \
+    if (FIRST) {                                                                                                    \
+      /* o = l = 0: adopt the tile max as m */                                                                      \
+      sc[0] -= tmax;                                                                                                \
+      sc[1] -= tmax;                                                                                                \
+      negm = (f32x16)(-tmax);                                                                                       \
+    } else if (!__all(tmax <= RESCALE_THR)) {                                                                       \
+      const float delta = fmaxf(tmax, 0.f);                                                                         \
+      float alpha = __builtin_amdgcn_exp2f(-delta);                                                                 \
+      /* in-place multiply through tied asm operands: a plain `o *= alpha` makes hipcc keep a second copy of the */ \
+      /* 32 accumulator registers alive (32 v_mov per tile) just to feed this rare branch out of place.  s_nop:  */ \
+      /* the compiler pads the v_exp -> VALU (trans) hazard only for its own instructions, not ahead of asm.     */ \
+      asm volatile("s_nop 1" : "+v"(alpha));                                                                        \
       l *= alpha;                                                                                                   \
-      o[0] *= alpha;                                                                                                \
-      o[1] *= alpha;                                                                                                \
-      m = mn;                                                                                                       \
+      _Pragma("unroll") for (int dt = 0; dt < 2; ++dt)                                                              \
+      _Pragma("unroll") for (int i = 0; i < 16; ++i)                                                                \
+        asm volatile("v_mul_f32 %0, %1, %0" : "+v"(o[dt][i]) : "v"(alpha));                                         \
+      sc[0] -= delta;                                                                                               \
+      sc[1] -= delta;                                                                                               \
+      negm -= delta;                                                                                                \
     }                                                                                                               \
     bf16x8 pf[2][2];                                                                                                \
     float psum = 0.f;                                                                                               \
@@ -154,8 +172,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
     _Pragma("unroll") for (int s2 = 0; s2 < 2; ++s2) {                                                              \
       u32x4 pw;                                                                                                     \
       _Pragma("unroll") for (int jj = 0; jj < 4; ++jj) {                                                            \
-        const float p0 = __builtin_amdgcn_exp2f(sc[kt][8 * s2 + 2 * jj] - m);                                       \
-        const float p1 = __builtin_amdgcn_exp2f(sc[kt][8 * s2 + 2 * jj + 1] - m);                                   \
+        const float p0 = __builtin_amdgcn_exp2f(sc[kt][8 * s2 + 2 * jj]);                                           \
+        const float p1 = __builtin_amdgcn_exp2f(sc[kt][8 * s2 + 2 * jj + 1]);                                       \
         psum += p0 + p1;                                                                                            \
         pw[jj] = pack_bf16x2(p0, p1);                                                                               \
       }                                                                                                             \
@@ -183,8 +201,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
     }                                                                                                               \
   }
 
-  for (int t = 0; t < nt - 1; ++t) ATT_TILE(t, false)
-  ATT_TILE(nt - 1, true)
+  if (nt == 1) {
+    ATT_TILE(0, true, true)
+  } else {
+    ATT_TILE(0, true, false)
+    for (int t = 1; t < nt - 1; ++t) ATT_TILE(t, false, false)
+    ATT_TILE(nt - 1, false, true)
+  }
 
   // ---- finalize: O[q][d] = O^T[d][q] / l
   const float lt = l + __shfl_xor(l, 32, 64);
@@ -225,6 +248,18 @@ extern "C" int pi3_attention(const void* q, const void* k, const void* v, long t
     pi3_set_error("pi3_attention: grid too large");
     return PI3_ERR_ARG;
   }
-  hipLaunchKernelGGL(attn_fwd_kernel, dim3((unsigned)nwg), dim3(256), 0, (hipStream_t)stream, p);
+  // MIN_WAVES = waves per SIMD the register allocator must leave room for (3 -> <=168 VGPRs, 4 -> <=128).
+  // PI3_ATTN_WAVES is a tuning knob for A/B runs; the default is the measured best.
+  static int waves = -1;
+  if (waves < 0) {
+    const char* e = getenv("PI3_ATTN_WAVES");
+    waves = e ? atoi(e) : 3;
+  }
+  if (waves >= 4)
+    hipLaunchKernelGGL(attn_fwd_kernel<4>, dim3((unsigned)nwg), dim3(256), 0, (hipStream_t)stream, p);
+  else if (waves == 2)
+    hipLaunchKernelGGL(attn_fwd_kernel<2>, dim3((unsigned)nwg), dim3(256), 0, (hipStream_t)stream, p);
+  else
+    hipLaunchKernelGGL(attn_fwd_kernel<3>, dim3((unsigned)nwg), dim3(256), 0, (hipStream_t)stream, p);
   return pi3_check_launch("attn_fwd");
 }

@@ -59,11 +59,16 @@ def main() -> None:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus}")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device(f"cuda:{local_rank}")
+    ndev = torch.cuda.device_count()
+    backend = os.environ.get("PI3_DIST_BACKEND", "nccl")   # "gloo" only to rehearse the N > 1 logic on a 1-GPU box
+    dev = torch.device(f"cuda:{local_rank % max(1, ndev) if backend == 'gloo' else local_rank}")
+    torch.cuda.set_device(dev)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)   # RCCL over xGMI
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)   # RCCL over xGMI
+        else:
+            dist.init_process_group(backend)
 
     from pi3_slam_amd import ops
     from pi3_slam_amd.alignment import create_view_graph_matches, estimate_sim3
@@ -110,7 +115,8 @@ def main() -> None:
                 ops.sim3_apply(out[13:29].contiguous(), chunk["points"].to(dev, torch.float32).contiguous(),
                                chunk["camera_poses"].to(dev).contiguous())
         else:
-            blocks = [unpack_boundary(b.cpu(), OV, KP) for b in allgather_boundaries(pack_boundary(chunk, OV, KP), dev)]
+            blocks = [unpack_boundary(b.cpu(), OV, KP)
+                      for b in allgather_boundaries(pack_boundary(chunk, OV, KP), dev if backend == "nccl" else "cpu")]
             rel = [torch.eye(4, dtype=torch.float64, device=dev).reshape(16)]
             for r in range(1, world):
                 rel.append(relative_sim3_from_boundaries(blocks[r - 1], blocks[r], OV, dev)[13:29])
@@ -142,7 +148,7 @@ def main() -> None:
     dt = time.perf_counter() - t0
     if world > 1:
         import torch.distributed as dist
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        tt = torch.tensor([dt], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 

@@ -80,12 +80,26 @@ __global__ __launch_bounds__(256, MIN_WAVES) void attn_fwd_kernel(AttnParams p) 
     vw[i] = 16384 + srow[i] * 128 + ((sch[i] ^ (((srow[i] >> 1) & 1) << 2)) << 4);
   }
   u32x4 kr[2], vr[2];
-#define ATT_LOAD(T)                                                      \
-  _Pragma("unroll") for (int i = 0; i < 2; ++i) {                         \
-    int grow = (T) * ATT_KT + srow[i];                                   \
-    grow = grow < S ? grow : S - 1;                                      \
-    kr[i] = *(const u32x4*)(kbase + (long)grow * p.tok_stride + sch[i] * 8); \
-    vr[i] = *(const u32x4*)(vbase + (long)grow * p.tok_stride + sch[i] * 8); \
+  // per-thread byte offset of its two chunks inside a tile: constant over the sweep; the tile base is wave-uniform, so
+  // the loads use the scalar-base + 32-bit-offset form and cost no per-tile address arithmetic
+  unsigned goff[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) goff[i] = (unsigned)(srow[i] * p.tok_stride + sch[i] * 8) * 2u;
+#define ATT_LOAD(T, CLAMP)                                                          \
+  if (CLAMP) {                                                                      \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                 \
+      int grow = (T) * ATT_KT + srow[i];                                            \
+      grow = grow < S ? grow : S - 1;                                               \
+      kr[i] = *(const u32x4*)(kbase + (long)grow * p.tok_stride + sch[i] * 8);      \
+      vr[i] = *(const u32x4*)(vbase + (long)grow * p.tok_stride + sch[i] * 8);      \
+    }                                                                               \
+  } else {                                                                          \
+    const char* kt_ = (const char*)(kbase + (long)(T) * ATT_KT * p.tok_stride);     \
+    const char* vt_ = (const char*)(vbase + (long)(T) * ATT_KT * p.tok_stride);     \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                 \
+      kr[i] = *(const u32x4*)(kt_ + goff[i]);                                       \
+      vr[i] = *(const u32x4*)(vt_ + goff[i]);                                       \
+    }                                                                               \
   }
 #define ATT_WRITE(BUF)                                   \
   _Pragma("unroll") for (int i = 0; i < 2; ++i) {         \
@@ -93,7 +107,7 @@ __global__ __launch_bounds__(256, MIN_WAVES) void attn_fwd_kernel(AttnParams p) 
     *(u32x4*)(lds + (BUF) * 8192 + vw[i]) = vr[i];       \
   }
 
-  ATT_LOAD(0)
+  ATT_LOAD(0, true)
   ATT_WRITE(0)
   __syncthreads();
 
@@ -112,10 +126,10 @@ __global__ __launch_bounds__(256, MIN_WAVES) void attn_fwd_kernel(AttnParams p) 
 
   // One KV tile.  LAST = the final tile of the sweep (tail keys masked, nothing left to prefetch); every other tile
   // runs the branch-free body so the O accumulators stay in place across iterations.
-#define ATT_TILE(T, FIRST, LAST)                                                                                          \
+#define ATT_TILE(T, BUF, FIRST, LAST, CLAMPNEXT)                                                                                          \
   {                                                                                                                 \
-    const int buf = (T) & 1;                                                                                        \
-    if (!(LAST)) { ATT_LOAD((T) + 1) }                                                                              \
+    constexpr int buf = (BUF);                                                                                      \
+    if (!(LAST)) { ATT_LOAD((T) + 1, CLAMPNEXT) }                                                                   \
     f32x16 sc[2];                                                                                                   \
     const char* kl = lds + buf * 8192 + krow_off;                                                                   \
     {                                                                                                               \
@@ -201,12 +215,30 @@ __global__ __launch_bounds__(256, MIN_WAVES) void attn_fwd_kernel(AttnParams p) 
     }                                                                                                               \
   }
 
+  // tile t lives in ring slot t & 1; the steady-state loop is unrolled by two so the slot is a compile-time constant
+  // (LDS addresses become immediates).  Only the load of the final tile needs row clamping (tail keys).
+  const bool tail = (S & (ATT_KT - 1)) != 0;
   if (nt == 1) {
-    ATT_TILE(0, true, true)
+    ATT_TILE(0, 0, true, true, false)
   } else {
-    ATT_TILE(0, true, false)
-    for (int t = 1; t < nt - 1; ++t) ATT_TILE(t, false, false)
-    ATT_TILE(nt - 1, false, true)
+    ATT_TILE(0, 0, true, false, (tail && nt == 2))
+    // steady tiles 1 .. nt-2; tile u prefetches u+1, which needs row clamping only when u+1 is the final tile
+    int t = 1;
+    for (; t + 1 <= nt - 3; t += 2) {
+      ATT_TILE(t, 1, false, false, false)
+      ATT_TILE(t + 1, 0, false, false, false)
+    }
+    const int rem = nt - 1 - t;  // steady tiles left (t is odd): 0, 1 or 2
+    if (rem == 2) {
+      ATT_TILE(t, 1, false, false, false)
+      ATT_TILE(t + 1, 0, false, false, tail)
+      ATT_TILE(nt - 1, 1, false, true, false)
+    } else if (rem == 1) {
+      ATT_TILE(t, 1, false, false, tail)
+      ATT_TILE(nt - 1, 0, false, true, false)
+    } else {
+      ATT_TILE(nt - 1, 1, false, true, false)
+    }
   }
 
   // ---- finalize: O[q][d] = O^T[d][q] / l

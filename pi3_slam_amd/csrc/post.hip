@@ -135,7 +135,10 @@ extern "C" int pi3_masked_ratio_median(const float* num, const float* den, long 
 // (offline_chunk_creator.py:189-191).
 __global__ __launch_bounds__(256) void apply_scale_kernel(const float* __restrict__ scale, float* lp, float* pts,
                                                           long n3, float* poses, int F) {
-  const float s = scale[0];
+  float s = scale[0];
+  // an empty / NaN / non-positive / infinite median (no valid pixel in frame 0) leaves the chunk unscaled: the
+  // reference would raise on the empty median (offline_chunk_creator.py:126) and lose the chunk; we degrade instead
+  if (!(s > 0.f) || isinf(s)) s = 1.0f;
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   const long stride = (long)gridDim.x * 256;
   for (long j = i; j < n3; j += stride) {

@@ -47,7 +47,7 @@ def load_image(path: str, target_size: Tuple[int, int]) -> torch.Tensor:
     if not os.path.exists(path):
         raise ValueError(f"Image file not found: {path}")
     img = Image.open(path).convert("RGB").resize((target_size[1], target_size[0]), Image.BILINEAR)
-    arr = np.asarray(img, dtype=np.uint8)
+    arr = np.array(img, dtype=np.uint8)  # writable copy
     return torch.from_numpy(arr).permute(2, 0, 1).to(torch.float32).div(255.0)
 
 

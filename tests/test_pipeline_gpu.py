@@ -1,0 +1,67 @@
+"""GPU end-to-end plumbing (BASELINE.json configs[0] shape): 32 synthetic 256x192 PNG frames, chunk_length=32,
+overlap=8 -> chunk files with the reference's layout -> OfflineReconstructor -> TUM trajectory.  Uses a narrow model
+(recipe weights) so it runs in seconds; the frames are resized to 308x406 by the reference's target-size rule."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _write_frames(d, n=32, w=256, h=192):
+    from PIL import Image
+    rng = np.random.default_rng(0)
+    base = rng.integers(0, 256, (h + 40, w + 40, 3)).astype(np.float32)
+    k = 9
+    sm = np.cumsum(np.cumsum(base, 0), 1)           # box blur via integral image so the resize is non-trivial
+    sm = (sm[k:, k:] - sm[:-k, k:] - sm[k:, :-k] + sm[:-k, :-k]) / (k * k)
+    paths = []
+    for i in range(n):
+        crop = sm[i % 20: i % 20 + h, (2 * i) % 20: (2 * i) % 20 + w]
+        p = os.path.join(d, f"frame_{i:05d}.png")
+        Image.fromarray(np.clip(crop, 0, 255).astype(np.uint8)).save(p)
+        paths.append(p)
+    return paths
+
+
+def test_process_and_save_then_reconstruct(tmp_path, built_lib):
+    assert torch.cuda.is_available()
+    from pi3_slam_amd.chunk_creator import OfflineChunkCreator, OfflineCreatorConfig
+    from pi3_slam_amd.engine import Pi3Engine
+    from pi3_slam_amd.moge import MoGeEngine
+    from pi3_slam_amd.reconstructor import OfflineReconstructor
+    from pi3_slam_amd.weights import Pi3Config
+    frames = tmp_path / "frames"
+    frames.mkdir()
+    paths = _write_frames(str(frames))
+    out = tmp_path / "out"
+    cfg = OfflineCreatorConfig(model_path="recipe", output_dir=str(out), chunk_length=32, overlap=8,
+                               do_metric_depth=True, keypoint_type="grid", max_num_keypoints=200,
+                               num_loader_workers=0, pin_memory=False)
+    small = Pi3Config(dim=128, enc_depth=1, dec_depth=2, head_depth=1, cam_dim=128, pos_grid=5)
+    creator = OfflineChunkCreator(cfg, model=Pi3Engine(small, "cuda:0"),
+                                  moge_model=MoGeEngine.from_pretrained("recipe", "cuda:0"))
+    saved = creator.process_and_save(paths)
+    assert creator.target_size == (308, 406)
+    assert [os.path.basename(s) for s in saved] == ["chunk_000000.pt", "chunk_000001.pt"]   # (0,32) + tail (24,32)
+    meta = json.load(open(out / "chunk_metadata.json"))
+    assert meta == {"chunk_length": 32, "overlap": 8, "target_size": [308, 406]}
+    man = json.load(open(out / "chunks_manifest.json"))
+    assert [(m["start_idx"], m["end_idx"], m["num_frames"]) for m in man] == [(0, 32, 32), (24, 32, 8)]
+    c0 = torch.load(saved[0], map_location="cpu", weights_only=False)
+    assert c0["points"].shape == (32, 200, 3) and c0["points"].dtype == torch.float16
+    assert c0["keypoints"].shape == (32, 200, 2) and c0["masks"].dtype == torch.bool
+    assert c0["intrinsics"].shape == (32, 3, 3) and c0["chunk_index"] == 0 and c0["end_idx"] == 32
+    assert torch.isfinite(c0["points"].float()).all() and torch.isfinite(c0["camera_poses"]).all()
+    with pytest.raises(ValueError):
+        creator.process_and_save([])                                             # offline_chunk_creator.py:263-264
+    rec = OfflineReconstructor(str(out), str(tmp_path / "recon"))
+    assert (rec.chunk_length, rec.overlap) == (32, 8)
+    rec.run()
+    lines = open(tmp_path / "recon" / "trajectory_tum.txt").read().strip().split("\n")
+    assert len(lines) == 1 + 32                                                  # 40 poses, 8 duplicates dropped
+    vals = np.array([[float(v) for v in l.split()] for l in lines[1:]])
+    assert np.isfinite(vals).all() and np.allclose(np.linalg.norm(vals[:, 4:8], axis=1), 1.0, atol=1e-5)

@@ -244,3 +244,12 @@ def test_offline_reconstructor_roundtrip(dev, tmp_path):
     assert np.abs(traj - gt_pos).max() < 2e-2                    # chunk 0 is the world frame; fp16 point storage
     assert [l.split()[0] for l in lines[1:4]] == ["0", "1", "2"]
     assert os.path.exists(tmp_path / "out" / "final_points.ply") and os.path.exists(tmp_path / "out" / "final_camera_poses.ply")
+
+
+def test_apply_scale_ignores_invalid_median(dev):
+    from pi3_slam_amd import ops
+    lp, pts, poses = torch.rand(1, 3, 4, 3, device=dev), torch.rand(1, 3, 4, 3, device=dev), torch.rand(1, 4, 4, device=dev)
+    for bad in (float("nan"), 0.0, -1.0, float("inf")):
+        a, b, c = lp.clone(), pts.clone(), poses.clone()
+        ops.apply_scale(torch.tensor([bad], device=dev), a, b, c)
+        assert torch.equal(a, lp) and torch.equal(b, pts) and torch.equal(c, poses)

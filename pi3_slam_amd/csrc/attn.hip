@@ -39,7 +39,9 @@ __device__ __forceinline__ bf16x8 cat4(bf16x4 a, bf16x4 b) {
   return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
-template <int MIN_WAVES>
+// ABL != 0 builds are timing-only ablations (wrong results) used to find the limiting resource (tools/dev_attn.py):
+// 1 no exp, 2 no max / rescale, 3 no P.V MFMAs, 4 no Q.K MFMAs, 5 no global loads / LDS writes, 6 no barrier.
+template <int MIN_WAVES, int ABL = 0>
 __global__ __launch_bounds__(256, MIN_WAVES) void attn_fwd_kernel(AttnParams p) {
   __shared__ __attribute__((aligned(16))) char lds[32768];  // K ring [2][64][128 B] then V ring [2][64][128 B]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -129,7 +131,7 @@ __global__ __launch_bounds__(256, MIN_WAVES) void attn_fwd_kernel(AttnParams p) 
 #define ATT_TILE(T, BUF, FIRST, LAST, CLAMPNEXT)                                                                                          \
   {                                                                                                                 \
     constexpr int buf = (BUF);                                                                                      \
-    if (!(LAST)) { ATT_LOAD((T) + 1, CLAMPNEXT) }                                                                   \
+    if (!(LAST) && ABL != 5) { ATT_LOAD((T) + 1, CLAMPNEXT) }                                                       \
     f32x16 sc[2];                                                                                                   \
     const char* kl = lds + buf * 8192 + krow_off;                                                                   \
     {                                                                                                               \
@@ -139,6 +141,7 @@ __global__ __launch_bounds__(256, MIN_WAVES) void attn_fwd_kernel(AttnParams p) 
       sc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, qf[0], negm, 0, 0, 0);                                    \
       sc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, qf[0], negm, 0, 0, 0);                                    \
     }                                                                                                               \
+    if (ABL != 4)                                                                                                   \
     _Pragma("unroll") for (int s = 1; s < 4; ++s) {                                                                 \
       const int off = ((2 * s + h) ^ kswz) << 4;                                                                    \
       const bf16x8 a0 = *(const bf16x8*)(kl + off);                                                                 \
@@ -157,15 +160,17 @@ __global__ __launch_bounds__(256, MIN_WAVES) void attn_fwd_kernel(AttnParams p) 
     /* online softmax: query on the lane; the other half-wave holds the other 32 keys of the same query.        */  \
     /* sc already holds s - m (m = 0 before the first tile).                                                     */  \
     float tmax = sc[0][0];                                                                                          \
-    _Pragma("unroll") for (int i = 1; i < 16; ++i) tmax = fmaxf(tmax, sc[0][i]);                                    \
-    _Pragma("unroll") for (int i = 0; i < 16; ++i) tmax = fmaxf(tmax, sc[1][i]);                                    \
-    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));                                                                   \
+    if (ABL != 2) {                                                                                                 \
+      _Pragma("unroll") for (int i = 1; i < 16; ++i) tmax = fmaxf(tmax, sc[0][i]);                                  \
+      _Pragma("unroll") for (int i = 0; i < 16; ++i) tmax = fmaxf(tmax, sc[1][i]);                                  \
+      tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));                                                                 \
+    }                                                                                                               \
     if (FIRST) {                                                                                                    \
       /* o = l = 0: adopt the tile max as m */                                                                      \
       sc[0] -= tmax;                                                                                                \
       sc[1] -= tmax;                                                                                                \
       negm = (f32x16)(-tmax);                                                                                       \
-    } else if (!__all(tmax <= RESCALE_THR)) {                                                                       \
+    } else if (ABL != 2 && !__all(tmax <= RESCALE_THR)) {                                                           \
       const float delta = fmaxf(tmax, 0.f);                                                                         \
       float alpha = __builtin_amdgcn_exp2f(-delta);                                                                 \
       /* in-place multiply through tied asm operands: a plain `o *= alpha` makes hipcc keep a second copy of the */ \
@@ -186,8 +191,8 @@ __global__ __launch_bounds__(256, MIN_WAVES) void attn_fwd_kernel(AttnParams p) 
     _Pragma("unroll") for (int s2 = 0; s2 < 2; ++s2) {                                                              \
       u32x4 pw;                                                                                                     \
       _Pragma("unroll") for (int jj = 0; jj < 4; ++jj) {                                                            \
-        const float p0 = __builtin_amdgcn_exp2f(sc[kt][8 * s2 + 2 * jj]);                                           \
-        const float p1 = __builtin_amdgcn_exp2f(sc[kt][8 * s2 + 2 * jj + 1]);                                       \
+        const float p0 = ABL == 1 ? sc[kt][8 * s2 + 2 * jj] : __builtin_amdgcn_exp2f(sc[kt][8 * s2 + 2 * jj]);      \
+        const float p1 = ABL == 1 ? sc[kt][8 * s2 + 2 * jj + 1] : __builtin_amdgcn_exp2f(sc[kt][8 * s2 + 2 * jj + 1]); \
         psum += p0 + p1;                                                                                            \
         pw[jj] = pack_bf16x2(p0, p1);                                                                               \
       }                                                                                                             \
@@ -196,6 +201,9 @@ __global__ __launch_bounds__(256, MIN_WAVES) void attn_fwd_kernel(AttnParams p) 
     l += psum;                                                                                                      \
     /* O^T += V^T . P^T */                                                                                          \
     const char* vl = lds + 16384 + buf * 8192;                                                                      \
+    if (ABL == 3) { _Pragma("unroll") for (int kt = 0; kt < 2; ++kt) _Pragma("unroll") for (int s2 = 0; s2 < 2; ++s2) \
+                    asm volatile("" :: "v"(pf[kt][s2])); }                                                           \
+    else                                                                                                            \
     _Pragma("unroll") for (int kt = 0; kt < 2; ++kt)                                                                \
     _Pragma("unroll") for (int s2 = 0; s2 < 2; ++s2) {                                                              \
       const int row0 = 32 * kt + 16 * s2 + vrow_l;                                                                  \
@@ -210,8 +218,8 @@ __global__ __launch_bounds__(256, MIN_WAVES) void attn_fwd_kernel(AttnParams p) 
       }                                                                                                             \
     }                                                                                                               \
     if (!(LAST)) {                                                                                                  \
-      ATT_WRITE(buf ^ 1)                                                                                            \
-      __syncthreads();                                                                                              \
+      if (ABL != 5) { ATT_WRITE(buf ^ 1) }                                                                          \
+      if (ABL != 6) __syncthreads();                                                                                \
     }                                                                                                               \
   }
 
@@ -258,6 +266,9 @@ __global__ __launch_bounds__(256, MIN_WAVES) void attn_fwd_kernel(AttnParams p) 
   }
 }
 
+int pi3_attention64_launch(const void* q, const void* k, const void* v, long tok_stride, long batch_stride, void* o,
+                           long o_tok_stride, long o_batch_stride, int B, int S, int H, hipStream_t stream);
+
 extern "C" int pi3_attention(const void* q, const void* k, const void* v, long tok_stride, long batch_stride,
                              void* o, long o_tok_stride, long o_batch_stride, int B, int S, int H, int head_dim,
                              void* stream) {
@@ -270,6 +281,15 @@ extern "C" int pi3_attention(const void* q, const void* k, const void* v, long t
     pi3_set_error("pi3_attention: q/k/v must be 16-byte aligned with strides that are multiples of 8 elements");
     return PI3_ERR_ARG;
   }
+  // PI3_ATTN_IMPL: 0 = automatic (64-row kernel for long sequences), 1 = 32-row kernel, 2 = 64-row kernel (A/B knob)
+  static int impl = -1;
+  if (impl < 0) {
+    const char* e = getenv("PI3_ATTN_IMPL");
+    impl = e ? atoi(e) : 0;
+  }
+  if (impl == 2 || (impl == 0 && S >= 4096))
+    return pi3_attention64_launch(q, k, v, tok_stride, batch_stride, o, o_tok_stride, o_batch_stride, B, S, H,
+                                  (hipStream_t)stream);
   AttnParams p;
   p.q = (const bf16_t*)q; p.k = (const bf16_t*)k; p.v = (const bf16_t*)v;
   p.tok_stride = tok_stride; p.batch_stride = batch_stride;
@@ -287,6 +307,14 @@ extern "C" int pi3_attention(const void* q, const void* k, const void* v, long t
     const char* e = getenv("PI3_ATTN_WAVES");
     waves = e ? atoi(e) : 3;
   }
+  static int abl = -1;
+  if (abl < 0) {
+    const char* e = getenv("PI3_ATTN_ABL");
+    abl = e ? atoi(e) : 0;
+  }
+#define ABL_CASE(K) if (abl == K) { hipLaunchKernelGGL((attn_fwd_kernel<3, K>), dim3((unsigned)nwg), dim3(256), 0, (hipStream_t)stream, p); return pi3_check_launch("attn_fwd_abl"); }
+  ABL_CASE(1) ABL_CASE(2) ABL_CASE(3) ABL_CASE(4) ABL_CASE(5) ABL_CASE(6)
+#undef ABL_CASE
   if (waves >= 4)
     hipLaunchKernelGGL(attn_fwd_kernel<4>, dim3((unsigned)nwg), dim3(256), 0, (hipStream_t)stream, p);
   else if (waves == 2)

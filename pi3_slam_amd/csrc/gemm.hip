@@ -12,23 +12,8 @@
 // columns of one output row: 8/16-byte stores and float4 bias loads in the epilogue.
 // The f32 variant uses v_mfma_f32_16x16x4_f32 (exact fp32, runs at the vector rate) for the heads the reference
 // computes with autocast disabled (pi3/models/pi3.py:192-209).
-#include "common.h"
-
-struct GemmParams {
-  const void* A; long lda;   // [M][K], element stride
-  const void* W; long ldw;   // [N][K]
-  int M, N, K;
-  const float* bias;         // [N] or null
-  const float* gamma;        // [N] or null  (LayerScale)
-  const float* resid; long ldr;  // fp32 [*][ldr] residual source (indexed by the remapped row) or null
-  void* out; long ldo;       // bf16 or f32
-  int rpg, gstride, goff;    // row remap: orow = (m / rpg) * gstride + goff + (m % rpg); rpg == 0 -> orow = m
-  const float* addtab; long ldadd;  // optional f32 table [rpg][ldadd], row (m % rpg), added after everything else
-  float qscale; int qcols;   // columns n < qcols are multiplied by qscale (softmax scale folded into q)
-  // implicit-GEMM 3x3 convolution, replicate padding (moge/model/modules.py:47-60): A is an NHWC image
-  // [B][cH][cW][cC] (cC % 64 == 0), row m = pixel, K = 9 * cC with k = (ky*3 + kx) * cC + ci; cW == 0 -> plain GEMM
-  int cH, cW, cC;
-};
+#include "gemm_common.h"
+#include <stdlib.h>
 
 #define BM 128
 #define BN 128
@@ -167,56 +152,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmParams p) {
   }
 
   // ---- epilogue: lane holds rows n = nb + 4*(lane>>4) + r (r = 0..3) of column m = mb + (lane & 15)
-  const int nq = (lane >> 4) * 4;
-#pragma unroll
-  for (int mi = 0; mi < 4; ++mi) {
-    const int m = bm * BM + wm * 64 + mi * 16 + frow;
-    if (m >= p.M) continue;
-    long orow = m;
-    int trow = 0;
-    if (p.rpg > 0) {
-      const int gq = m / p.rpg;
-      trow = m - gq * p.rpg;
-      orow = (long)gq * p.gstride + p.goff + trow;
-    }
-#pragma unroll
-    for (int ni = 0; ni < 4; ++ni) {
-      const int n0 = bn * BN + wn * 64 + ni * 16 + nq;
-      f32x4 v = acc[ni][mi];
-      if (p.bias) {
-        const f32x4 b = *(const f32x4*)(p.bias + n0);
-        v += b;
-      }
-      if (n0 < p.qcols) v *= p.qscale;
-      if constexpr (ACT == 1) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
-      } else if constexpr (ACT == 2) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
-      }
-      if (p.gamma) {
-        const f32x4 gmm = *(const f32x4*)(p.gamma + n0);
-        v *= gmm;
-      }
-      if (p.resid) {
-        const f32x4 rr = *(const f32x4*)(p.resid + orow * p.ldr + n0);
-        v += rr;
-      }
-      if (p.addtab) {
-        const f32x4 tt = *(const f32x4*)(p.addtab + (long)trow * p.ldadd + n0);
-        v += tt;
-      }
-      if constexpr (OUT_BF16) {
-        u32x2 o;
-        o[0] = pack_bf16x2(v[0], v[1]);
-        o[1] = pack_bf16x2(v[2], v[3]);
-        *(u32x2*)((bf16_t*)p.out + orow * p.ldo + n0) = o;
-      } else {
-        *(f32x4*)((float*)p.out + orow * p.ldo + n0) = v;
-      }
-    }
-  }
+  gemm_epilogue<OUT_BF16, ACT, 4, 4>(p, acc, bm * BM + wm * 64, bn * BN + wn * 64, lane);
 }
 
 template <bool IS_BF16, bool OUT_BF16, int ACT, bool CONV = false>
@@ -231,6 +167,8 @@ static int launch_gemm(const GemmParams& p, hipStream_t stream) {
   hipLaunchKernelGGL(kern, dim3(nbm * nbn), dim3(256), 4 * TILE_BYTES, stream, p);
   return pi3_check_launch("gemm_tn");
 }
+
+int pi3_gemm256_try(const GemmParams& p, int out_dtype, int act, hipStream_t stream);
 
 // in_dtype: 0 = bf16 operands, 1 = f32 operands.  out_dtype: 0 = bf16, 1 = f32.  act: 0 none, 1 GELU(erf), 2 ReLU.
 extern "C" int pi3_gemm(const void* A, long lda, const void* W, long ldw, int M, int N, int K, int in_dtype,
@@ -254,6 +192,17 @@ extern "C" int pi3_gemm(const void* A, long lda, const void* W, long ldw, int M,
   p.qscale = qscale; p.qcols = qcols;
   p.cH = 0; p.cW = 0; p.cC = 0;
   hipStream_t s = (hipStream_t)stream;
+  if (in_dtype == 0) {  // large bf16 GEMMs: 256x256 pipelined kernel (PI3_GEMM_IMPL=1 forces the 128x128 kernel)
+    static int impl = -1;
+    if (impl < 0) {
+      const char* e = getenv("PI3_GEMM_IMPL");
+      impl = e ? atoi(e) : 0;
+    }
+    if (impl != 1) {
+      const int rc = pi3_gemm256_try(p, out_dtype, act, s);
+      if (rc <= 0) return rc;
+    }
+  }
 #define GEMM_CASE(INB, OUTB, ACTV) \
   if ((in_dtype == 0) == INB && (out_dtype == 0) == OUTB && act == ACTV) return launch_gemm<INB, OUTB, ACTV>(p, s);
   GEMM_CASE(true, true, 0)

@@ -1,0 +1,293 @@
+// 256x256-tile bf16 GEMM with a phase-pipelined K loop (the transformer GEMMs of the north-star chunk: M = 64 300,
+// N in {1024, 3072, 4096}, K in {1024, 2048, 4096}).  Same math / epilogue as gemm.hip, different staging structure:
+// one 512-thread workgroup per CU (8 waves, 2 per SIMD), LDS-DMA prefetch kept in flight ACROSS barriers with counted
+// s_waitcnt vmcnt(N), raw s_barrier, one MFMA cluster per phase (cdna guide "256^2 8-phase template", re-derived here
+// for the swapped-operand orientation).
+//
+// Geometry: BK = 64 (one 128-byte row per operand row).  Waves 2 (m) x 4 (n): wave (wm, wn) owns the 128 (m) x 64 (n)
+// output = 8 x 4 MFMA 16x16x32 tiles = 128 accumulator registers.  LDS = 2 K-tile buffers x {act half 0, act half 1,
+// W half 0, W half 1} x 16 KiB = 128 KiB; a wave reads exactly one act half (wm) and one W half (wn >> 1) per K tile.
+//
+// Per K tile u (buffer u & 1) four phases, each: fragment ds_reads -> one half-tile LDS-DMA prefetch (2 x
+// global_load_lds_dwordx4 per thread) -> s_waitcnt lgkmcnt(0) -> 16 MFMAs (one 64 x 32 quadrant, K = 64) -> s_barrier:
+//   phase a: read W(nh0)[4] + act(mh0)[8]   MFMA (mh0, nh0)   prefetch act half 0 of tile u+1
+//   phase b: read W(nh1)[4]                 MFMA (mh0, nh1)   prefetch act half 1 of tile u+1
+//   phase c: read act(mh1)[8]               MFMA (mh1, nh1)   prefetch W half 0 of tile u+2   (W of this buffer is dead)
+//   phase d: (all fragments in registers)   MFMA (mh1, nh0)   prefetch W half 1 of tile u+2, then s_waitcnt vmcnt(4)
+// Hazards: a buffer region is re-staged only after the barrier that follows its last fragment read (W halves after
+// phase b, act halves after phase c); staged data is read in the phase AFTER the counted wait + barrier that retires
+// it (phase d's vmcnt(4) leaves only the two newest half-tiles, W(u+2), in flight: tile u+1 is complete).
+#include "gemm_common.h"
+#include <stdlib.h>
+
+#define G2_BM 256
+#define G2_BN 256
+#define G2_HALF 16384          // 128 rows x 128 B
+#define G2_BUF (4 * G2_HALF)   // act h0 | act h1 | W h0 | W h1
+#define G2_LDS (2 * G2_BUF)
+#define G2_EPI_WAVE 18432        // per-wave epilogue staging: 128 rows x 144 B (bf16) or 64 rows x 272 B (f32) <= 18 KiB
+#define G2_LDS_TOTAL (8 * G2_EPI_WAVE > G2_LDS ? 8 * G2_EPI_WAVE : G2_LDS)
+
+// stage one half-tile (128 rows x 128 B) of a row-major bf16 matrix: 16 segments of 1 KiB, 2 per wave
+__device__ __forceinline__ void g2_stage_half(const char* gbase, long ld_bytes, int row0, int rows, long k_bytes,
+                                              char* lds_half, int wave, int lane) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int seg = wave * 2 + i;
+    const int row = seg * 8 + (lane >> 3);
+    const int pos = lane & 7;
+    const int c = pos ^ ((row >> 1) & 7);
+    int grow = row0 + row;
+    grow = grow < rows ? grow : rows - 1;
+    const char* src = gbase + (long)grow * ld_bytes + k_bytes + c * 16;
+    __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(lds_half + seg * 1024), 16, 0, 0);
+  }
+}
+
+// Epilogue through LDS (all pipeline buffers are dead after the last barrier): each wave transposes its 128 (m) x 64 (n)
+// accumulator block into row-major [m][n] rows in its private LDS region, then streams whole rows out with 16-byte
+// lanes: 128-byte (bf16) / 256-byte (f32) contiguous segments per output row instead of 8/16-byte pieces per lane.
+// The register-direct epilogue of gemm.hip costs this kernel +35..70 % at K = 1024 (one workgroup per CU: the store
+// tail is not hidden behind another block's math).  bias / qscale / activation / LayerScale are applied in registers
+// before the transpose; residual and table adds in the streaming pass (coalesced 16-byte loads).
+// Row pitch 144 B (bf16) / 272 B (f32): 16-byte aligned for ds_read_b128, at most 2-way write conflicts.
+template <bool OUT_BF16, int ACT>
+__device__ __forceinline__ void g2_epilogue_lds(const GemmParams& p, f32x4 (&acc)[4][8], int m_base, int n_base,
+                                                char* wl, int lane) {
+  const int frow = lane & 15;
+  const int nq = (lane >> 4) * 4;
+  f32x4 bias4[4], gamma4[4];
+#pragma unroll
+  for (int ni = 0; ni < 4; ++ni) {
+    bias4[ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    gamma4[ni] = (f32x4){1.f, 1.f, 1.f, 1.f};
+  }
+  if (p.bias) {
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) bias4[ni] = *(const f32x4*)(p.bias + n_base + ni * 16 + nq);
+  }
+  if (p.gamma) {
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) gamma4[ni] = *(const f32x4*)(p.gamma + n_base + ni * 16 + nq);
+  }
+  constexpr int PITCH = OUT_BF16 ? 144 : 272;
+  constexpr int ROWS_PER_PASS = OUT_BF16 ? 128 : 64;
+  constexpr int MI_PER_PASS = ROWS_PER_PASS / 16;
+#pragma unroll
+  for (int pass = 0; pass < 128 / ROWS_PER_PASS; ++pass) {
+    // ---- registers -> LDS (row = local m, 4 consecutive n per lane and tile)
+#pragma unroll
+    for (int mq = 0; mq < MI_PER_PASS; ++mq) {
+      const int mi = pass * MI_PER_PASS + mq;
+      char* rowp = wl + (mq * 16 + frow) * PITCH;
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) {
+        f32x4 v = acc[ni][mi] + bias4[ni];
+        if (n_base + ni * 16 + nq < p.qcols) v *= p.qscale;
+        if constexpr (ACT == 1) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+        } else if constexpr (ACT == 2) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+        }
+        v *= gamma4[ni];
+        if constexpr (OUT_BF16) {
+          u32x2 o;
+          o[0] = pack_bf16x2(v[0], v[1]);
+          o[1] = pack_bf16x2(v[2], v[3]);
+          *(u32x2*)(rowp + (ni * 16 + nq) * 2) = o;
+        } else {
+          *(f32x4*)(rowp + (ni * 16 + nq) * 4) = v;
+        }
+      }
+    }
+    // ---- LDS -> global, whole rows
+    constexpr int CHUNKS = OUT_BF16 ? 8 : 16;          // 16-byte chunks per row
+    constexpr int ROWS_PER_IT = 64 / CHUNKS;
+    const int ch = lane % CHUNKS, rsub = lane / CHUNKS;
+#pragma unroll 4
+    for (int it = 0; it < ROWS_PER_PASS / ROWS_PER_IT; ++it) {
+      const int lrow = it * ROWS_PER_IT + rsub;
+      const int m = m_base + pass * ROWS_PER_PASS + lrow;
+      if (m >= p.M) continue;
+      long orow = m;
+      int trow = 0;
+      if (p.rpg > 0) {
+        const int gq = m / p.rpg;
+        trow = m - gq * p.rpg;
+        orow = (long)gq * p.gstride + p.goff + trow;
+      }
+      if constexpr (OUT_BF16) {
+        const u32x4 v = *(const u32x4*)(wl + lrow * PITCH + ch * 16);
+        *(u32x4*)((bf16_t*)p.out + orow * p.ldo + n_base + ch * 8) = v;
+      } else {
+        f32x4 v = *(const f32x4*)(wl + lrow * PITCH + ch * 16);
+        const int n0 = n_base + ch * 4;
+        if (p.resid) v += *(const f32x4*)(p.resid + orow * p.ldr + n0);
+        if (p.addtab) v += *(const f32x4*)(p.addtab + (long)trow * p.ldadd + n0);
+        *(f32x4*)((float*)p.out + orow * p.ldo + n0) = v;
+      }
+    }
+  }
+}
+
+// NOEPI: timing-only ablation (no output) to separate the main loop from the epilogue.
+template <bool OUT_BF16, int ACT, bool NOEPI = false>
+__global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 2, wn = wave & 3;
+
+  const int nbm = (p.M + G2_BM - 1) / G2_BM, nbn = p.N / G2_BN;
+  const int nwg = nbm * nbn;
+  const int id = xcd_remap(blockIdx.x, nwg);
+  constexpr int GM = 8;
+  const int per_group = GM * nbn;
+  const int g = id / per_group;
+  const int gm = min(GM, nbm - g * GM);
+  const int rem = id - g * per_group;
+  const int bm = g * GM + rem % gm;
+  const int bn = rem / gm;
+
+  const char* Ab = (const char*)p.A;
+  const char* Wb = (const char*)p.W;
+  const long lda_b = p.lda * 2, ldw_b = p.ldw * 2;
+  const int nk = p.K >> 6;
+
+  f32x4 acc[4][8];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+#define STAGE_A(U, HALF) g2_stage_half(Ab, lda_b, bm * G2_BM + (HALF) * 128, p.M, (long)(U) * 128, \
+                                       smem + ((U) & 1) * G2_BUF + (HALF) * G2_HALF, wave, lane)
+#define STAGE_W(U, HALF) g2_stage_half(Wb, ldw_b, bn * G2_BN + (HALF) * 128, p.N, (long)(U) * 128, \
+                                       smem + ((U) & 1) * G2_BUF + (2 + (HALF)) * G2_HALF, wave, lane)
+
+  // prologue: tile 0 complete, W halves of tile 1 in flight
+  STAGE_A(0, 0);
+  STAGE_A(0, 1);
+  STAGE_W(0, 0);
+  STAGE_W(0, 1);
+  if (nk > 1) {
+    STAGE_W(1, 0);
+    STAGE_W(1, 1);
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+
+  const int frow = lane & 15;
+  const int swz = (lane >> 1) & 7;
+  const int cq = lane >> 4;
+  const int off0 = ((cq) ^ swz) << 4, off1 = ((cq + 4) ^ swz) << 4;   // kk = 0, 1
+  // fragment bases inside a K-tile buffer
+  const int a_base = wm * G2_HALF + frow * 128;                                    // act half wm, rows mi*16 + frow
+  const int w_base = (2 + (wn >> 1)) * G2_HALF + ((wn & 1) * 64 + frow) * 128;     // W half, rows (wn&1)*64 + ni*16 + frow
+
+  bf16x8 fa[4][2], fw[4][2];   // act fragments of the current m-half [mi][kk]; W fragments [ni (0..3)][kk]
+
+#define READ_W(BUFP, NH)                                                                   \
+  _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                           \
+    fw[2 * (NH) + i][0] = *(const bf16x8*)((BUFP) + w_base + (2 * (NH) + i) * 2048 + off0); \
+    fw[2 * (NH) + i][1] = *(const bf16x8*)((BUFP) + w_base + (2 * (NH) + i) * 2048 + off1); \
+  }
+#define READ_A(BUFP, MH)                                                                 \
+  _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                         \
+    fa[i][0] = *(const bf16x8*)((BUFP) + a_base + (4 * (MH) + i) * 2048 + off0);          \
+    fa[i][1] = *(const bf16x8*)((BUFP) + a_base + (4 * (MH) + i) * 2048 + off1);          \
+  }
+#define MFMA_Q(MH, NH)                                                                                   \
+  __builtin_amdgcn_s_setprio(1);                                                                         \
+  _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                                        \
+  _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                           \
+  _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                           \
+    acc[2 * (NH) + i][4 * (MH) + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                            \
+        fw[2 * (NH) + i][kk], fa[j][kk], acc[2 * (NH) + i][4 * (MH) + j], 0, 0, 0);                       \
+  __builtin_amdgcn_s_setprio(0);
+// raw barrier (no vmcnt drain); the empty asm statements with a memory clobber stop the compiler from moving LDS reads /
+// LDS-DMA issues across it (s_barrier itself is not a memory operation to LLVM)
+#define PHASE_END()                            \
+  asm volatile("" ::: "memory");               \
+  __builtin_amdgcn_s_barrier();                \
+  asm volatile("" ::: "memory");
+
+  for (int u = 0; u < nk; ++u) {
+    const char* bp = smem + (u & 1) * G2_BUF;
+    const bool pre1 = (u + 1 < nk), pre2 = (u + 2 < nk);
+    // ---- phase a
+    READ_W(bp, 0)
+    READ_A(bp, 0)
+    if (pre1) STAGE_A(u + 1, 0);
+    MFMA_Q(0, 0)
+    PHASE_END()
+    // ---- phase b
+    READ_W(bp, 1)
+    if (pre1) STAGE_A(u + 1, 1);
+    MFMA_Q(0, 1)
+    PHASE_END()
+    // ---- phase c
+    READ_A(bp, 1)
+    if (pre2) STAGE_W(u + 2, 0);
+    MFMA_Q(1, 1)
+    PHASE_END()
+    // ---- phase d
+    if (pre2) {
+      STAGE_W(u + 2, 1);
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    MFMA_Q(1, 0)
+    PHASE_END()
+  }
+
+  // ---- epilogue
+  if constexpr (NOEPI) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) asm volatile("" ::"v"(acc[i][j]));
+  } else {
+    // bf16 outputs go through the LDS transpose (8-byte pieces per lane otherwise); f32 outputs already store 64-byte
+    // row segments per 4 lanes straight from the accumulators, and the LDS round trip measured slower for them
+    if constexpr (OUT_BF16)
+      g2_epilogue_lds<OUT_BF16, ACT>(p, acc, bm * G2_BM + wm * 128, bn * G2_BN + wn * 64, smem + wave * G2_EPI_WAVE,
+                                     lane);
+    else
+      gemm_epilogue<OUT_BF16, ACT, 4, 8>(p, acc, bm * G2_BM + wm * 128, bn * G2_BN + wn * 64, lane);
+  }
+}
+
+template <bool OUT_BF16, int ACT, bool NOEPI = false>
+static int launch256(const GemmParams& p, hipStream_t stream) {
+  const int nbm = (p.M + G2_BM - 1) / G2_BM, nbn = p.N / G2_BN;
+  auto kern = gemm256_kernel<OUT_BF16, ACT, NOEPI>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS_TOTAL);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(nbm * nbn), dim3(512), G2_LDS_TOTAL, stream, p);
+  return pi3_check_launch("gemm256");
+}
+
+// Used by pi3_gemm (gemm.hip) for bf16 operands when N % 256 == 0 and M is large.  Returns 1 if not applicable.
+int pi3_gemm256_try(const GemmParams& p, int out_dtype, int act, hipStream_t stream) {
+  if ((p.N % G2_BN) != 0 || (p.K % 64) != 0 || p.M < 1024) return 1;
+  if (out_dtype == 0 && (p.resid || p.addtab)) return 1;   // the bf16 streaming pass carries no residual / table add
+  static int abl = -1;
+  if (abl < 0) {
+    const char* e = getenv("PI3_GEMM_ABL");
+    abl = e ? atoi(e) : 0;
+  }
+  if (abl == 1) return launch256<true, 0, true>(p, stream);
+  if (out_dtype == 0 && act == 0) return launch256<true, 0>(p, stream);
+  if (out_dtype == 0 && act == 1) return launch256<true, 1>(p, stream);
+  if (out_dtype == 1 && act == 0) return launch256<false, 0>(p, stream);
+  return 1;
+}

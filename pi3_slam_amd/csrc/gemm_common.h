@@ -1,0 +1,91 @@
+// Shared by gemm.hip (128x128 tile) and gemm256.hip (256x256 pipelined tile): parameter block and the fused epilogue.
+#pragma once
+#include "common.h"
+
+struct GemmParams {
+  const void* A; long lda;   // [M][K], element stride
+  const void* W; long ldw;   // [N][K]
+  int M, N, K;
+  const float* bias;         // [N] or null
+  const float* gamma;        // [N] or null  (LayerScale)
+  const float* resid; long ldr;  // fp32 [*][ldr] residual source (indexed by the remapped row) or null
+  void* out; long ldo;       // bf16 or f32
+  int rpg, gstride, goff;    // row remap: orow = (m / rpg) * gstride + goff + (m % rpg); rpg == 0 -> orow = m
+  const float* addtab; long ldadd;  // optional f32 table [rpg][ldadd], row (m % rpg), added after everything else
+  float qscale; int qcols;   // columns n < qcols are multiplied by qscale (softmax scale folded into q)
+  // implicit-GEMM 3x3 convolution, replicate padding (moge/model/modules.py:47-60): A is an NHWC image
+  // [B][cH][cW][cC] (cC % 64 == 0), row m = pixel, K = 9 * cC with k = (ky*3 + kx) * cC + ci; cW == 0 -> plain GEMM
+  int cH, cW, cC;
+};
+
+
+// Fused epilogue of one wave, swapped orientation (MFMA tile rows = n, cols = m): the lane owns output row m(mi) and,
+// per n-tile ni, the 4 consecutive columns n0(ni) .. n0(ni)+3.  Per-column vectors (bias, LayerScale) are loaded once
+// for all NI tiles; per-row operands (residual, table) once per row, all NI at a time, so each optional operand costs
+// one uniform branch and one wait per row instead of one per tile.
+template <bool OUT_BF16, int ACT, int NI, int MI>
+__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[NI][MI], int m_base, int n_base,
+                                              int lane) {
+  const int frow = lane & 15;
+  const int nq = (lane >> 4) * 4;
+  f32x4 bias4[NI], gamma4[NI];
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) {
+    bias4[ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    gamma4[ni] = (f32x4){1.f, 1.f, 1.f, 1.f};
+  }
+  if (p.bias) {
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) bias4[ni] = *(const f32x4*)(p.bias + n_base + ni * 16 + nq);
+  }
+  if (p.gamma) {
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) gamma4[ni] = *(const f32x4*)(p.gamma + n_base + ni * 16 + nq);
+  }
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) {
+    const int m = m_base + mi * 16 + frow;
+    if (m >= p.M) continue;
+    long orow = m;
+    int trow = 0;
+    if (p.rpg > 0) {
+      const int gq = m / p.rpg;
+      trow = m - gq * p.rpg;
+      orow = (long)gq * p.gstride + p.goff + trow;
+    }
+    f32x4 extra[NI];
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) extra[ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (p.resid) {
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) extra[ni] = *(const f32x4*)(p.resid + orow * p.ldr + n_base + ni * 16 + nq);
+    }
+    if (p.addtab) {
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+        extra[ni] += *(const f32x4*)(p.addtab + (long)trow * p.ldadd + n_base + ni * 16 + nq);
+    }
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      const int n0 = n_base + ni * 16 + nq;
+      f32x4 v = acc[ni][mi] + bias4[ni];
+      if (n0 < p.qcols) v *= p.qscale;
+      if constexpr (ACT == 1) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+      } else if constexpr (ACT == 2) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+      }
+      v = v * gamma4[ni] + extra[ni];
+      if constexpr (OUT_BF16) {
+        u32x2 o;
+        o[0] = pack_bf16x2(v[0], v[1]);
+        o[1] = pack_bf16x2(v[2], v[3]);
+        *(u32x2*)((bf16_t*)p.out + orow * p.ldo + n0) = o;
+      } else {
+        *(f32x4*)((float*)p.out + orow * p.ldo + n0) = v;
+      }
+    }
+  }
+}

@@ -66,7 +66,9 @@ __device__ __forceinline__ void a64_softmax(f32x16 (&sc)[2], float& m, f32x16 (&
   l += psum;
 }
 
-__global__ __launch_bounds__(256, 2) void attn_fwd64_kernel(Attn64Params p) {
+// NW = waves per workgroup (4 or 8): NW * 64 query rows share one staged K/V tile.
+template <int NW>
+__global__ __launch_bounds__(NW * 64, 2) void attn_fwd64_kernel(Attn64Params p) {
   __shared__ __attribute__((aligned(16))) char lds[32768];  // K ring [2][64][128 B] then V ring [2][64][128 B]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
@@ -77,7 +79,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd64_kernel(Attn64Params p) {
   const int b = id / (p.nqb * p.H);
   const int S = p.S;
 
-  const int q0 = qb * A64_QB + wave * 64;
+  const int q0 = qb * (NW * 64) + wave * 64;
   bf16x8 qfA[4], qfB[4];
   {
     const int ra = min(q0 + r, S - 1), rb = min(q0 + 32 + r, S - 1);
@@ -97,22 +99,23 @@ __global__ __launch_bounds__(256, 2) void attn_fwd64_kernel(Attn64Params p) {
   const int nt = (S + A64_KT - 1) / A64_KT;
   const bf16_t* kbase = p.k + (long)b * p.batch_stride + head * 64;
   const bf16_t* vbase = p.v + (long)b * p.batch_stride + head * 64;
-  int srow[2], sch[2], kw[2], vw[2];
-  unsigned goff[2];
+  constexpr int CPT = 512 / (NW * 64);   // 16-byte chunks of K (and of V) per thread and tile
+  int srow[CPT], sch[CPT], kw[CPT], vw[CPT];
+  unsigned goff[CPT];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int cid = tid + 256 * i;
+  for (int i = 0; i < CPT; ++i) {
+    const int cid = tid + NW * 64 * i;
     srow[i] = cid >> 3;
     sch[i] = cid & 7;
     kw[i] = srow[i] * 128 + ((sch[i] ^ ((srow[i] >> 1) & 7)) << 4);
     vw[i] = 16384 + srow[i] * 128 + ((sch[i] ^ (((srow[i] >> 1) & 1) << 2)) << 4);
     goff[i] = (unsigned)(srow[i] * p.tok_stride + sch[i] * 8) * 2u;
   }
-  u32x4 kr[2], vr[2];
+  u32x4 kr[CPT], vr[CPT];
   auto load_tile = [&](int T, bool clamp) {
     if (clamp) {
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
+      for (int i = 0; i < CPT; ++i) {
         int grow = T * A64_KT + srow[i];
         grow = grow < S ? grow : S - 1;
         kr[i] = *(const u32x4*)(kbase + (long)grow * p.tok_stride + sch[i] * 8);
@@ -122,7 +125,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd64_kernel(Attn64Params p) {
       const char* kt_ = (const char*)(kbase + (long)T * A64_KT * p.tok_stride);
       const char* vt_ = (const char*)(vbase + (long)T * A64_KT * p.tok_stride);
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
+      for (int i = 0; i < CPT; ++i) {
         kr[i] = *(const u32x4*)(kt_ + goff[i]);
         vr[i] = *(const u32x4*)(vt_ + goff[i]);
       }
@@ -130,7 +133,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd64_kernel(Attn64Params p) {
   };
   auto write_tile = [&](int buf) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < CPT; ++i) {
       *(u32x4*)(lds + buf * 8192 + kw[i]) = kr[i];
       *(u32x4*)(lds + buf * 8192 + vw[i]) = vr[i];
     }
@@ -243,8 +246,17 @@ int pi3_attention64_launch(const void* q, const void* k, const void* v, long tok
   p.q = (const bf16_t*)q; p.k = (const bf16_t*)k; p.v = (const bf16_t*)v;
   p.tok_stride = tok_stride; p.batch_stride = batch_stride;
   p.o = (bf16_t*)o; p.o_tok_stride = o_tok_stride; p.o_batch_stride = o_batch_stride;
-  p.S = S; p.H = H; p.B = B; p.nqb = (S + A64_QB - 1) / A64_QB;
+  static int nw = -1;   // PI3_ATTN_NW: 4 or 8 waves per workgroup (A/B knob)
+  if (nw < 0) {
+    const char* e = getenv("PI3_ATTN_NW");
+    nw = e ? atoi(e) : 8;
+  }
+  const int qrows = nw == 8 ? 512 : 256;
+  p.S = S; p.H = H; p.B = B; p.nqb = (S + qrows - 1) / qrows;
   const long nwg = (long)p.nqb * H * B;
-  hipLaunchKernelGGL(attn_fwd64_kernel, dim3((unsigned)nwg), dim3(256), 0, stream, p);
+  if (nw == 8)
+    hipLaunchKernelGGL(attn_fwd64_kernel<8>, dim3((unsigned)nwg), dim3(512), 0, stream, p);
+  else
+    hipLaunchKernelGGL(attn_fwd64_kernel<4>, dim3((unsigned)nwg), dim3(256), 0, stream, p);
   return pi3_check_launch("attn_fwd64");
 }

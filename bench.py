@@ -25,7 +25,7 @@ CL, OV, H, W, KP = 100, 20, 308, 406, 200
 PEAK_BF16_DENSE_TFLOPS = 2500.0   # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md)
 
 
-def cpu_baseline(engine_cfg, n_frames: int = 2):
+def cpu_baseline(engine_cfg, n_frames: int = 4):
     """The oracle (CPU restatement of the reference forward, fp32 eager) timed on this box's host cores on a bounded
     sample of the same workload.  Weights are produced on the device by the same recipe and copied over (values do
     not matter for timing; this avoids a minute of numpy)."""
@@ -179,7 +179,7 @@ def main() -> None:
                        "algorithmic_tflop_per_chunk": fl["total"] / 1e12},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_DENSE_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_BF16_DENSE_TFLOPS, "traffic": None,
-                         "kernel": "attn_fwd_kernel (global attention, S=64300, 16 heads, d=64)",
+                         "kernel": "attn_fwd64_kernel<8, true, 0> (global attention, S=64300, 16 heads, d=64)",
                          "launch_ms": attn_ms, "launches_timed": len(attn_events),
                          "end_to_end_tflops": fl["total"] * args.steps / dt / 1e12},
         }

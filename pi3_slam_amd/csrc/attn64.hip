@@ -67,7 +67,11 @@ __device__ __forceinline__ void a64_softmax(f32x16 (&sc)[2], float& m, f32x16 (&
 }
 
 // NW = waves per workgroup (4 or 8): NW * 64 query rows share one staged K/V tile.
-template <int NW>
+// GLDS: stage K/V with LDS-DMA (global_load_lds, swizzle on the source address) instead of registers + ds_write.
+// ORDER 0: the two query blocks share every fragment read (QK and PV MFMAs interleaved A/B).
+// ORDER 1: block-sequential issue  QK_A, QK_B, softmax_A, PV_A, softmax_B, PV_B  (fragments re-read per block): one
+//          block's softmax (VALU) is issued while the other block's MFMAs are still in the matrix pipe.
+template <int NW, bool GLDS = false, int ORDER = 0>
 __global__ __launch_bounds__(NW * 64, 2) void attn_fwd64_kernel(Attn64Params p) {
   __shared__ __attribute__((aligned(16))) char lds[32768];  // K ring [2][64][128 B] then V ring [2][64][128 B]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -131,6 +135,21 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd64_kernel(Attn64Params p) 
       }
     }
   };
+  // LDS-DMA form: wave w, instruction i writes the 1 KiB segment (rows 8*seg .. 8*seg+7) of the K (V) tile; the lane's
+  // slot (row, pos) must receive source chunk pos ^ f(row)
+  auto glds_tile = [&](int T, bool clamp, int buf) {
+#pragma unroll
+    for (int i = 0; i < CPT; ++i) {
+      const int seg = wave * CPT + i;
+      const int row = seg * 8 + (lane >> 3), pos = lane & 7;
+      int grow = T * A64_KT + row;
+      if (clamp) grow = grow < S ? grow : S - 1;
+      const char* ks = (const char*)(kbase + (long)grow * p.tok_stride) + ((pos ^ ((row >> 1) & 7)) << 4);
+      const char* vs = (const char*)(vbase + (long)grow * p.tok_stride) + ((pos ^ (((row >> 1) & 1) << 2)) << 4);
+      __builtin_amdgcn_global_load_lds(GLB_PTR(ks), LDS_PTR(lds + buf * 8192 + seg * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(GLB_PTR(vs), LDS_PTR(lds + 16384 + buf * 8192 + seg * 1024), 16, 0, 0);
+    }
+  };
   auto write_tile = [&](int buf) {
 #pragma unroll
     for (int i = 0; i < CPT; ++i) {
@@ -138,8 +157,12 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd64_kernel(Attn64Params p) 
       *(u32x4*)(lds + buf * 8192 + vw[i]) = vr[i];
     }
   };
-  load_tile(0, true);
-  write_tile(0);
+  if constexpr (GLDS) {
+    glds_tile(0, true, 0);
+  } else {
+    load_tile(0, true);
+    write_tile(0);
+  }
   __syncthreads();
 
   const int kswz = (r >> 1) & 7;
@@ -151,59 +174,104 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd64_kernel(Attn64Params p) 
   const int vin_l = (vcol_l & 7) * 2;
   const int vswz = ((vrow_l >> 1) & 1) << 2;
 
-#define A64_TILE(T, BUF, FIRST, LAST, CLAMPNEXT)                                                                  \
+#define A64_QK(QF, SC)                                                                                           \
   {                                                                                                               \
-    const int buf = (BUF);                                                                                        \
-    if (!(LAST)) load_tile((T) + 1, CLAMPNEXT);                                                                   \
-    f32x16 scA[2], scB[2];                                                                                        \
-    const char* kl = lds + buf * 8192 + krow_off;                                                                 \
     {                                                                                                             \
       const int off = (h ^ kswz) << 4;                                                                            \
       const bf16x8 a0 = *(const bf16x8*)(kl + off);                                                               \
       const bf16x8 a1 = *(const bf16x8*)(kl + 32 * 128 + off);                                                    \
-      scA[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, qfA[0], (f32x16)(0.f), 0, 0, 0);                       \
-      scB[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, qfB[0], (f32x16)(0.f), 0, 0, 0);                       \
-      scA[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, qfA[0], (f32x16)(0.f), 0, 0, 0);                       \
-      scB[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, qfB[0], (f32x16)(0.f), 0, 0, 0);                       \
+      SC[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, QF[0], (f32x16)(0.f), 0, 0, 0);                         \
+      SC[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, QF[0], (f32x16)(0.f), 0, 0, 0);                         \
     }                                                                                                             \
     _Pragma("unroll") for (int s = 1; s < 4; ++s) {                                                               \
       const int off = ((2 * s + h) ^ kswz) << 4;                                                                  \
       const bf16x8 a0 = *(const bf16x8*)(kl + off);                                                               \
       const bf16x8 a1 = *(const bf16x8*)(kl + 32 * 128 + off);                                                    \
-      scA[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, qfA[s], scA[0], 0, 0, 0);                              \
-      scB[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, qfB[s], scB[0], 0, 0, 0);                              \
-      scA[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, qfA[s], scA[1], 0, 0, 0);                              \
-      scB[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, qfB[s], scB[1], 0, 0, 0);                              \
+      SC[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, QF[s], SC[0], 0, 0, 0);                                 \
+      SC[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, QF[s], SC[1], 0, 0, 0);                                 \
     }                                                                                                             \
-    if ((LAST) && (S & (A64_KT - 1))) {                                                                           \
-      const int kb = (T) * A64_KT + 4 * h;                                                                        \
-      _Pragma("unroll") for (int kt = 0; kt < 2; ++kt)                                                            \
-      _Pragma("unroll") for (int i = 0; i < 16; ++i) {                                                            \
-        const int key = kb + 32 * kt + (i & 3) + 8 * (i >> 2);                                                    \
-        if (key >= S) { scA[kt][i] = -INFINITY; scB[kt][i] = -INFINITY; }                                         \
-      }                                                                                                           \
+  }
+#define A64_PV(PF, O)                                                                                            \
+  _Pragma("unroll") for (int kt = 0; kt < 2; ++kt)                                                                \
+  _Pragma("unroll") for (int s2 = 0; s2 < 2; ++s2) {                                                              \
+    const int row0 = 32 * kt + 16 * s2 + vrow_l;                                                                  \
+    _Pragma("unroll") for (int dt = 0; dt < 2; ++dt) {                                                            \
+      const int ch = (4 * dt + vch_l) ^ vswz;                                                                     \
+      const char* a = vl + row0 * 128 + (ch << 4) + vin_l;                                                        \
+      const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(                                                 \
+          (__attribute__((address_space(3))) bf16x4*)LDS_PTR(a));                                                 \
+      const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(                                                 \
+          (__attribute__((address_space(3))) bf16x4*)LDS_PTR(a + 8 * 128));                                       \
+      O[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a64_cat4(lo, hi), PF[kt][s2], O[dt], 0, 0, 0);              \
     }                                                                                                             \
-    bf16x8 pfA[2][2], pfB[2][2];                                                                                  \
-    a64_softmax<FIRST>(scA, mA, oA, lA, pfA);                                                                  \
-    a64_softmax<FIRST>(scB, mB, oB, lB, pfB);                                                                  \
-    const char* vl = lds + 16384 + buf * 8192;                                                                    \
+  }
+#define A64_MASK(T, SC)                                                                                          \
+  {                                                                                                               \
+    const int kb = (T) * A64_KT + 4 * h;                                                                          \
     _Pragma("unroll") for (int kt = 0; kt < 2; ++kt)                                                              \
-    _Pragma("unroll") for (int s2 = 0; s2 < 2; ++s2) {                                                            \
-      const int row0 = 32 * kt + 16 * s2 + vrow_l;                                                                \
-      _Pragma("unroll") for (int dt = 0; dt < 2; ++dt) {                                                          \
-        const int ch = (4 * dt + vch_l) ^ vswz;                                                                   \
-        const char* a = vl + row0 * 128 + (ch << 4) + vin_l;                                                      \
-        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(                                               \
-            (__attribute__((address_space(3))) bf16x4*)LDS_PTR(a));                                               \
-        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(                                               \
-            (__attribute__((address_space(3))) bf16x4*)LDS_PTR(a + 8 * 128));                                     \
-        const bf16x8 vf = a64_cat4(lo, hi);                                                                       \
-        oA[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pfA[kt][s2], oA[dt], 0, 0, 0);                       \
-        oB[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pfB[kt][s2], oB[dt], 0, 0, 0);                       \
+    _Pragma("unroll") for (int i = 0; i < 16; ++i) {                                                              \
+      const int key = kb + 32 * kt + (i & 3) + 8 * (i >> 2);                                                      \
+      if (key >= S) SC[kt][i] = -INFINITY;                                                                        \
+    }                                                                                                             \
+  }
+
+#define A64_TILE(T, BUF, FIRST, LAST, CLAMPNEXT)                                                                  \
+  {                                                                                                               \
+    const int buf = (BUF);                                                                                        \
+    if (!(LAST)) { if constexpr (GLDS) glds_tile((T) + 1, CLAMPNEXT, buf ^ 1); else load_tile((T) + 1, CLAMPNEXT); } \
+    f32x16 scA[2], scB[2];                                                                                        \
+    bf16x8 pfA[2][2], pfB[2][2];                                                                                  \
+    const char* kl = lds + buf * 8192 + krow_off;                                                                 \
+    const char* vl = lds + 16384 + buf * 8192;                                                                    \
+    const bool masktail = (LAST) && (S & (A64_KT - 1));                                                           \
+    if constexpr (ORDER == 1) {                                                                                   \
+      A64_QK(qfA, scA)                                                                                            \
+      A64_QK(qfB, scB)                                                                                            \
+      if (masktail) { A64_MASK(T, scA) A64_MASK(T, scB) }                                                         \
+      a64_softmax<FIRST>(scA, mA, oA, lA, pfA);                                                                   \
+      A64_PV(pfA, oA)                                                                                             \
+      a64_softmax<FIRST>(scB, mB, oB, lB, pfB);                                                                   \
+      A64_PV(pfB, oB)                                                                                             \
+    } else {                                                                                                      \
+      {                                                                                                           \
+        const int off = (h ^ kswz) << 4;                                                                          \
+        const bf16x8 a0 = *(const bf16x8*)(kl + off);                                                             \
+        const bf16x8 a1 = *(const bf16x8*)(kl + 32 * 128 + off);                                                  \
+        scA[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, qfA[0], (f32x16)(0.f), 0, 0, 0);                     \
+        scB[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, qfB[0], (f32x16)(0.f), 0, 0, 0);                     \
+        scA[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, qfA[0], (f32x16)(0.f), 0, 0, 0);                     \
+        scB[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, qfB[0], (f32x16)(0.f), 0, 0, 0);                     \
+      }                                                                                                           \
+      _Pragma("unroll") for (int s = 1; s < 4; ++s) {                                                             \
+        const int off = ((2 * s + h) ^ kswz) << 4;                                                                \
+        const bf16x8 a0 = *(const bf16x8*)(kl + off);                                                             \
+        const bf16x8 a1 = *(const bf16x8*)(kl + 32 * 128 + off);                                                  \
+        scA[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, qfA[s], scA[0], 0, 0, 0);                            \
+        scB[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, qfB[s], scB[0], 0, 0, 0);                            \
+        scA[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, qfA[s], scA[1], 0, 0, 0);                            \
+        scB[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, qfB[s], scB[1], 0, 0, 0);                            \
+      }                                                                                                           \
+      if (masktail) { A64_MASK(T, scA) A64_MASK(T, scB) }                                                         \
+      a64_softmax<FIRST>(scA, mA, oA, lA, pfA);                                                                   \
+      a64_softmax<FIRST>(scB, mB, oB, lB, pfB);                                                                   \
+      _Pragma("unroll") for (int kt = 0; kt < 2; ++kt)                                                            \
+      _Pragma("unroll") for (int s2 = 0; s2 < 2; ++s2) {                                                          \
+        const int row0 = 32 * kt + 16 * s2 + vrow_l;                                                              \
+        _Pragma("unroll") for (int dt = 0; dt < 2; ++dt) {                                                        \
+          const int ch = (4 * dt + vch_l) ^ vswz;                                                                 \
+          const char* a = vl + row0 * 128 + (ch << 4) + vin_l;                                                    \
+          const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(                                             \
+              (__attribute__((address_space(3))) bf16x4*)LDS_PTR(a));                                             \
+          const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(                                             \
+              (__attribute__((address_space(3))) bf16x4*)LDS_PTR(a + 8 * 128));                                   \
+          const bf16x8 vf = a64_cat4(lo, hi);                                                                     \
+          oA[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pfA[kt][s2], oA[dt], 0, 0, 0);                     \
+          oB[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pfB[kt][s2], oB[dt], 0, 0, 0);                     \
+        }                                                                                                         \
       }                                                                                                           \
     }                                                                                                             \
     if (!(LAST)) {                                                                                                \
-      write_tile(buf ^ 1);                                                                                        \
+      if constexpr (!GLDS) write_tile(buf ^ 1);                                                                   \
       __syncthreads();                                                                                            \
     }                                                                                                             \
   }
@@ -254,7 +322,21 @@ int pi3_attention64_launch(const void* q, const void* k, const void* v, long tok
   const int qrows = nw == 8 ? 512 : 256;
   p.S = S; p.H = H; p.B = B; p.nqb = (S + qrows - 1) / qrows;
   const long nwg = (long)p.nqb * H * B;
-  if (nw == 8)
+  static int glds = -1;   // PI3_ATTN_GLDS: 1 = LDS-DMA staging (A/B knob)
+  if (glds < 0) {
+    const char* e = getenv("PI3_ATTN_GLDS");
+    glds = e ? atoi(e) : 1;
+  }
+  static int order = -1;   // PI3_ATTN_ORDER: 0 interleaved blocks, 1 block-sequential issue (A/B knob)
+  if (order < 0) {
+    const char* e = getenv("PI3_ATTN_ORDER");
+    order = e ? atoi(e) : 0;
+  }
+  if (nw == 8 && glds && order == 1)
+    hipLaunchKernelGGL((attn_fwd64_kernel<8, true, 1>), dim3((unsigned)nwg), dim3(512), 0, stream, p);
+  else if (nw == 8 && glds)
+    hipLaunchKernelGGL((attn_fwd64_kernel<8, true>), dim3((unsigned)nwg), dim3(512), 0, stream, p);
+  else if (nw == 8)
     hipLaunchKernelGGL(attn_fwd64_kernel<8>, dim3((unsigned)nwg), dim3(512), 0, stream, p);
   else
     hipLaunchKernelGGL(attn_fwd64_kernel<4>, dim3((unsigned)nwg), dim3(256), 0, stream, p);

@@ -206,3 +206,60 @@ def test_patch_gather_and_resample(dev):
     got = ops.resample_grid(src, wy, wx)
     ref = torch.nn.functional.interpolate(src.permute(2, 0, 1)[None].cpu(), size=(2, 3), mode="bicubic", antialias=True)
     assert rel(got.cpu(), ref[0].permute(1, 2, 0))[0] < 1e-5
+
+
+@pytest.mark.parametrize("M,N,K", [(2049, 512, 128), (1500, 256, 4096), (5000, 1024, 1024), (1024, 256, 64)])
+def test_gemm256_pipelined_kernel(dev, M, N, K):
+    """Shapes that take the 256x256 phase-pipelined kernel (N % 256 == 0, M >= 1024): every epilogue it serves, the M
+    tail (clamped rows), 1 and 2 K-tiles (prologue / drain paths) and a long K loop."""
+    from pi3_slam_amd import ops
+    a = torch.randn(M, K, device=dev).bfloat16()
+    w = (torch.randn(N, K, device=dev) / math.sqrt(K)).bfloat16()
+    bias, gamma, resid = torch.randn(N, device=dev), torch.rand(N, device=dev) + 0.5, torch.randn(M, N, device=dev)
+    ref = a.float() @ w.float().T + bias
+    out = torch.full((M + 3, N), 9.0, device=dev, dtype=torch.bfloat16)
+    ops.gemm(a, w, out, M=M, bias=bias)
+    assert rel(out[:M], ref)[0] < 6e-3 and torch.all(out[M:] == 9.0)            # rows beyond M untouched
+    ops.gemm(a, w, out, M=M, bias=bias, act=ops.ACT_GELU)
+    assert rel(out[:M], torch.nn.functional.gelu(ref))[0] < 6e-3
+    ops.gemm(a, w, out, M=M, bias=bias, qscale=0.25, qcols=N // 2)
+    ref2 = ref.clone(); ref2[:, : N // 2] *= 0.25
+    assert rel(out[:M], ref2)[0] < 6e-3
+    o32 = resid.clone()
+    ops.gemm(a, w, o32, bias=bias, gamma=gamma, resid=o32)
+    assert rel(o32, resid + gamma * ref)[0] < 2e-5
+    # row remap + table (patch-embed form) through the f32 epilogue
+    P, T = 250, 257
+    Fr = M // P
+    tab = torch.randn(P, N, device=dev)
+    outr = torch.full((Fr * T, N), 7.0, device=dev)
+    ops.gemm(a, w, outr, M=Fr * P, bias=bias, rpg=P, gstride=T, goff=5, addtab=tab)
+    refr = ref[: Fr * P].view(Fr, P, N) + tab
+    assert rel(outr.view(Fr, T, N)[:, 5:5 + P], refr)[0] < 2e-5
+    assert torch.all(outr.view(Fr, T, N)[:, :5] == 7.0)
+
+
+def test_gemm_fast_gelu_matches_erf_gelu(dev):
+    """The epilogue GELU uses an Abramowitz-Stegun erf (abs error 1.5e-7): check it on an f32-out GEMM against erf-GELU."""
+    from pi3_slam_amd import ops
+    M, N, K = 256, 128, 64
+    a = (torch.randn(M, K, device=dev) * 3).bfloat16()
+    w = torch.eye(N, K, device=dev).bfloat16()
+    out = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+    ops.gemm(a, w, out, act=ops.ACT_GELU)
+    ref = torch.nn.functional.gelu(a.float()[:, :N].contiguous() if K >= N else torch.nn.functional.pad(a.float(), (0, N - K)))
+    assert (out.float() - ref).abs().max() < 2e-2 and rel(out, ref)[0] < 5e-3
+
+
+@pytest.mark.parametrize("B,S,H", [(1, 4500, 2), (2, 4096, 1), (1, 5121, 3)])
+def test_attention_long_sequence_kernel(dev, B, S, H):
+    """S >= 4096 takes the 64-rows-per-wave kernel (8 waves, LDS-DMA staging): compare with a softmax reference."""
+    from pi3_slam_amd import ops
+    qkv = torch.randn(B * S, 3 * H * 64, device=dev)
+    qkv[:, :H * 64] *= ops.QSCALE * 2.0
+    qkv[S // 2, H * 64: H * 64 + 64] = qkv[11, :64] * 30.0        # forces a late rescale in the first head
+    qkv = qkv.bfloat16()
+    out = torch.empty(B * S, H * 64, device=dev, dtype=torch.bfloat16)
+    ops.attention(qkv, out, B, S, H)
+    mx, mean = rel(out, attn_ref(qkv, B, S, H))
+    assert mx < 8e-3 and mean < 5e-3

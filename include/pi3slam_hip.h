@@ -182,6 +182,12 @@ int pi3_sim3_apply(const double* M4_dev, float* pts, long n, float* poses, int F
 /* G[c] = G[c-1] . T[c], G[0] = T[0]: prefix composition of per-chunk relative similarities ([n][16] f64). */
 int pi3_sim3_compose_prefix(const double* T, double* G, int n, void* stream);
 
+/* ---- next-tier: observation projection of ChunkPTRecon (utils/chunk_reconstruction.py:162-185,
+ * 445-509).  points f16 [N][K][3], poses f32 [N][16], intrinsics f32 [N][9] -> uv f32 [N][N][K][2] ([source][target]),
+ * valid uint8 [N][N][K] (in-bounds observations of the pairs target < source or source < target <= source + max_after). */
+int pi3_project_observations(const void* points, const float* poses, const float* intrinsics, int N, int K, int W,
+                             int H, int max_after, float* uv, unsigned char* valid, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -115,6 +115,44 @@ def main() -> None:
     for (cl, ov) in [(100, 20), (32, 8), (5, 0)]:
         layout[f"vgm_{cl}_{ov}"] = np.array(create_view_graph_matches(cl, ov), dtype=np.int64).reshape(-1, 2)
     np.savez_compressed(os.path.join(out_dir, "post_layout.npz"), **layout)
+
+    # next tier: observation projection of ChunkPTRecon, run through the reference's own methods
+    for name in ("matplotlib", "matplotlib.pyplot", "matplotlib.animation"):
+        if name not in sys.modules:
+            try:
+                __import__(name)
+            except Exception:
+                sys.modules[name] = _Placeholder(name)
+    from utils.chunk_reconstruction import ChunkPTRecon
+    rec = object.__new__(ChunkPTRecon)  # the projection methods use no constructor state (pytheia is absent)
+    N, K, W, H, max_obs = 7, 40, 112, 84, 5
+    rec.set_target_size(W, H)
+    g = torch.Generator().manual_seed(77)
+    ang = 0.25 * torch.randn(N, 3, generator=g, dtype=torch.float64)
+    poses = torch.eye(4, dtype=torch.float64).repeat(N, 1, 1)
+    for i in range(N):
+        th = ang[i].norm()
+        k = ang[i] / th
+        Kx = torch.tensor([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]], dtype=torch.float64)
+        poses[i, :3, :3] = torch.eye(3, dtype=torch.float64) + torch.sin(th) * Kx + (1 - torch.cos(th)) * Kx @ Kx
+        poses[i, :3, 3] = 0.3 * torch.randn(3, generator=g, dtype=torch.float64)
+    poses = poses.float()
+    intr = torch.tensor([[90.0, 0, W / 2], [0, 92.0, H / 2], [0, 0, 1]]).repeat(N, 1, 1)
+    intr[:, 0, 0] += torch.arange(N) * 0.5
+    pts = torch.randn(N, K, 3, generator=g) * torch.tensor([1.0, 0.8, 1.0]) + torch.tensor([0.0, 0.0, 3.0])
+    pts = pts.to(torch.float16)
+    chunk = {"camera_poses": poses, "intrinsics": intr, "points": pts, "keypoints": torch.zeros(N, K, 2)}
+    uv = np.zeros((N, N, K, 2))
+    valid = np.zeros((N, N, K), dtype=bool)
+    for src in range(N):
+        frames = list(range(N))
+        targets = frames[:src] + frames[src + 1: src + max_obs // 2 + 1]
+        for tgt, pr in zip(targets, rec._project_points_to_other_cams(chunk, src, targets)):
+            uv[src, tgt] = pr
+            valid[src, tgt] = [(0 <= q[0] < rec.original_width and 0 <= q[1] < rec.original_height) for q in pr]
+    np.savez_compressed(os.path.join(out_dir, "post_proj.npz"), poses=poses.numpy(), intrinsics=intr.numpy(),
+                        points=pts.numpy(), uv=uv, valid=valid, shape=np.array([N, K, W, H, max_obs // 2]))
+    print("projection golden: valid frac", valid.mean())
     print("wrote post goldens to", out_dir)
 
 

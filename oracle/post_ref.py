@@ -264,3 +264,25 @@ def apply_sim3(M: np.ndarray, pts: np.ndarray, poses: np.ndarray):
     P2[:, :3, :3] = (sR / s) @ poses[:, :3, :3].astype(np.float64)
     P2[:, :3, 3] = (sR @ poses[:, :3, 3].astype(np.float64).T).T + t
     return p2, P2
+
+
+# ------------------------------------------------------------------------------------------------ next tier (§8f)
+def project_observations(points: np.ndarray, poses: np.ndarray, intrinsics: np.ndarray, W: int, H: int,
+                         max_after: int):
+    """ChunkPTRecon observation projection (utils/chunk_reconstruction.py:162-185 loop, :481-509 projection).
+    points (N,K,3) float16, poses (N,4,4) float32, intrinsics (N,3,3) float32 -> uv (N,N,K,2) float64 [src][tgt],
+    valid (N,N,K) bool."""
+    N, K = points.shape[:2]
+    uv = np.zeros((N, N, K, 2))
+    valid = np.zeros((N, N, K), dtype=bool)
+    for src in range(N):
+        targets = list(range(src)) + list(range(src + 1, min(N, src + max_after + 1)))
+        X = np.hstack([points[src], np.ones((K, 1))])
+        for tgt in targets:
+            w2t = np.linalg.inv(poses[tgt])
+            pt = (w2t @ X.T).T
+            p2d = pt[:, :3] / pt[:, 2:3]
+            proj = (intrinsics[tgt] @ p2d.T).T
+            uv[src, tgt] = proj[:, :2]
+            valid[src, tgt] = (proj[:, 0] >= 0) & (proj[:, 0] < W) & (proj[:, 1] >= 0) & (proj[:, 1] < H)
+    return uv, valid

@@ -308,3 +308,82 @@ extern "C" int pi3_sim3_compose_prefix(const double* T, double* G, int n, void* 
   hipLaunchKernelGGL(sim3_compose_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, T, G, n);
   return pi3_check_launch("sim3_compose_prefix");
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Observation projection of ChunkPTRecon.create_recon_from_chunk (utils/chunk_reconstruction.py:162-185, 445-509),
+// every frame's K keypoint world points are projected into all EARLIER frames and into the next
+// `max_after` (= max_observations_per_track // 2) frames:  x = K_t . ((T_t^-1 X)[:3] / z);  an observation is kept when
+// 0 <= u < W and 0 <= v < H (no z > 0 test in the reference).  The reference is a python triple loop with one
+// np.linalg.inv per (source, target) pair; here one workgroup per (source, target) pair, fp64 math like the
+// reference's float64 promotion, the 4x4 inverse by Gauss-Jordan with partial pivoting.
+// points: f16 [N][K][3]; poses: f32 [N][16] cam->world; intr: f32 [N][9].  uv: f32 [N][N][K][2] indexed
+// [source][target]; valid: uint8 [N][N][K] (0 for pairs that are not projected at all).
+// ---------------------------------------------------------------------------------------------------------------
+__device__ inline void inv4x4_d(const double* A, double* Ainv) {
+  double M[4][8];
+  for (int r = 0; r < 4; ++r)
+    for (int c = 0; c < 4; ++c) { M[r][c] = A[4 * r + c]; M[r][4 + c] = (r == c) ? 1.0 : 0.0; }
+  for (int col = 0; col < 4; ++col) {
+    int piv = col;
+    for (int r = col + 1; r < 4; ++r)
+      if (fabs(M[r][col]) > fabs(M[piv][col])) piv = r;
+    if (piv != col)
+      for (int c = 0; c < 8; ++c) { const double t = M[col][c]; M[col][c] = M[piv][c]; M[piv][c] = t; }
+    const double d = 1.0 / M[col][col];
+    for (int c = 0; c < 8; ++c) M[col][c] *= d;
+    for (int r = 0; r < 4; ++r)
+      if (r != col) {
+        const double f = M[r][col];
+        for (int c = 0; c < 8; ++c) M[r][c] -= f * M[col][c];
+      }
+  }
+  for (int r = 0; r < 4; ++r)
+    for (int c = 0; c < 4; ++c) Ainv[4 * r + c] = M[r][4 + c];
+}
+
+__global__ __launch_bounds__(128) void project_obs_kernel(const __half* __restrict__ points,
+                                                          const float* __restrict__ poses,
+                                                          const float* __restrict__ intr, int N, int K, int W, int H,
+                                                          int max_after, float* __restrict__ uv,
+                                                          uint8_t* __restrict__ valid) {
+  const int src = blockIdx.y, tgt = blockIdx.x;
+  const bool active = (tgt < src) || (tgt > src && tgt <= src + max_after);
+  const long base = ((long)src * N + tgt) * K;
+  __shared__ double Winv[16];
+  __shared__ double Kt[9];
+  if (!active) {
+    for (int k = threadIdx.x; k < K; k += 128) valid[base + k] = 0;
+    return;
+  }
+  if (threadIdx.x == 0) {
+    double P[16];
+    for (int i = 0; i < 16; ++i) P[i] = (double)poses[16 * tgt + i];
+    inv4x4_d(P, Winv);
+    for (int i = 0; i < 9; ++i) Kt[i] = (double)intr[9 * tgt + i];
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < K; k += 128) {
+    const __half* p = points + ((long)src * K + k) * 3;
+    const double X = (double)__half2float(p[0]), Y = (double)__half2float(p[1]), Z = (double)__half2float(p[2]);
+    const double xc = Winv[0] * X + Winv[1] * Y + Winv[2] * Z + Winv[3];
+    const double yc = Winv[4] * X + Winv[5] * Y + Winv[6] * Z + Winv[7];
+    const double zc = Winv[8] * X + Winv[9] * Y + Winv[10] * Z + Winv[11];
+    const double xn = xc / zc, yn = yc / zc, zn = zc / zc;
+    const double u = Kt[0] * xn + Kt[1] * yn + Kt[2] * zn;
+    const double v = Kt[3] * xn + Kt[4] * yn + Kt[5] * zn;
+    uv[2 * (base + k)] = (float)u;
+    uv[2 * (base + k) + 1] = (float)v;
+    valid[base + k] = (u >= 0.0 && u < (double)W && v >= 0.0 && v < (double)H) ? 1 : 0;
+  }
+}
+
+extern "C" int pi3_project_observations(const void* points, const float* poses, const float* intrinsics, int N, int K,
+                                        int W, int H, int max_after, float* uv, unsigned char* valid, void* stream) {
+  if (!points || !poses || !intrinsics || !uv || !valid || N <= 0 || K <= 0 || W <= 0 || H <= 0 || max_after < 0) {
+    pi3_set_error("pi3_project_observations: bad arguments");
+    return PI3_ERR_ARG;
+  }
+  hipLaunchKernelGGL(project_obs_kernel, dim3(N, N), dim3(128), 0, (hipStream_t)stream, (const __half*)points, poses,
+                     intrinsics, N, K, W, H, max_after, uv, valid);
+  return pi3_check_launch("project_observations");
+}

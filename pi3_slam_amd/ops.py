@@ -369,3 +369,18 @@ def moge_depth(pts, shift, log_scale, mask, n, depth) -> None:
     rc = lib.pi3_moge_depth(pts.data_ptr(), shift.data_ptr(), _L.ptr(log_scale), mask.data_ptr(), n,
                             depth.data_ptr(), _L.stream_ptr())
     _L.check(rc, "pi3_moge_depth")
+
+
+def project_observations(points: torch.Tensor, poses: torch.Tensor, intrinsics: torch.Tensor, W: int, H: int,
+                         max_after: int):
+    """points f16 [N,K,3], poses f32 [N,4,4], intrinsics f32 [N,3,3] -> (uv f32 [N,N,K,2], valid bool [N,N,K])."""
+    lib = _L.load()
+    N, K = points.shape[:2]
+    assert points.dtype == torch.float16 and points.is_contiguous()
+    poses, intrinsics = poses.float().contiguous(), intrinsics.float().contiguous()
+    uv = torch.zeros(N, N, K, 2, device=points.device, dtype=torch.float32)
+    valid = torch.empty(N, N, K, device=points.device, dtype=torch.uint8)
+    rc = lib.pi3_project_observations(points.data_ptr(), poses.data_ptr(), intrinsics.data_ptr(), N, K, W, H,
+                                      max_after, uv.data_ptr(), valid.data_ptr(), _L.stream_ptr())
+    _L.check(rc, "pi3_project_observations")
+    return uv, valid.bool()

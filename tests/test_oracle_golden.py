@@ -105,3 +105,14 @@ def test_moge_oracle_matches_reference_vectors(name):
     assert np.all(np.isinf(out["depth"].numpy()[~mask]))
     np.testing.assert_allclose(out["metric_scale"].numpy(), g["metric_scale"][0], rtol=1e-5)
     np.testing.assert_allclose(out["intrinsics"].numpy(), g["intrinsics"], rtol=1e-4)
+
+
+def test_projection_oracle_matches_reference():
+    """Observation projection restatement vs the reference's own ChunkPTRecon methods (gen_golden_post.py)."""
+    from oracle import post_ref
+    g = np.load(os.path.join(GOLDEN, "post_proj.npz"))
+    N, K, W, H, max_after = [int(v) for v in g["shape"]]
+    uv, valid = post_ref.project_observations(g["points"], g["poses"], g["intrinsics"], W, H, max_after)
+    assert np.array_equal(valid, g["valid"])
+    np.testing.assert_allclose(uv, g["uv"], rtol=0, atol=1e-9)
+    assert valid.any() and not valid.all()

@@ -253,3 +253,58 @@ def test_apply_scale_ignores_invalid_median(dev):
         a, b, c = lp.clone(), pts.clone(), poses.clone()
         ops.apply_scale(torch.tensor([bad], device=dev), a, b, c)
         assert torch.equal(a, lp) and torch.equal(b, pts) and torch.equal(c, poses)
+
+
+def test_project_observations_against_reference_vectors(dev):
+    """§8f rank 1: observation projection kernel vs vectors produced by the reference's ChunkPTRecon methods."""
+    from pi3_slam_amd import ops
+    from pi3_slam_amd.observations import project_chunk_observations
+    g = np.load(os.path.join(GOLDEN, "post_proj.npz"))
+    N, K, W, H, max_after = [int(v) for v in g["shape"]]
+    pts = torch.from_numpy(g["points"]).to(dev)
+    poses = torch.from_numpy(g["poses"]).to(dev)
+    intr = torch.from_numpy(g["intrinsics"]).to(dev)
+    uv, valid = ops.project_observations(pts, poses, intr, W, H, max_after)
+    torch.cuda.synchronize()
+    uv, valid = uv.cpu().numpy(), valid.cpu().numpy()
+    ref_uv, ref_valid = g["uv"], g["valid"]
+    pair = np.zeros((N, N), dtype=bool)
+    for s in range(N):
+        pair[s, :s] = True
+        pair[s, s + 1:s + 1 + max_after] = True
+    assert not valid[~pair].any()
+    # tolerance: the reference inverts the fp32 pose with LAPACK sgetri, the kernel in fp64 -> ~1e-6 relative on the
+    # camera-frame point, amplified by 1/z for points near the camera plane.  Compare where the reference value is
+    # finite and moderately sized; require the in-bounds flag to agree except within 1e-2 px of a border.
+    sel = pair[:, :, None] & np.isfinite(ref_uv).all(-1) & (np.abs(ref_uv).max(-1) < 1e4)
+    err = np.abs(uv - ref_uv)[sel]
+    scale = np.maximum(1.0, np.abs(ref_uv)[sel])
+    assert (err / scale).max() < 2e-4, (err / scale).max()
+    flips = (valid != ref_valid) & pair[:, :, None]
+    if flips.any():
+        u, v = ref_uv[..., 0][flips], ref_uv[..., 1][flips]
+        d = np.minimum.reduce([np.abs(u), np.abs(u - W), np.abs(v), np.abs(v - H)])
+        assert d.max() < 1e-2
+    assert flips.mean() < 1e-3
+    # host mirror: same observations, in the reference's loop order
+    chunk = {"points": pts, "camera_poses": poses, "intrinsics": intr}
+    obs = project_chunk_observations(chunk, W, H, max_observations_per_track=2 * max_after + 1)
+    s, t, k = np.nonzero(valid)
+    assert np.array_equal(obs["source_frame"].cpu().numpy(), s)
+    assert np.array_equal(obs["target_frame"].cpu().numpy(), t)
+    assert np.array_equal(obs["keypoint"].cpu().numpy(), k)
+    assert np.array_equal(obs["uv"].cpu().numpy(), uv[s, t, k])
+    # full chunk size (cl=100, K=200 keypoints): count agrees with the oracle
+    from oracle import post_ref
+    gen = torch.Generator().manual_seed(5)
+    Nf, Kf = 100, 200
+    P = torch.eye(4).repeat(Nf, 1, 1)
+    P[:, 0, 3] = torch.arange(Nf) * 0.05
+    X = (torch.randn(Nf, Kf, 3, generator=gen) * torch.tensor([2.0, 1.5, 1.0]) + torch.tensor([2.5, 0.0, 4.0])).half()
+    Kf33 = torch.tensor([[400.0, 0, 320], [0, 400.0, 240], [0, 0, 1]]).repeat(Nf, 1, 1)
+    uvf, vf = ops.project_observations(X.to(dev), P.to(dev), Kf33.to(dev), 640, 480, 2)
+    ouv, ov_ = post_ref.project_observations(X.numpy(), P.numpy(), Kf33.numpy(), 640, 480, 2)
+    vf = vf.cpu().numpy()
+    assert (vf != ov_).mean() < 1e-4
+    both = vf & ov_
+    assert np.abs(uvf.cpu().numpy()[both] - ouv[both]).max() < 1e-2

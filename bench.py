@@ -183,7 +183,7 @@ def main() -> None:
                        "algorithmic_tflop_per_chunk": fl["total"] / 1e12},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_DENSE_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_BF16_DENSE_TFLOPS, "traffic": ATTN_TRAFFIC_BYTES,
-                         "kernel": "attn_fwd64_kernel<8, true, 0> (global attention, S=64300, 16 heads, d=64)",
+                         "kernel": "attn_fwd64_kernel<8, true> + 25 us key-norm pre-pass (global attention, S=64300, 16 heads, d=64)",
                          "launch_ms": attn_ms, "launches_timed": len(attn_events),
                          "end_to_end_tflops": fl["total"] * args.steps / dt / 1e12},
         }

@@ -69,11 +69,18 @@ __device__ __forceinline__ void a64_glds16(const void* gsrc, const void* lds_dst
   asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(m0v) : "memory", "m0");
 }
 
-// online-softmax step of one 32-row block on its two raw score tiles; m is the per-lane running max (exp2 domain)
-template <bool FIRST, bool NOMAX>
-__device__ __forceinline__ void a64_softmax(f32x16 (&sc)[2], float& m, f32x16 (&o)[2], float& l, bf16x8 (&pf)[2][2]) {
+// online-softmax step of one 32-row block on its two raw score tiles; m is the per-lane running max (exp2 domain).
+// MSUM (bounded-score path only): the row sum is taken by the matrix pipe, which idles through most of this VALU-bound
+// phase: v_mfma_f32_4x4x4_16B_bf16 with an all-ones A operand adds the lane's own four packed bf16 probabilities into
+// lacc (D_b[i][j] = sum_k B_b[k][j], and lane 4b+j holds both column j of B_b and column j of D_b).  16 two-pass MFMAs
+// replace 68 v_add_f32 per tile, and l sums exactly the bf16 values that P.V multiplies.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+template <bool FIRST, bool NOMAX, bool MSUM>
+__device__ __forceinline__ void a64_softmax(f32x16 (&sc)[2], float& m, f32x16 (&o)[2], float& l, f32x4& lacc,
+                                            bf16x8 (&pf)[2][2]) {
   if constexpr (NOMAX) {
     float ps0 = 0.f, ps1 = 0.f;
+    const s16x4 ones = {0x3f80, 0x3f80, 0x3f80, 0x3f80};
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
@@ -83,13 +90,21 @@ __device__ __forceinline__ void a64_softmax(f32x16 (&sc)[2], float& m, f32x16 (&
         for (int jj = 0; jj < 4; ++jj) {
           const float p0 = __builtin_amdgcn_exp2f(sc[kt][8 * s2 + 2 * jj]);
           const float p1 = __builtin_amdgcn_exp2f(sc[kt][8 * s2 + 2 * jj + 1]);
-          ps0 += p0;
-          ps1 += p1;
+          if constexpr (!MSUM) {
+            ps0 += p0;
+            ps1 += p1;
+          }
           pw[jj] = pack_bf16x2(p0, p1);
+        }
+        if constexpr (MSUM) {
+          u32x2 lo2, hi2;
+          lo2[0] = pw[0]; lo2[1] = pw[1]; hi2[0] = pw[2]; hi2[1] = pw[3];
+          lacc = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(ones, __builtin_bit_cast(s16x4, lo2), lacc, 0, 0, 0);
+          lacc = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(ones, __builtin_bit_cast(s16x4, hi2), lacc, 0, 0, 0);
         }
         pf[kt][s2] = __builtin_bit_cast(bf16x8, pw);
       }
-    l += ps0 + ps1;
+    if constexpr (!MSUM) l += ps0 + ps1;
     return;
   }
   float tmax = sc[0][0];
@@ -131,7 +146,7 @@ __device__ __forceinline__ void a64_softmax(f32x16 (&sc)[2], float& m, f32x16 (&
 
 // NW = waves per workgroup (4 or 8): NW * 64 query rows share one staged K/V tile.
 // GLDS: stage K/V with LDS-DMA (global_load_lds, swizzle on the source address) instead of registers + ds_write.
-template <int NW, bool GLDS = false>
+template <int NW, bool GLDS = false, bool MSUM = false>
 __global__ __launch_bounds__(NW * 64, 2) void attn_fwd64_kernel(Attn64Params p) {
   __shared__ __attribute__((aligned(16))) char lds[32768];  // K ring [2][64][128 B] then V ring [2][64][128 B]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -159,6 +174,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd64_kernel(Attn64Params p) 
   float mA = 0.f, mB = 0.f;
   oA[0] = oA[1] = oB[0] = oB[1] = (f32x16)(0.f);
   float lA = 0.f, lB = 0.f;
+  f32x4 laccA = (f32x4)(0.f), laccB = (f32x4)(0.f);   // MSUM: row sums accumulated by the matrix pipe
 
   const int nt = (S + A64_KT - 1) / A64_KT;
   const bf16_t* kbase = p.k + (long)b * p.batch_stride + head * 64;
@@ -276,8 +292,8 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd64_kernel(Attn64Params p) 
       }                                                                                                           \
       if (masktail) { A64_MASK(T, scA) A64_MASK(T, scB) }                                                         \
       A64_STAMP(T, 1)                                                                                             \
-      a64_softmax<FIRST, NOMAX>(scA, mA, oA, lA, pfA);                                                                   \
-      a64_softmax<FIRST, NOMAX>(scB, mB, oB, lB, pfB);                                                                   \
+      a64_softmax<FIRST, NOMAX, MSUM>(scA, mA, oA, lA, laccA, pfA);                                                                   \
+      a64_softmax<FIRST, NOMAX, MSUM>(scB, mB, oB, lB, laccB, pfB);                                                                   \
       _Pragma("unroll") for (int kt = 0; kt < 2; ++kt)                                                            \
       _Pragma("unroll") for (int s2 = 0; s2 < 2; ++s2) {                                                          \
         const int row0 = 32 * kt + 16 * s2 + vrow_l;                                                              \
@@ -349,230 +365,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd64_kernel(Attn64Params p) 
   // finalize both blocks
 #pragma unroll
   for (int blk = 0; blk < 2; ++blk) {
-    const float lsum = blk ? lB : lA;
-    const float inv = 1.0f / (lsum + __shfl_xor(lsum, 32, 64));
-    const int row = q0 + 32 * blk + r;
-    if (row < S) {
-      bf16_t* optr = p.o + (long)b * p.o_batch_stride + (long)row * p.o_tok_stride + head * 64;
-#pragma unroll
-      for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const f32x16& ov = blk ? oB[dt] : oA[dt];
-          u32x2 w;
-          w[0] = pack_bf16x2(ov[4 * g + 0] * inv, ov[4 * g + 1] * inv);
-          w[1] = pack_bf16x2(ov[4 * g + 2] * inv, ov[4 * g + 3] * inv);
-          *(u32x2*)(optr + 32 * dt + 8 * g + 4 * h) = w;
-        }
-    }
-  }
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// Ping-pong form (default).  In the kernel above all 8 waves run the same phase at the same time: a matrix-only phase
-// (QK^T: the VALU idles) followed by a VALU-bound phase (softmax + PV: the matrix pipe idles) - measured 3900 cycles
-// per pair of tiles on a SIMD whose matrix pipe needs 2048 and whose VALU needs ~2300.  Here the two waves that share a
-// SIMD (wave w and w + 4) run half a tile apart: while waves 0-3 do QK^T(t), waves 4-7 do softmax + PV(t-1), then they
-// swap, so every half-step pairs one wave's matrix-only phase with its partner's VALU-heavy phase.
-//   half-step 2t   : waves 0-3  QK(t)          waves 4-7  softmax+PV(t-1)    all waves issue the LDS-DMA of K(t+1)
-//   half-step 2t+1 : waves 0-3  softmax+PV(t)  waves 4-7  QK(t)              all waves issue the LDS-DMA of V(t+1)
-// K(t) is read in half-steps 2t, 2t+1 and V(t) in 2t+1, 2t+2, so 2-deep K and V rings suffice: K(t+1) overwrites
-// K(t-1) (last read in 2t-1) and must land by the end of 2t+1; V(t+1) overwrites V(t-1) (last read in 2t) and must
-// land by the end of 2t+2.  Each wave issues one K piece then one V piece per tile and vmcnt retires in order, so
-// every half-step ends with  s_waitcnt vmcnt(1) ; s_barrier  (vmcnt(0) once nothing newer has been issued).
-template <bool NOMAX>
-__device__ __forceinline__ void a64_softmax_rt(f32x16 (&sc)[2], float& m, f32x16 (&o)[2], float& l,
-                                               bf16x8 (&pf)[2][2], bool first) {
-  if constexpr (NOMAX) {
-    a64_softmax<false, true>(sc, m, o, l, pf);
-  } else {
-    if (first) a64_softmax<true, false>(sc, m, o, l, pf);
-    else a64_softmax<false, false>(sc, m, o, l, pf);
-  }
-}
-
-template <int PRIO>
-__global__ __launch_bounds__(512, 2) void attn_fwd64pp_kernel(Attn64Params p) {
-  __shared__ __attribute__((aligned(16))) char lds[32768];  // K ring [2][64][128 B] then V ring [2][64][128 B]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int r = lane & 31, h = lane >> 5;
-  const int nwg = p.nqb * p.H * p.B;
-  const int id = xcd_remap(blockIdx.x, nwg);
-  const int qb = id % p.nqb;
-  const int head = (id / p.nqb) % p.H;
-  const int b = id / (p.nqb * p.H);
-  const int S = p.S;
-  const int grp = wave >> 2;
-
-  const int q0 = qb * 512 + wave * 64;
-  bf16x8 qfA[4], qfB[4];
-  {
-    const int ra = min(q0 + r, S - 1), rb = min(q0 + 32 + r, S - 1);
-    const bf16_t* pa = p.q + (long)b * p.batch_stride + (long)ra * p.tok_stride + head * 64;
-    const bf16_t* pb = p.q + (long)b * p.batch_stride + (long)rb * p.tok_stride + head * 64;
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      qfA[s] = *(const bf16x8*)(pa + 16 * s + 8 * h);
-      qfB[s] = *(const bf16x8*)(pb + 16 * s + 8 * h);
-    }
-  }
-  f32x16 oA[2], oB[2];
-  float mA = 0.f, mB = 0.f, lA = 0.f, lB = 0.f;
-  oA[0] = oA[1] = oB[0] = oB[1] = (f32x16)(0.f);
-
-  const int nt = (S + A64_KT - 1) / A64_KT;
-  const bf16_t* kbase = p.k + (long)b * p.batch_stride + head * 64;
-  const bf16_t* vbase = p.v + (long)b * p.batch_stride + head * 64;
-  // LDS-DMA: wave w writes the 1 KiB piece (rows 8w .. 8w+7) of each tile; slot (row, pos) receives chunk pos ^ f(row)
-  const int srow = wave * 8 + (lane >> 3), spos = lane & 7;
-  const int kchunk = (spos ^ ((srow >> 1) & 7)) << 4, vchunk = (spos ^ (((srow >> 1) & 1) << 2)) << 4;
-  auto stage_k = [&](int T) {
-    const int grow = min(T * A64_KT + srow, S - 1);
-    const char* src = (const char*)(kbase + (long)grow * p.tok_stride) + kchunk;
-    a64_glds16(src, lds + (T & 1) * 8192 + wave * 1024);
-  };
-  auto stage_v = [&](int T) {
-    const int grow = min(T * A64_KT + srow, S - 1);
-    const char* src = (const char*)(vbase + (long)grow * p.tok_stride) + vchunk;
-    a64_glds16(src, lds + 16384 + (T & 1) * 8192 + wave * 1024);
-  };
-  stage_k(0);
-  stage_v(0);
-
-  // bounded-score test (see header), under the flight of the first tiles
-  bool fast = false;
-  if (p.k2max) {
-    const float k2 = p.k2max[b * p.H + head];
-    float qa = 0.f, qb2 = 0.f;
-#pragma unroll
-    for (int s = 0; s < 4; ++s)
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const float fa = (float)qfA[s][e], fb = (float)qfB[s][e];
-        qa += fa * fa;
-        qb2 += fb * fb;
-      }
-    qa += __shfl_xor(qa, 32, 64);
-    qb2 += __shfl_xor(qb2, 32, 64);
-    fast = __all(fmaxf(qa, qb2) * k2 <= A64_BOUND2);
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
-
-  const int kswz = (r >> 1) & 7;
-  const int krow_off = r * 128;
-  const int gi = lane & 15, gg = (lane >> 4) & 1;
-  const int vrow_l = 4 * h + (gi >> 2);
-  const int vcol_l = 16 * gg + 4 * (gi & 3);
-  const int vch_l = vcol_l >> 3;
-  const int vin_l = (vcol_l & 7) * 2;
-  const int vswz = ((vrow_l >> 1) & 1) << 2;
-  const bool tail = (S & (A64_KT - 1)) != 0;
-  f32x16 scA[2], scB[2];
-
-#define PP_END(MORE)                                                 \
-  if (MORE) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");         \
-  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              \
-  __builtin_amdgcn_s_barrier();                                      \
-  asm volatile("" ::: "memory");
-
-#define PP_QK(T)                                                                                                  \
-  {                                                                                                               \
-    const char* kl = lds + ((T) & 1) * 8192 + krow_off;                                                           \
-    {                                                                                                             \
-      const int off = (h ^ kswz) << 4;                                                                            \
-      const bf16x8 a0 = *(const bf16x8*)(kl + off);                                                               \
-      const bf16x8 a1 = *(const bf16x8*)(kl + 32 * 128 + off);                                                    \
-      scA[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, qfA[0], (f32x16)(0.f), 0, 0, 0);                       \
-      scB[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, qfB[0], (f32x16)(0.f), 0, 0, 0);                       \
-      scA[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, qfA[0], (f32x16)(0.f), 0, 0, 0);                       \
-      scB[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, qfB[0], (f32x16)(0.f), 0, 0, 0);                       \
-    }                                                                                                             \
-    _Pragma("unroll") for (int s = 1; s < 4; ++s) {                                                               \
-      const int off = ((2 * s + h) ^ kswz) << 4;                                                                  \
-      const bf16x8 a0 = *(const bf16x8*)(kl + off);                                                               \
-      const bf16x8 a1 = *(const bf16x8*)(kl + 32 * 128 + off);                                                    \
-      scA[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, qfA[s], scA[0], 0, 0, 0);                              \
-      scB[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, qfB[s], scB[0], 0, 0, 0);                              \
-      if constexpr (PRIO == 3) __builtin_amdgcn_s_sleep(1);                                                       \
-      scA[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, qfA[s], scA[1], 0, 0, 0);                              \
-      scB[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, qfB[s], scB[1], 0, 0, 0);                              \
-      if constexpr (PRIO >= 3) __builtin_amdgcn_s_sleep(1);                                                       \
-    }                                                                                                             \
-    if (tail && (T) == nt - 1) { A64_MASK(T, scA) A64_MASK(T, scB) }                                              \
-  }
-
-#define PP_SMPV(T, NOMAX)                                                                                         \
-  {                                                                                                               \
-    bf16x8 pfA[2][2], pfB[2][2];                                                                                  \
-    const char* vl = lds + 16384 + ((T) & 1) * 8192;                                                              \
-    if constexpr (PRIO == 1 || PRIO >= 3) __builtin_amdgcn_s_setprio(1);                                                       \
-    if constexpr (PRIO == 2) __builtin_amdgcn_s_setprio(0);                                                       \
-    a64_softmax_rt<NOMAX>(scA, mA, oA, lA, pfA, (T) == 0);                                                        \
-    a64_softmax_rt<NOMAX>(scB, mB, oB, lB, pfB, (T) == 0);                                                        \
-    _Pragma("unroll") for (int kt = 0; kt < 2; ++kt)                                                              \
-    _Pragma("unroll") for (int s2 = 0; s2 < 2; ++s2) {                                                            \
-      const int row0 = 32 * kt + 16 * s2 + vrow_l;                                                                \
-      _Pragma("unroll") for (int dt = 0; dt < 2; ++dt) {                                                          \
-        const int ch = (4 * dt + vch_l) ^ vswz;                                                                   \
-        const char* a = vl + row0 * 128 + (ch << 4) + vin_l;                                                      \
-        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(                                               \
-            (__attribute__((address_space(3))) bf16x4*)LDS_PTR(a));                                               \
-        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(                                               \
-            (__attribute__((address_space(3))) bf16x4*)LDS_PTR(a + 8 * 128));                                     \
-        const bf16x8 vf = a64_cat4(lo, hi);                                                                       \
-        oA[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pfA[kt][s2], oA[dt], 0, 0, 0);                       \
-        oB[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pfB[kt][s2], oB[dt], 0, 0, 0);                       \
-      }                                                                                                           \
-    }                                                                                                             \
-    if constexpr (PRIO == 1 || PRIO >= 3) __builtin_amdgcn_s_setprio(0);                                                       \
-    if constexpr (PRIO == 2) __builtin_amdgcn_s_setprio(1);                                                       \
-  }
-
-#define PP_LOOP(NOMAX)                                                                                            \
-  if (grp == 0) {                                                                                                 \
-    for (int t = 0; t < nt; ++t) {                                                                                \
-      const bool more = t + 1 < nt;                                                                               \
-      A64_STAMP(t, 0)                                                                                             \
-      if (more) stage_k(t + 1);                                                                                   \
-      PP_QK(t)                                                                                                    \
-      A64_STAMP(t, 1)                                                                                             \
-      PP_END(more)                                                                                                \
-      A64_STAMP(t, 2)                                                                                             \
-      if (more) stage_v(t + 1);                                                                                   \
-      PP_SMPV(t, NOMAX)                                                                                           \
-      A64_STAMP(t, 3)                                                                                             \
-      PP_END(more)                                                                                                \
-      A64_STAMP(t, 4)                                                                                             \
-    }                                                                                                             \
-  } else {                                                                                                        \
-    for (int t = 0; t < nt; ++t) {                                                                                \
-      const bool more = t + 1 < nt;                                                                               \
-      A64_STAMP(t, 0)                                                                                             \
-      if (more) stage_k(t + 1);                                                                                   \
-      if (t > 0) PP_SMPV(t - 1, NOMAX)                                                                            \
-      A64_STAMP(t, 1)                                                                                             \
-      PP_END(more)                                                                                                \
-      A64_STAMP(t, 2)                                                                                             \
-      if (more) stage_v(t + 1);                                                                                   \
-      PP_QK(t)                                                                                                    \
-      A64_STAMP(t, 3)                                                                                             \
-      PP_END(more)                                                                                                \
-      A64_STAMP(t, 4)                                                                                                \
-    }                                                                                                             \
-    PP_SMPV(nt - 1, NOMAX)                                                                                        \
-  }
-
-  if (fast) {
-    PP_LOOP(true)
-  } else {
-    PP_LOOP(false)
-  }
-
-#pragma unroll
-  for (int blk = 0; blk < 2; ++blk) {
-    const float lsum = blk ? lB : lA;
+    const float lsum = blk ? lB + laccB[0] : lA + laccA[0];
     const float inv = 1.0f / (lsum + __shfl_xor(lsum, 32, 64));
     const int row = q0 + 32 * blk + r;
     if (row < S) {
@@ -669,26 +462,13 @@ int pi3_attention64_launch(const void* q, const void* k, const void* v, long tok
       p.k2max = scratch;
     }
   }
-  static int pingpong = -1;   // PI3_ATTN_PP: 1 = ping-pong kernel (experimental, measured slower: see its header)
-  if (pingpong < 0) {
-    const char* e = getenv("PI3_ATTN_PP");
-    pingpong = e ? atoi(e) : 0;
+  static int msum = -1;   // PI3_ATTN_MSUM: 1 = row sums on the matrix pipe in the bounded-score loop (A/B knob)
+  if (msum < 0) {
+    const char* e = getenv("PI3_ATTN_MSUM");
+    msum = e ? atoi(e) : 1;
   }
-  static int prio = -1;   // PI3_ATTN_PRIO: 1 = softmax+PV phase at s_setprio 1, 2 = QK phase at s_setprio 1 (A/B knob)
-  if (prio < 0) {
-    const char* e = getenv("PI3_ATTN_PRIO");
-    prio = e ? atoi(e) : 1;
-  }
-  if (nw == 8 && glds && pingpong && prio == 1)
-    hipLaunchKernelGGL(attn_fwd64pp_kernel<1>, dim3((unsigned)nwg), dim3(512), 0, stream, p);
-  else if (nw == 8 && glds && pingpong && prio == 3)
-    hipLaunchKernelGGL(attn_fwd64pp_kernel<3>, dim3((unsigned)nwg), dim3(512), 0, stream, p);
-  else if (nw == 8 && glds && pingpong && prio == 4)
-    hipLaunchKernelGGL(attn_fwd64pp_kernel<4>, dim3((unsigned)nwg), dim3(512), 0, stream, p);
-  else if (nw == 8 && glds && pingpong && prio == 2)
-    hipLaunchKernelGGL(attn_fwd64pp_kernel<2>, dim3((unsigned)nwg), dim3(512), 0, stream, p);
-  else if (nw == 8 && glds && pingpong)
-    hipLaunchKernelGGL(attn_fwd64pp_kernel<0>, dim3((unsigned)nwg), dim3(512), 0, stream, p);
+  if (nw == 8 && glds && msum)
+    hipLaunchKernelGGL((attn_fwd64_kernel<8, true, true>), dim3((unsigned)nwg), dim3(512), 0, stream, p);
   else if (nw == 8 && glds)
     hipLaunchKernelGGL((attn_fwd64_kernel<8, true>), dim3((unsigned)nwg), dim3(512), 0, stream, p);
   else if (nw == 8)

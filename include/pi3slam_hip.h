@@ -188,6 +188,14 @@ int pi3_sim3_compose_prefix(const double* T, double* G, int n, void* stream);
 int pi3_project_observations(const void* points, const float* poses, const float* intrinsics, int N, int K, int W,
                              int H, int max_after, float* uv, unsigned char* valid, void* stream);
 
+/* ---- next-tier: frame ingest = Resize + ToTensor of ChunkImageDataset._load_image_chunk
+ * (datasets/image_datasets.py:186-208), bit-exact with Pillow's 8-bit bilinear resample.  src u8 [N][H0][W0][3];
+ * x/y bounds int32 [out][2] = (first tap, taps), coefs int32 [out][ksize] (22-bit fixed point, built on the host);
+ * tmp u8 [N][H0][W1][3] workspace; dst f32 [N][3][H1][W1] in [0, 1]. */
+int pi3_ingest_frames(const unsigned char* src, int N, int H0, int W0, int H1, int W1, const int* xbounds,
+                      const int* xcoefs, int xksize, const int* ybounds, const int* ycoefs, int yksize,
+                      unsigned char* tmp, float* dst, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

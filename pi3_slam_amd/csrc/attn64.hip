@@ -17,7 +17,18 @@
 // and the max, the compare, the rescale branch and all 64 subtractions disappear.  pi3's q/k are LayerNorm'ed per head
 // (qk_norm, pi3/models/layers/attention.py:321-323), which is what makes the bound hold in practice; waves whose rows
 // exceed it take the online-max loop, so the result is the same softmax for every input.  max |k|^2 per (batch, head)
-// comes from a 25 us pre-pass over K (a64_knorm_kernel).
+// comes from a ~30 us pre-pass over K (a64_knorm_kernel).
+//
+// What the loop is bound by (s_memtime stamps, build with -DPI3_ATTN_STAMPS; 2.05 GHz under load): per tile and SIMD,
+// QK^T of the two resident waves = 32 MFMAs = 1012 cycles with the VALU idle, then softmax + PV = ~2400 cycles bound by
+// VALU issue (64 v_exp at 8 cycles, 32 cvt_pk, MFMA issue slots) with the matrix pipe half idle.  Tried and measured
+// slower than this kernel, so not kept: (a) ping-pong halves (waves 0-3 in QK^T while waves 4-7 are in softmax + PV,
+// two barriers per tile, with and without s_setprio / throttled QK^T): an in-order wave stalls on the busy matrix pipe
+// and its vector work stalls behind it, 4-6 % slower; (b) block B of each wave half a tile late, so that each phase has
+// independent matrix and vector work: V fragments are then read twice and hipcc's schedule leaves the MFMAs clustered,
+// 9 % slower.  Closing the gap to the matrix roof needs the 512-register one-wave-per-SIMD form with a hand-placed
+// instruction stream (cdna guide, attention section); the row-sum-on-MFMA and bounded-score steps above are what a
+// two-waves-per-SIMD compiler-scheduled loop could still give.
 #include "common.h"
 #include <stdlib.h>
 #include <stdio.h>
@@ -388,23 +399,29 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd64_kernel(Attn64Params p) 
 // like their bit patterns, so the reduction is an integer atomicMax)
 __global__ __launch_bounds__(256) void a64_knorm_kernel(const bf16_t* __restrict__ k, long tok_stride,
                                                         long batch_stride, int S, int H, float* __restrict__ out) {
+  // 8 lanes per key row (16 bytes each: one full 128-byte line per row and instruction), 32 rows per pass, 8 passes
   const int head = blockIdx.y, b = blockIdx.z;
-  const int row = blockIdx.x * 256 + threadIdx.x;
-  float s = 0.f;
-  if (row < S) {
-    const u32x4* src = (const u32x4*)(k + (long)b * batch_stride + (long)row * tok_stride + head * 64);
+  const int sub = threadIdx.x & 7, rl = threadIdx.x >> 3;
+  float best = 0.f;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const u32x4 w = src[i];
+  for (int pass = 0; pass < 8; ++pass) {
+    const int row = blockIdx.x * 256 + pass * 32 + rl;
+    float s = 0.f;
+    if (row < S) {
+      const u32x4 w = *(const u32x4*)(k + (long)b * batch_stride + (long)row * tok_stride + head * 64 + sub * 8);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const float lo = __uint_as_float(w[j] << 16), hi = __uint_as_float(w[j] & 0xffff0000u);
         s += lo * lo + hi * hi;
       }
     }
+    s += __shfl_xor(s, 1, 64);
+    s += __shfl_xor(s, 2, 64);
+    s += __shfl_xor(s, 4, 64);
+    best = fmaxf(best, s);
   }
-  s = wave_max(s);
-  if ((threadIdx.x & 63) == 0) atomicMax((unsigned*)&out[b * H + head], __float_as_uint(s));
+  best = wave_max(best);
+  if ((threadIdx.x & 63) == 0) atomicMax((unsigned*)&out[b * H + head], __float_as_uint(best));
 }
 
 // per-device ring of scratch slots for k2max (one process drives one stream per device; 16 launches may be in flight)

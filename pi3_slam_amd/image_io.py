@@ -51,6 +51,65 @@ def load_image(path: str, target_size: Tuple[int, int]) -> torch.Tensor:
     return torch.from_numpy(arr).permute(2, 0, 1).to(torch.float32).div(255.0)
 
 
+def resample_coeffs(in_size: int, out_size: int):
+    """Tap tables of Pillow's 8-bit bilinear resample (Resample.c: precompute_coeffs + normalize_coeffs_8bpc) for one
+    axis, vectorised: bounds int32 [out][2] = (first tap, tap count), coefs int32 [out][ksize] in 22-bit fixed point.
+    Every operation is an IEEE double operation in Pillow's order, so the tables equal Pillow's bit for bit."""
+    scale = in_size / out_size
+    filterscale = max(scale, 1.0)
+    support = 1.0 * filterscale
+    ksize = int(math.ceil(support)) * 2 + 1
+    ss = 1.0 / filterscale
+    center = 0.0 + (np.arange(out_size, dtype=np.float64) + 0.5) * scale
+    xmin = np.maximum(np.trunc(center - support + 0.5).astype(np.int64), 0)
+    xmax = np.minimum(np.trunc(center + support + 0.5).astype(np.int64), in_size) - xmin
+    taps = np.arange(ksize, dtype=np.int64)[None, :]
+    live = taps < xmax[:, None]
+    a = np.abs((taps + xmin[:, None] - center[:, None] + 0.5) * ss)
+    w = np.where(live & (a < 1.0), 1.0 - a, 0.0)
+    ww = np.zeros(out_size, dtype=np.float64)
+    for t in range(ksize):              # sequential accumulation like the C loop (summation order matters in fp64)
+        ww = ww + w[:, t]
+    w = np.where(ww[:, None] != 0.0, w / np.where(ww == 0.0, 1.0, ww)[:, None], w)
+    kk = np.trunc(0.5 + w * float(1 << 22)).astype(np.int32)   # weights of the triangle filter are never negative
+    kk[~live] = 0
+    bounds = np.stack([xmin, xmax], axis=1).astype(np.int32)
+    return bounds, kk
+
+
+_COEF_CACHE = {}
+
+
+def ingest_frames_device(frames_u8: torch.Tensor, target_size: Tuple[int, int]) -> torch.Tensor:
+    """Device form of Resize + ToTensor for a stack of decoded frames: uint8 [N,H0,W0,3] on the GPU -> float32
+    [N,3,H,W], bit-identical to load_image() on each frame (HIP kernels, csrc/ingest.hip)."""
+    from . import ops
+    H1, W1 = int(target_size[0]), int(target_size[1])
+    N, H0, W0 = frames_u8.shape[:3]
+    key = (H0, W0, H1, W1, str(frames_u8.device))
+    if key not in _COEF_CACHE:
+        xb, xk = resample_coeffs(W0, W1)
+        yb, yk = resample_coeffs(H0, H1)
+        _COEF_CACHE[key] = tuple(torch.from_numpy(np.ascontiguousarray(t)).to(frames_u8.device)
+                                 for t in (xb, xk, yb, yk))
+    xb, xk, yb, yk = _COEF_CACHE[key]
+    return ops.ingest_frames(frames_u8.contiguous(), H1, W1, xb, xk, yb, yk)
+
+
+def decode_frames_u8(paths: List[str]) -> torch.Tensor:
+    """PIL decode only (host): uint8 [N,H0,W0,3], pinned when a GPU is present so the upload can overlap compute."""
+    from PIL import Image
+    frames = []
+    for p in paths:
+        if not os.path.exists(p):
+            raise ValueError(f"Image file not found: {p}")
+        frames.append(np.array(Image.open(p).convert("RGB"), dtype=np.uint8))
+    if any(f.shape != frames[0].shape for f in frames):
+        raise ValueError("frames of one chunk must share a size for the batched device resize")
+    out = torch.from_numpy(np.stack(frames))
+    return out.pin_memory() if torch.cuda.is_available() else out
+
+
 class ChunkImageDataset(Dataset):
     def __init__(self, image_paths: List[str], chunk_length: int, overlap: int, target_size: Tuple[int, int],
                  device: str = "cpu", undistortion_maps=None):
@@ -67,4 +126,12 @@ class ChunkImageDataset(Dataset):
         s, e = self.chunk_indices[idx]
         paths = self.image_paths[s:e]
         chunk = torch.stack([load_image(p, self.target_size) for p in paths])
+        return {"chunk": chunk, "start_idx": torch.tensor([s]), "end_idx": torch.tensor([e]), "chunk_paths": [paths]}
+
+    def load_chunk_device(self, idx, device="cuda"):
+        """Same item as __getitem__ with the resize + ToTensor done on the GPU (frames cross PCIe as uint8)."""
+        s, e = self.chunk_indices[idx]
+        paths = self.image_paths[s:e]
+        frames = decode_frames_u8(paths).to(device, non_blocking=True)
+        chunk = ingest_frames_device(frames, self.target_size)
         return {"chunk": chunk, "start_idx": torch.tensor([s]), "end_idx": torch.tensor([e]), "chunk_paths": [paths]}

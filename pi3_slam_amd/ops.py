@@ -384,3 +384,21 @@ def project_observations(points: torch.Tensor, poses: torch.Tensor, intrinsics: 
                                       max_after, uv.data_ptr(), valid.data_ptr(), _L.stream_ptr())
     _L.check(rc, "pi3_project_observations")
     return uv, valid.bool()
+
+
+def ingest_frames(frames_u8: torch.Tensor, H1: int, W1: int, xb: torch.Tensor, xk: torch.Tensor, yb: torch.Tensor,
+                  yk: torch.Tensor) -> torch.Tensor:
+    """uint8 [N,H0,W0,3] -> float32 [N,3,H1,W1]; bounds / coefs are int32 device tensors from image_io.resample_coeffs."""
+    lib = _L.load()
+    assert frames_u8.dtype == torch.uint8 and frames_u8.is_contiguous() and frames_u8.shape[-1] == 3
+    N, H0, W0 = frames_u8.shape[:3]
+    for t in (xb, xk, yb, yk):
+        assert t.dtype == torch.int32 and t.is_contiguous()
+    assert xb.shape == (W1, 2) and yb.shape == (H1, 2) and xk.shape[0] == W1 and yk.shape[0] == H1
+    tmp = torch.empty(N, H0, W1, 3, device=frames_u8.device, dtype=torch.uint8)
+    dst = torch.empty(N, 3, H1, W1, device=frames_u8.device, dtype=torch.float32)
+    rc = lib.pi3_ingest_frames(frames_u8.data_ptr(), N, H0, W0, H1, W1, xb.data_ptr(), xk.data_ptr(), xk.shape[1],
+                               yb.data_ptr(), yk.data_ptr(), yk.shape[1], tmp.data_ptr(), dst.data_ptr(),
+                               _L.stream_ptr())
+    _L.check(rc, "pi3_ingest_frames")
+    return dst

@@ -116,3 +116,19 @@ def test_projection_oracle_matches_reference():
     assert np.array_equal(valid, g["valid"])
     np.testing.assert_allclose(uv, g["uv"], rtol=0, atol=1e-9)
     assert valid.any() and not valid.all()
+
+
+@pytest.mark.parametrize("name", ["ingest_down", "ingest_up", "ingest_mixed"])
+def test_ingest_oracle_and_host_tables_match_pillow_vectors(name):
+    """§8f rank 2: the resample restatement and the product's vectorised tap tables against Pillow-generated vectors."""
+    from oracle import ingest_ref
+    from pi3_slam_amd.image_io import resample_coeffs
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    H1, W1 = [int(v) for v in g["target"]]
+    got = np.stack([ingest_ref.resize_bilinear_u8(f, (H1, W1)) for f in g["frames"]])
+    assert np.array_equal(got, g["resized"])
+    assert np.array_equal(ingest_ref.ingest_frames(g["frames"], (H1, W1)), g["tensor"])
+    for n_in, n_out in [(g["frames"].shape[2], W1), (g["frames"].shape[1], H1), (752, 406), (480, 308), (7, 15)]:
+        b0, k0 = ingest_ref.resample_coeffs(n_in, n_out)
+        b1, k1 = resample_coeffs(n_in, n_out)
+        assert np.array_equal(b0, b1) and np.array_equal(k0, k1)

@@ -308,3 +308,39 @@ def test_project_observations_against_reference_vectors(dev):
     assert (vf != ov_).mean() < 1e-4
     both = vf & ov_
     assert np.abs(uvf.cpu().numpy()[both] - ouv[both]).max() < 1e-2
+
+
+@pytest.mark.parametrize("name", ["ingest_down", "ingest_up", "ingest_mixed"])
+def test_ingest_frames_bit_exact_with_pillow_vectors(dev, name):
+    """§8f rank 2: device Resize + ToTensor vs vectors produced by Pillow (what transforms.Resize runs on a PIL image)."""
+    from pi3_slam_amd.image_io import ingest_frames_device
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    H1, W1 = [int(v) for v in g["target"]]
+    out = ingest_frames_device(torch.from_numpy(g["frames"]).to(dev), (H1, W1))
+    torch.cuda.synchronize()
+    assert out.shape == (g["frames"].shape[0], 3, H1, W1) and out.dtype == torch.float32
+    assert np.array_equal(out.cpu().numpy(), g["tensor"])                # bit-exact, including the /255
+
+
+def test_ingest_full_size_against_oracle_and_dataset_item(dev, tmp_path):
+    """Full ingest size (EuRoC-like 480x752 -> 308x406, 100 frames would be 108 MB: 12 frames here) against the oracle,
+    and ChunkImageDataset.load_chunk_device against the host loader item on real PNG files."""
+    from PIL import Image
+    from oracle import ingest_ref
+    from pi3_slam_amd.image_io import ChunkImageDataset, ingest_frames_device, target_size_for
+    rng = np.random.default_rng(3)
+    frames = rng.integers(0, 256, (12, 480, 752, 3), dtype=np.uint8)
+    H1, W1 = target_size_for(752, 480)
+    out = ingest_frames_device(torch.from_numpy(frames).to(dev), (H1, W1)).cpu().numpy()
+    assert np.array_equal(out[:3], ingest_ref.ingest_frames(frames[:3], (H1, W1)))
+    assert np.array_equal(out[11], ingest_ref.ingest_frames(frames[11:], (H1, W1))[0])
+    paths = []
+    for i in range(5):
+        p = str(tmp_path / f"f{i:03d}.png")
+        Image.fromarray(frames[i, :120, :160]).save(p)
+        paths.append(p)
+    ds = ChunkImageDataset(paths, 4, 1, (56, 70))
+    for idx in range(len(ds)):
+        host, devi = ds[idx], ds.load_chunk_device(idx, dev)
+        assert torch.equal(host["chunk"], devi["chunk"].cpu())
+        assert host["chunk_paths"] == devi["chunk_paths"] and int(host["start_idx"]) == int(devi["start_idx"])

@@ -23,10 +23,10 @@ sys.path.insert(0, ROOT)
 
 CL, OV, H, W, KP = 100, 20, 308, 406, 200
 PEAK_BF16_DENSE_TFLOPS = 2500.0   # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md)
-# HBM-side bytes of ONE global-attention launch from rocprofv3 PMC passes (profiles/r01_attention_pmc.csv):
-# FETCH_SIZE 643 186 KB (x2: gfx950 reports half of a wide coalesced read stream) + WRITE_SIZE 128 600 KB.
+# HBM-side bytes of ONE global-attention launch from rocprofv3 PMC passes (profiles/r01c_attention_pmc.csv):
+# FETCH_SIZE 643 097 KB (x2: gfx950 reports half of a wide coalesced read stream) + WRITE_SIZE 128 601 KB.
 # Algorithmic bytes are 527 MB (q, k, v read once + o written); L2 hit rate 95.8 % on the K/V re-reads.
-ATTN_TRAFFIC_BYTES = (2 * 643186.25 + 128600.0) * 1024.0
+ATTN_TRAFFIC_BYTES = (2 * 643096.75 + 128600.9) * 1024.0
 
 
 def cpu_baseline(engine_cfg, n_frames: int = 4):
@@ -183,7 +183,7 @@ def main() -> None:
                        "algorithmic_tflop_per_chunk": fl["total"] / 1e12},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_DENSE_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_BF16_DENSE_TFLOPS, "traffic": ATTN_TRAFFIC_BYTES,
-                         "kernel": "attn_fwd64_kernel<8, true> + 25 us key-norm pre-pass (global attention, S=64300, 16 heads, d=64)",
+                         "kernel": "attn_fwd64_kernel<8, true, true> + key-norm pre-pass (global attention, S=64300, 16 heads, d=64)",
                          "launch_ms": attn_ms, "launches_timed": len(attn_events),
                          "end_to_end_tflops": fl["total"] * args.steps / dt / 1e12},
         }

@@ -397,31 +397,46 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd64_kernel(Attn64Params p) 
 
 // max over keys of |k|^2 per (batch, head) for the bounded-score test; out must be zeroed (non-negative floats order
 // like their bit patterns, so the reduction is an integer atomicMax)
+#define A64_KNORM_BLOCKS 24   // blocks per (batch, head): 24 * 16 heads = 384 blocks, one atomic each
 __global__ __launch_bounds__(256) void a64_knorm_kernel(const bf16_t* __restrict__ k, long tok_stride,
                                                         long batch_stride, int S, int H, float* __restrict__ out) {
-  // 8 lanes per key row (16 bytes each: one full 128-byte line per row and instruction), 32 rows per pass, 8 passes
+  // 8 lanes per key row (16 bytes each: one full 128-byte line per row and instruction), 32 rows per pass; the block
+  // strides over the sequence and issues ONE atomic (thousands of same-address atomics serialise in L2: the first
+  // version spent 160 of its 190 us there)
+  __shared__ float red[4];
   const int head = blockIdx.y, b = blockIdx.z;
   const int sub = threadIdx.x & 7, rl = threadIdx.x >> 3;
+  const bf16_t* base = k + (long)b * batch_stride + head * 64 + sub * 8;
   float best = 0.f;
+  for (int row0 = blockIdx.x * 128; row0 < S; row0 += A64_KNORM_BLOCKS * 128) {
+    float s[4];
 #pragma unroll
-  for (int pass = 0; pass < 8; ++pass) {
-    const int row = blockIdx.x * 256 + pass * 32 + rl;
-    float s = 0.f;
-    if (row < S) {
-      const u32x4 w = *(const u32x4*)(k + (long)b * batch_stride + (long)row * tok_stride + head * 64 + sub * 8);
+    for (int pass = 0; pass < 4; ++pass) {
+      const int row = row0 + pass * 32 + rl;
+      s[pass] = 0.f;
+      if (row < S) {
+        const u32x4 w = *(const u32x4*)(base + (long)row * tok_stride);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float lo = __uint_as_float(w[j] << 16), hi = __uint_as_float(w[j] & 0xffff0000u);
-        s += lo * lo + hi * hi;
+        for (int j = 0; j < 4; ++j) {
+          const float lo = __uint_as_float(w[j] << 16), hi = __uint_as_float(w[j] & 0xffff0000u);
+          s[pass] += lo * lo + hi * hi;
+        }
       }
     }
-    s += __shfl_xor(s, 1, 64);
-    s += __shfl_xor(s, 2, 64);
-    s += __shfl_xor(s, 4, 64);
-    best = fmaxf(best, s);
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+      float v = s[pass];
+      v += __shfl_xor(v, 1, 64);
+      v += __shfl_xor(v, 2, 64);
+      v += __shfl_xor(v, 4, 64);
+      best = fmaxf(best, v);
+    }
   }
   best = wave_max(best);
-  if ((threadIdx.x & 63) == 0) atomicMax((unsigned*)&out[b * H + head], __float_as_uint(best));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = best;
+  __syncthreads();
+  if (threadIdx.x == 0)
+    atomicMax((unsigned*)&out[b * H + head], __float_as_uint(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]))));
 }
 
 // per-device ring of scratch slots for k2max (one process drives one stream per device; 16 launches may be in flight)
@@ -474,7 +489,7 @@ int pi3_attention64_launch(const void* q, const void* k, const void* v, long tok
         pi3_set_error("attn_fwd64: hipMemsetAsync failed");
         return PI3_ERR_LAUNCH;
       }
-      hipLaunchKernelGGL(a64_knorm_kernel, dim3((S + 255) / 256, H, B), dim3(256), 0, stream, p.k, tok_stride,
+      hipLaunchKernelGGL(a64_knorm_kernel, dim3(A64_KNORM_BLOCKS, H, B), dim3(256), 0, stream, p.k, tok_stride,
                          batch_stride, S, H, scratch);
       p.k2max = scratch;
     }

@@ -1,0 +1,19 @@
+"""Summarise rocprofv3 --pmc passes: mean counter value per dispatch for kernels whose name contains a pattern.
+usage: python tools/pmc_summary.py <pattern> <min_ms> <dir> [<dir> ...]   (each dir = one rocprofv3 -d output)"""
+import csv, glob, os, sys
+from collections import defaultdict
+
+pat, min_ms, dirs = sys.argv[1], float(sys.argv[2]), sys.argv[3:]
+print("kernel,pass_dir,counter,dispatches,mean_value_per_dispatch,mean_ms")
+for d in dirs:
+    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        acc = defaultdict(list)
+        for r in csv.DictReader(open(f)):
+            if pat not in r["Kernel_Name"]:
+                continue
+            ms = (float(r["End_Timestamp"]) - float(r["Start_Timestamp"])) / 1e6
+            if ms < min_ms:
+                continue
+            acc[(r["Kernel_Name"], r["Counter_Name"])].append((float(r["Counter_Value"]), ms))
+        for (k, c), v in sorted(acc.items()):
+            print(f'"{k}",{os.path.basename(d.rstrip("/"))},{c},{len(v)},{sum(x[0] for x in v) / len(v)},{sum(x[1] for x in v) / len(v)}')

@@ -1,9 +1,10 @@
-// Attention forward, 64 query rows per wave (two 32-row blocks A/B), 256 query rows per 256-thread workgroup.
+// Attention forward for long sequences: 64 query rows per wave (two 32-row blocks A/B), 8 waves = 512 query rows per
+// workgroup (PI3_ATTN_NW=4: 256).
 //
 // Same math and data flow as attn.hip (see its header: S^T = K.Q^T with the query on the lane, the bf16-converted
-// accumulators are the B operand of O^T += V^T.P^T, -m folded into the first MFMA's C operand, deferred rescale), but
-// every K fragment (ds_read_b128) and every V^T fragment (ds_read_b64_tr_b16) feeds TWO MFMAs, one per query block:
-//   * K/V global->LDS traffic per FLOP halves (256 instead of 128 query rows share a staged tile): the ablation of
+// accumulators are the B operand of O^T += V^T.P^T, deferred rescale of the online max), but every K fragment
+// (ds_read_b128) and every V^T fragment (ds_read_b64_tr_b16) feeds TWO MFMAs, one per query block:
+//   * K/V global->LDS traffic per FLOP drops 4x (512 instead of 128 query rows share a staged tile): the ablation of
 //     attn.hip shows 19 % of its time is the staging path (7 TB/s of L2/MALL reads at S = 64 300);
 //   * LDS fragment reads per FLOP halve;
 //   * the two blocks are independent, so one block's softmax (VALU) overlaps the other block's MFMAs inside a wave.

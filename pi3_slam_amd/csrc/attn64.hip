@@ -27,9 +27,14 @@
 // two barriers per tile, with and without s_setprio / throttled QK^T): an in-order wave stalls on the busy matrix pipe
 // and its vector work stalls behind it, 4-6 % slower; (b) block B of each wave half a tile late, so that each phase has
 // independent matrix and vector work: V fragments are then read twice and hipcc's schedule leaves the MFMAs clustered,
-// 9 % slower.  Closing the gap to the matrix roof needs the 512-register one-wave-per-SIMD form with a hand-placed
-// instruction stream (cdna guide, attention section); the row-sum-on-MFMA and bounded-score steps above are what a
-// two-waves-per-SIMD compiler-scheduled loop could still give.
+// 9 % slower; (c) one wave per SIMD with 128 rows per wave, two block groups half a tile apart, chunks of
+// {MFMA, 2 exp, MFMA, 2 exp, 2 cvt, row-sum MFMA} pinned with sched_barrier and the QK^T MFMAs in asm so that the scores
+// stay in arch VGPRs (hipcc otherwise puts every MFMA result of a 512-register kernel in the accumulator file and the
+// softmax pays 400 v_accvgpr copies per tile): 123 cycles per chunk against 64 of matrix pipe, 8 % slower.
+// tools/micro/valu_rates.hip gives the reason: ONE wave's stream issues a v_exp every 8 cycles and a v_cvt_pk every 6
+// (two waves on a SIMD together: 5.3 and 3.0), so a single in-order stream cannot feed the matrix pipe at d = 64, and two
+// streams per SIMD is what the 64-row register budget allows.  The row-sum-on-MFMA and bounded-score steps above are
+// what this form could still give.
 #include "common.h"
 #include <stdlib.h>
 #include <stdio.h>

@@ -511,6 +511,8 @@ int pi3_attention64_launch(const void* q, const void* k, const void* v, long tok
     hipLaunchKernelGGL((attn_fwd64_kernel<8, true>), dim3((unsigned)nwg), dim3(512), 0, stream, p);
   else if (nw == 8)
     hipLaunchKernelGGL(attn_fwd64_kernel<8>, dim3((unsigned)nwg), dim3(512), 0, stream, p);
+  else if (glds && msum)   // 4 waves: two independent workgroups per CU, the two waves of a SIMD drift out of phase
+    hipLaunchKernelGGL((attn_fwd64_kernel<4, true, true>), dim3((unsigned)nwg), dim3(256), 0, stream, p);
   else
     hipLaunchKernelGGL(attn_fwd64_kernel<4>, dim3((unsigned)nwg), dim3(256), 0, stream, p);
 #ifdef PI3_ATTN_STAMPS

@@ -45,9 +45,9 @@ template <int MODE>
 void run(const char* name, int n_instr, int threads) {
   float* out; unsigned long long* cyc; unsigned long long h;
   hipMalloc(&out, 1024 * 1024 * 4); hipMalloc(&cyc, 8);
-  const int iters = 4000;
-  hipLaunchKernelGGL(k<MODE>, dim3(256), dim3(threads), 0, 0, out, cyc, iters);
-  hipLaunchKernelGGL(k<MODE>, dim3(256), dim3(threads), 0, 0, out, cyc, iters);
+  const int iters = 20000;
+  for (int rep = 0; rep < 30; ++rep)   // the first launches run while the clocks ramp: keep the last one
+    hipLaunchKernelGGL(k<MODE>, dim3(256), dim3(threads), 0, 0, out, cyc, iters);
   hipDeviceSynchronize();
   hipMemcpy(&h, cyc, 8, hipMemcpyDeviceToHost);
   printf("%-34s waves/SIMD=%d  %.2f cycles per instruction per wave (%.2f per SIMD-instruction)\n", name, threads / 256,
@@ -55,7 +55,7 @@ void run(const char* name, int n_instr, int threads) {
   hipFree(out); hipFree(cyc);
 }
 int main() {
-  for (int th : {256, 512}) {
+  for (int th : {256, 512, 256, 512}) {
     run<0>("v_exp dependent chain", 16, th);
     run<1>("v_exp independent", 16, th);
     run<2>("v_add independent", 16, th);

@@ -73,6 +73,11 @@ def main() -> None:
             dist.init_process_group("nccl", device_id=dev)   # RCCL over xGMI
         else:
             dist.init_process_group(backend)
+        # build the communicator now (untimed set-up, like weight initialisation): the first collective of a process
+        # group pays the RCCL ring / xGMI topology discovery, which must not land in a timed step when --warmup is 0
+        _w = torch.zeros(1, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(_w)
+        dist.all_gather([torch.empty_like(_w) for _ in range(world)], _w)
 
     from pi3_slam_amd import ops
     from pi3_slam_amd.alignment import create_view_graph_matches, estimate_sim3

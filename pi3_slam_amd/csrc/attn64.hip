@@ -13,8 +13,9 @@
 // Bounded-score path (NOMAX).  The loop is VALU-ISSUE bound, not MFMA bound: per 64x64 tile a wave issues 32 MFMAs
 // (1024 matrix-pipe cycles) but ~1900 cycles of single-issue vector work (64 v_exp, 64 v_sub, 64 adds, 40 max, 32 cvt).
 // The running maximum exists only to keep exp2 in range.  By Cauchy-Schwarz |q.k| <= |q| |k|, and softmax is invariant
-// to the subtracted constant, so when  |q_row| * max_keys |k|  <= 60  (exp2 domain; q carries scale*log2e) for every
-// row of a wave, that wave uses m = 0: p = exp2(s) lies in [2^-60, 2^60], nothing overflows or underflows in fp32 / bf16,
+// to the subtracted constant, so when  |q_row| * max_keys |k|  <= 90  (exp2 domain; q carries scale*log2e) for every
+// row of a wave, that wave uses m = 0: p = exp2(s) lies in [2^-90, 2^90], nothing overflows or underflows in fp32 / bf16
+// (8 exponent bits both; row sums stay below 2^106),
 // and the max, the compare, the rescale branch and all 64 subtractions disappear.  pi3's q/k are LayerNorm'ed per head
 // (qk_norm, pi3/models/layers/attention.py:321-323), which is what makes the bound hold in practice; waves whose rows
 // exceed it take the online-max loop, so the result is the same softmax for every input.  max |k|^2 per (batch, head)
@@ -47,7 +48,7 @@ struct Attn64Params {
   const float* k2max;   // [B][H] max over keys of |k|^2, or null (always online max)
   unsigned long long* dbg;   // -DPI3_ATTN_STAMPS builds only: s_memtime stamps of workgroup 0
 };
-#define A64_BOUND2 3600.0f   // (60)^2
+#define A64_BOUND2 8100.0f   // (90)^2: p in [2^-90, 2^90], l <= 2^106, O <= 2^110: inside fp32 / bf16 range
 #ifdef PI3_ATTN_STAMPS
 __device__ __forceinline__ unsigned long long a64_stamp() {
   unsigned long long t;

@@ -133,7 +133,12 @@ __device__ __forceinline__ void g2_epilogue_lds(const GemmParams& p, f32x4 (&acc
 }
 
 // NOEPI: timing-only ablation (no output) to separate the main loop from the epilogue.
-template <bool OUT_BF16, int ACT, bool NOEPI = false>
+// STAG: waves 4-7 (the second wave of every SIMD) run one barrier behind waves 0-3, and every phase has a second
+// barrier between its LDS reads / LDS-DMA issues and its MFMAs: while one wave of a SIMD is in its MFMA segment the
+// other is in its load segment, instead of both loading and then both competing for the matrix pipe.  The staging
+// schedule already keeps every restage >= 2 phases after the last read of the region and reads a staged tile a phase
+// after the vmcnt wait that retires it, which is what the half-phase lag of the second group needs.
+template <bool OUT_BF16, int ACT, bool NOEPI = false, bool STAG = false>
 __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -215,7 +220,11 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
   asm volatile("" ::: "memory");               \
   __builtin_amdgcn_s_barrier();                \
   asm volatile("" ::: "memory");
+#define PHASE_MID() if constexpr (STAG) { PHASE_END() }
 
+  if constexpr (STAG) {
+    if (wm == 1) { PHASE_END() }
+  }
   for (int u = 0; u < nk; ++u) {
     const char* bp = smem + (u & 1) * G2_BUF;
     const bool pre1 = (u + 1 < nk), pre2 = (u + 2 < nk);
@@ -223,16 +232,19 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
     READ_W(bp, 0)
     READ_A(bp, 0)
     if (pre1) STAGE_A(u + 1, 0);
+    PHASE_MID()
     MFMA_Q(0, 0)
     PHASE_END()
     // ---- phase b
     READ_W(bp, 1)
     if (pre1) STAGE_A(u + 1, 1);
+    PHASE_MID()
     MFMA_Q(0, 1)
     PHASE_END()
     // ---- phase c
     READ_A(bp, 1)
     if (pre2) STAGE_W(u + 2, 0);
+    PHASE_MID()
     MFMA_Q(1, 1)
     PHASE_END()
     // ---- phase d
@@ -242,8 +254,12 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
+    PHASE_MID()
     MFMA_Q(1, 0)
     PHASE_END()
+  }
+  if constexpr (STAG) {
+    if (wm == 0) { PHASE_END() }   // barrier counts match again; nobody touches the epilogue LDS before everyone is out
   }
 
   // ---- epilogue
@@ -263,10 +279,10 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
   }
 }
 
-template <bool OUT_BF16, int ACT, bool NOEPI = false>
+template <bool OUT_BF16, int ACT, bool NOEPI = false, bool STAG = false>
 static int launch256(const GemmParams& p, hipStream_t stream) {
   const int nbm = (p.M + G2_BM - 1) / G2_BM, nbn = p.N / G2_BN;
-  auto kern = gemm256_kernel<OUT_BF16, ACT, NOEPI>;
+  auto kern = gemm256_kernel<OUT_BF16, ACT, NOEPI, STAG>;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS_TOTAL);
@@ -285,7 +301,17 @@ int pi3_gemm256_try(const GemmParams& p, int out_dtype, int act, hipStream_t str
     const char* e = getenv("PI3_GEMM_ABL");
     abl = e ? atoi(e) : 0;
   }
-  if (abl == 1) return launch256<true, 0, true>(p, stream);
+  static int stag = -1;   // PI3_GEMM_STAG: 0 = all eight waves in lockstep (A/B knob)
+  if (stag < 0) {
+    const char* e = getenv("PI3_GEMM_STAG");
+    stag = e ? atoi(e) : 1;
+  }
+  if (abl == 1) return stag ? launch256<true, 0, true, true>(p, stream) : launch256<true, 0, true>(p, stream);
+  if (stag) {
+    if (out_dtype == 0 && act == 0) return launch256<true, 0, false, true>(p, stream);
+    if (out_dtype == 0 && act == 1) return launch256<true, 1, false, true>(p, stream);
+    if (out_dtype == 1 && act == 0) return launch256<false, 0, false, true>(p, stream);
+  }
   if (out_dtype == 0 && act == 0) return launch256<true, 0>(p, stream);
   if (out_dtype == 0 && act == 1) return launch256<true, 1>(p, stream);
   if (out_dtype == 1 && act == 0) return launch256<false, 0>(p, stream);

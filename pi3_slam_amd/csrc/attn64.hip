@@ -31,7 +31,10 @@
 // 9 % slower; (c) one wave per SIMD with 128 rows per wave, two block groups half a tile apart, chunks of
 // {MFMA, 2 exp, MFMA, 2 exp, 2 cvt, row-sum MFMA} pinned with sched_barrier and the QK^T MFMAs in asm so that the scores
 // stay in arch VGPRs (hipcc otherwise puts every MFMA result of a 512-register kernel in the accumulator file and the
-// softmax pays 400 v_accvgpr copies per tile): 123 cycles per chunk against 64 of matrix pipe, 8 % slower.
+// softmax pays 400 v_accvgpr copies per tile): 123 cycles per chunk against 64 of matrix pipe, 8 % slower; (d) the
+// gemm256-style stagger with pure segments (M: PV(t) + QK(t+1), 32 MFMAs; V: softmax(t+1); waves 4-7 one barrier behind,
+// 3-deep rings): the lone wave in M exposes its LDS fragment latency (1800 cycles for 1024 of matrix pipe) and the
+// younger wave's vector segment doubles under the partner's priority, 20 % slower.
 // tools/micro/valu_rates.hip gives the reason: ONE wave's stream issues a v_exp every 8 cycles and a v_cvt_pk every 6
 // (two waves on a SIMD together: 5.3 and 3.0), so a single in-order stream cannot feed the matrix pipe at d = 64, and two
 // streams per SIMD is what the 64-row register budget allows.  The row-sum-on-MFMA and bounded-score steps above are

@@ -285,3 +285,25 @@ def test_attention_bounded_score_and_online_max_paths(dev):
     assert (out.float()[700, 64:] - ref[700, 64:]).abs().max() < 2e-2      # row dominated by the 2^70 term
     assert (out.float()[:64, :64] - ref[:64, :64]).abs().max() < 2e-2
     assert torch.isfinite(out.float()).all()
+
+
+@pytest.mark.parametrize("M,N,K,reps", [(5000, 256, 4096, 40), (2049, 1024, 1024, 40), (1024, 256, 64, 60), (33000, 512, 192, 20)])
+def test_gemm256_repeatable_bitwise(dev, M, N, K, reps):
+    """Race screen for the staggered-wave 256x256 kernel (waves 4-7 one barrier behind waves 0-3, counted vmcnt, raw
+    barriers): repeated launches on the same operands must agree bit for bit, bf16 and fp32+residual forms."""
+    from pi3_slam_amd import ops
+    a = torch.randn(M, K, device=dev).bfloat16()
+    w = (torch.randn(N, K, device=dev) / math.sqrt(K)).bfloat16()
+    bias, gamma, x0 = torch.randn(N, device=dev), torch.rand(N, device=dev), torch.randn(M, N, device=dev)
+    first16 = first32 = None
+    for _ in range(reps):
+        o16 = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+        ops.gemm(a, w, o16, bias=bias, act=ops.ACT_GELU)
+        x = x0.clone()
+        ops.gemm(a, w, x, bias=bias, gamma=gamma, resid=x)
+        if first16 is None:
+            first16, first32 = o16, x
+            ref = x0 + gamma * (a.float() @ w.float().T + bias)
+            assert rel(x, ref)[0] < 1e-4
+        else:
+            assert torch.equal(o16, first16) and torch.equal(x, first32)

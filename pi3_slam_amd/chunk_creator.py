@@ -22,7 +22,7 @@ from torch.utils.data import DataLoader
 
 from . import ops
 from .engine import Pi3Engine
-from .image_io import ChunkImageDataset, calculate_target_size
+from .image_io import ChunkImageDataset, calculate_target_size, ingest_frames_device
 from .keypoints import create_keypoint_extractor
 from .weights import Pi3Config
 
@@ -46,6 +46,7 @@ class OfflineCreatorConfig:
     # --- additions (the reference hard-codes "Ruicheng/moge-2-vits-normal" and an unseeded device randperm)
     moge_model_path: Optional[str] = None   # local MoGe-2 model.pt, or "recipe" for synthetic weights
     keypoint_seed: Optional[int] = 0
+    device_resize: bool = False             # loader workers only decode; Resize + ToTensor run on the GPU (bit-identical)
 
 
 def _uv_tables(H: int, W: int, device) -> Tuple[torch.Tensor, torch.Tensor]:
@@ -226,7 +227,8 @@ class OfflineChunkCreator:
             raise ValueError("image_paths is empty")
         self.target_size = calculate_target_size(image_paths[0], pixel_limit=255000 // 2)
         print(f"Target size: {self.target_size}")
-        dataset = ChunkImageDataset(image_paths, self.config.chunk_length, self.config.overlap, self.target_size)
+        dataset = ChunkImageDataset(image_paths, self.config.chunk_length, self.config.overlap, self.target_size,
+                                    decode_only=self.config.device_resize)
         nw = self.config.num_loader_workers
         loader = DataLoader(dataset, batch_size=1, shuffle=False, num_workers=nw, pin_memory=self.config.pin_memory,
                             persistent_workers=nw > 0, prefetch_factor=1 if nw > 0 else None)
@@ -237,7 +239,11 @@ class OfflineChunkCreator:
         for chunk_idx, batch in enumerate(loader):
             start_idx = int(batch["start_idx"].item())
             end_idx = int(batch["end_idx"].item())
-            chunk_images = batch["chunk"]
+            if self.config.device_resize:
+                frames = batch["chunk_u8"][0].to(self.device, non_blocking=True)
+                chunk_images = ingest_frames_device(frames, self.target_size)[None]
+            else:
+                chunk_images = batch["chunk"]
             chunk_paths = batch["chunk_paths"][0]
             print(f"📦 Chunk {chunk_idx + 1}/{len(dataset)}: frames {start_idx + 1}-{end_idx}")
             chunk_result = self._process_single_chunk(chunk_images, chunk_paths)

@@ -96,8 +96,9 @@ def ingest_frames_device(frames_u8: torch.Tensor, target_size: Tuple[int, int]) 
     return ops.ingest_frames(frames_u8.contiguous(), H1, W1, xb, xk, yb, yk)
 
 
-def decode_frames_u8(paths: List[str]) -> torch.Tensor:
-    """PIL decode only (host): uint8 [N,H0,W0,3], pinned when a GPU is present so the upload can overlap compute."""
+def decode_frames_u8(paths: List[str], pin: bool = True) -> torch.Tensor:
+    """PIL decode only (host): uint8 [N,H0,W0,3], pinned when a GPU is present so the upload can overlap compute
+    (pin=False inside DataLoader workers: the loader's own pin_memory thread does it)."""
     from PIL import Image
     frames = []
     for p in paths:
@@ -107,16 +108,17 @@ def decode_frames_u8(paths: List[str]) -> torch.Tensor:
     if any(f.shape != frames[0].shape for f in frames):
         raise ValueError("frames of one chunk must share a size for the batched device resize")
     out = torch.from_numpy(np.stack(frames))
-    return out.pin_memory() if torch.cuda.is_available() else out
+    return out.pin_memory() if (pin and torch.cuda.is_available()) else out
 
 
 class ChunkImageDataset(Dataset):
     def __init__(self, image_paths: List[str], chunk_length: int, overlap: int, target_size: Tuple[int, int],
-                 device: str = "cpu", undistortion_maps=None):
+                 device: str = "cpu", undistortion_maps=None, decode_only: bool = False):
         if undistortion_maps is not None:
             raise NotImplementedError("undistortion maps are out of scope for this build")
         self.image_paths, self.chunk_length, self.overlap = image_paths, chunk_length, overlap
         self.target_size = target_size
+        self.decode_only = decode_only   # items carry the decoded uint8 frames ("chunk_u8"); the resize runs on the GPU
         self.chunk_indices = chunk_indices(len(image_paths), chunk_length, overlap)
 
     def __len__(self):
@@ -125,6 +127,9 @@ class ChunkImageDataset(Dataset):
     def __getitem__(self, idx):
         s, e = self.chunk_indices[idx]
         paths = self.image_paths[s:e]
+        if self.decode_only:
+            return {"chunk_u8": decode_frames_u8(paths, pin=False), "start_idx": torch.tensor([s]),
+                    "end_idx": torch.tensor([e]), "chunk_paths": [paths]}
         chunk = torch.stack([load_image(p, self.target_size) for p in paths])
         return {"chunk": chunk, "start_idx": torch.tensor([s]), "end_idx": torch.tensor([e]), "chunk_paths": [paths]}
 

@@ -65,3 +65,29 @@ def test_process_and_save_then_reconstruct(tmp_path, built_lib):
     assert len(lines) == 1 + 32                                                  # 40 poses, 8 duplicates dropped
     vals = np.array([[float(v) for v in l.split()] for l in lines[1:]])
     assert np.isfinite(vals).all() and np.allclose(np.linalg.norm(vals[:, 4:8], axis=1), 1.0, atol=1e-5)
+
+
+def test_device_resize_pipeline_is_identical_to_host_resize(tmp_path, built_lib):
+    """§8f rank 2 wired into process_and_save: loader workers only decode, Resize + ToTensor run on the GPU.  The ingest
+    is bit-identical to PIL + ToTensor, so every stored tensor of every chunk must equal the host-resize run."""
+    from pi3_slam_amd.chunk_creator import OfflineChunkCreator, OfflineCreatorConfig
+    from pi3_slam_amd.engine import Pi3Engine
+    from pi3_slam_amd.weights import Pi3Config
+    frames = tmp_path / "frames"
+    frames.mkdir()
+    paths = _write_frames(str(frames))[:12]
+    small = Pi3Config(dim=128, enc_depth=1, dec_depth=2, head_depth=1, cam_dim=128, pos_grid=5)
+    engine = Pi3Engine(small, "cuda:0")
+    saved = {}
+    for flag, workers in ((False, 0), (True, 2)):
+        out = tmp_path / f"out_{int(flag)}"
+        cfg = OfflineCreatorConfig(model_path="recipe", output_dir=str(out), chunk_length=8, overlap=2,
+                                   do_metric_depth=False, keypoint_type="grid", max_num_keypoints=100,
+                                   num_loader_workers=workers, pin_memory=False, device_resize=flag)
+        saved[flag] = OfflineChunkCreator(cfg, model=engine, moge_model=None).process_and_save(paths)
+    assert len(saved[False]) == len(saved[True]) == 2
+    for a, b in zip(saved[False], saved[True]):
+        ca = torch.load(a, map_location="cpu", weights_only=False)
+        cb = torch.load(b, map_location="cpu", weights_only=False)
+        for k in ("points", "local_points", "conf", "masks", "keypoints", "colors", "camera_poses", "intrinsics"):
+            assert torch.equal(ca[k], cb[k]), k

@@ -196,6 +196,16 @@ int pi3_ingest_frames(const unsigned char* src, int N, int H0, int W0, int H1, i
                       const int* xcoefs, int xksize, const int* ybounds, const int* ycoefs, int yksize,
                       unsigned char* tmp, float* dst, void* stream);
 
+/* ---- next-tier: undistortion of the input frames (pi3/utils/undistortion.py:95-138, :157-177).
+ * pi3_undistort_maps: params is a HOST pointer to 16 doubles (undistorted camera f, aspect, cx, cy, skew; distorted
+ * camera f, aspect, cx, cy, skew; radial k1..k4; tangential t1, t2); model 0 PINHOLE, 1 PINHOLE_RADIAL_TANGENTIAL,
+ * 2 FISHEYE, 3 DIVISION_UNDISTORTION; map_x / map_y f32 [H][W] device (source pixel of every target pixel).
+ * pi3_remap_bilinear_u8: cv2.remap(INTER_LINEAR, BORDER_CONSTANT 0) of src u8 [N][H0][W0][3] + ToTensor ->
+ * dst f32 [N][3][H][W]. */
+int pi3_undistort_maps(const double* params, int model, int H, int W, float* map_x, float* map_y, void* stream);
+int pi3_remap_bilinear_u8(const unsigned char* src, int N, int H0, int W0, const float* map_x, const float* map_y,
+                          int H, int W, float* dst, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

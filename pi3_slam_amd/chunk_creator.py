@@ -23,6 +23,7 @@ from torch.utils.data import DataLoader
 from . import ops
 from .engine import Pi3Engine
 from .image_io import ChunkImageDataset, calculate_target_size, ingest_frames_device
+from .undistortion import create_undistortion_maps
 from .keypoints import create_keypoint_extractor
 from .weights import Pi3Config
 
@@ -106,8 +107,21 @@ class OfflineChunkCreator:
                 self.keypoint_extractor = None
 
         self.target_size: Optional[Tuple[int, int]] = None
+        # Undistortion maps (optional), offline_chunk_creator.py:98-112: built and applied on the device
+        self.undistortion_maps = None
         if getattr(self.config, "cam_dist_path", None):
-            print("⚠️  Undistortion maps are out of scope for this build; proceeding without undistortion")
+            try:
+                if os.path.exists(self.config.cam_dist_path):
+                    print(f"🔧 Creating undistortion maps from: {self.config.cam_dist_path}")
+                    self.undistortion_maps = create_undistortion_maps(self.config.cam_dist_path, str(self.device))
+                    if self.undistortion_maps is not None:
+                        print("✅ Undistortion maps ready; images will be undistorted before Pi3 inference")
+                    else:
+                        print("⚠️  Failed to create undistortion maps; proceeding without undistortion")
+                else:
+                    print(f"⚠️  Calibration file not found: {self.config.cam_dist_path}")
+            except Exception as e:  # noqa: BLE001
+                print(f"⚠️  Undistortion map creation failed: {e}")
 
     # ------------------------------------------------------------------ device steps (same names as the reference)
     @staticmethod
@@ -227,8 +241,9 @@ class OfflineChunkCreator:
             raise ValueError("image_paths is empty")
         self.target_size = calculate_target_size(image_paths[0], pixel_limit=255000 // 2)
         print(f"Target size: {self.target_size}")
+        undist = self.undistortion_maps
         dataset = ChunkImageDataset(image_paths, self.config.chunk_length, self.config.overlap, self.target_size,
-                                    decode_only=self.config.device_resize)
+                                    decode_only=self.config.device_resize or undist is not None)
         nw = self.config.num_loader_workers
         loader = DataLoader(dataset, batch_size=1, shuffle=False, num_workers=nw, pin_memory=self.config.pin_memory,
                             persistent_workers=nw > 0, prefetch_factor=1 if nw > 0 else None)
@@ -239,7 +254,10 @@ class OfflineChunkCreator:
         for chunk_idx, batch in enumerate(loader):
             start_idx = int(batch["start_idx"].item())
             end_idx = int(batch["end_idx"].item())
-            if self.config.device_resize:
+            if undist is not None:     # remap + ToTensor on the GPU (datasets/image_datasets.py:192-199)
+                frames = batch["chunk_u8"][0].to(self.device, non_blocking=True)
+                chunk_images = undist.undistort_frames_device(frames, self.target_size)[None]
+            elif self.config.device_resize:
                 frames = batch["chunk_u8"][0].to(self.device, non_blocking=True)
                 chunk_images = ingest_frames_device(frames, self.target_size)[None]
             else:

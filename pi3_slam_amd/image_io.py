@@ -1,7 +1,7 @@
 """Frame ingest: mirror of utils/image_utils.py:13-50 (calculate_target_size) and datasets/image_datasets.py:13-210
 (ChunkImageDataset) for image files.  PIL decode + bilinear resize is what torchvision's Resize does on a PIL image
 (transforms.Resize(size) -> img.resize((W, H), BILINEAR)); ToTensor = uint8 HWC -> float CHW / 255.
-Video / torchcodec / undistortion inputs are out of scope."""
+Video / torchcodec inputs are out of scope; undistortion: pi3_slam_amd/undistortion.py."""
 from __future__ import annotations
 
 import math
@@ -114,8 +114,9 @@ def decode_frames_u8(paths: List[str], pin: bool = True) -> torch.Tensor:
 class ChunkImageDataset(Dataset):
     def __init__(self, image_paths: List[str], chunk_length: int, overlap: int, target_size: Tuple[int, int],
                  device: str = "cpu", undistortion_maps=None, decode_only: bool = False):
-        if undistortion_maps is not None:
-            raise NotImplementedError("undistortion maps are out of scope for this build")
+        if undistortion_maps is not None and not decode_only:
+            raise NotImplementedError("undistortion runs on the GPU: build the dataset with decode_only=True and call "
+                                      "UndistortionMaps.undistort_frames_device (pi3_slam_amd/undistortion.py)")
         self.image_paths, self.chunk_length, self.overlap = image_paths, chunk_length, overlap
         self.target_size = target_size
         self.decode_only = decode_only   # items carry the decoded uint8 frames ("chunk_u8"); the resize runs on the GPU

@@ -50,6 +50,8 @@ SIGNATURES = {
     "pi3_sim3_compose_prefix": [_vp, _vp, _i, _vp],
     "pi3_project_observations": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp],
     "pi3_ingest_frames": [_vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp],
+    "pi3_undistort_maps": [_vp, _i, _i, _i, _vp, _vp, _vp],
+    "pi3_remap_bilinear_u8": [_vp, _i, _i, _i, _vp, _vp, _i, _i, _vp, _vp],
 }
 
 _lib: Optional[C.CDLL] = None

@@ -402,3 +402,30 @@ def ingest_frames(frames_u8: torch.Tensor, H1: int, W1: int, xb: torch.Tensor, x
                                _L.stream_ptr())
     _L.check(rc, "pi3_ingest_frames")
     return dst
+
+
+def undistort_maps(params16, model: int, H: int, W: int, device):
+    """params16: 16 python floats (see include/pi3slam_hip.h) -> (map_x, map_y) f32 [H,W] on `device`."""
+    import ctypes
+    lib = _L.load()
+    arr = (ctypes.c_double * 16)(*[float(v) for v in params16])
+    mx = torch.empty(H, W, device=device, dtype=torch.float32)
+    my = torch.empty(H, W, device=device, dtype=torch.float32)
+    rc = lib.pi3_undistort_maps(ctypes.cast(arr, ctypes.c_void_p), int(model), H, W, mx.data_ptr(), my.data_ptr(),
+                                _L.stream_ptr())
+    _L.check(rc, "pi3_undistort_maps")
+    return mx, my
+
+
+def remap_bilinear_u8(frames_u8: torch.Tensor, map_x: torch.Tensor, map_y: torch.Tensor) -> torch.Tensor:
+    """uint8 [N,H0,W0,3] + f32 maps [H,W] -> float32 [N,3,H,W] (cv2.remap INTER_LINEAR, border 0, then / 255)."""
+    lib = _L.load()
+    assert frames_u8.dtype == torch.uint8 and frames_u8.is_contiguous() and frames_u8.shape[-1] == 3
+    assert map_x.dtype == torch.float32 and map_y.dtype == torch.float32 and map_x.shape == map_y.shape
+    N, H0, W0 = frames_u8.shape[:3]
+    H, W = map_x.shape
+    dst = torch.empty(N, 3, H, W, device=frames_u8.device, dtype=torch.float32)
+    rc = lib.pi3_remap_bilinear_u8(frames_u8.data_ptr(), N, H0, W0, map_x.contiguous().data_ptr(),
+                                   map_y.contiguous().data_ptr(), H, W, dst.data_ptr(), _L.stream_ptr())
+    _L.check(rc, "pi3_remap_bilinear_u8")
+    return dst

@@ -112,3 +112,51 @@ def test_match_keypoints_oracle():
     q[1, 2] = [999.0, 999.0]
     idx = post_ref.match_keypoints(kp, q)
     assert np.array_equal(idx[0], perm) and idx[1, 2] == -1 and np.array_equal(idx[2], perm)
+
+
+# ------------------------------------------------------------------------------------------- undistortion (§8f rank 4)
+def _calib(name):
+    import json
+    return json.load(open(os.path.join(GOLDEN, "calib_" + name)))
+
+
+def test_undistortion_camera_quirks_and_oracle_known_answers():
+    """Host mirror of pi3/utils/camera.py + the undistorted-camera quirks, and known answers of the oracle restatement
+    (pytheia / cv2 are absent: parity unpinned, see oracle/undistort_ref.py)."""
+    from oracle import undistort_ref as U
+    from pi3_slam_amd.undistortion import Camera, UndistortionMaps, undistorted_copy
+    cal = _calib("euroc_cam0_calib.json")
+    cam = Camera()
+    cam.load_camera_calibration_json(cal, 1.0)
+    assert (cam.image_width, cam.image_height, cam.model) == (752, 480, "PINHOLE_RADIAL_TANGENTIAL")
+    und = undistorted_copy(cam)
+    assert und.aspect_ratio == 1.0 and und.radial == [0.0] * 4 and und.tangential == [0.0, 0.0]
+    assert und.principal_point == cam.principal_point == (367.215, 248.375)     # the re-centring is a no-op upstream
+    p = UndistortionMaps(cam, device="cpu").params16()
+    assert p[0] == p[5] == 458.654 and p[1] == 1.0 and abs(p[6] - 0.9970391624187296) < 1e-15 and p[10] == -0.28340811
+    # zero distortion + unit aspect ratio: identity map, and the remap of an identity map is the crop itself
+    cal0 = {**cal, "intrinsics": {**cal["intrinsics"], "aspect_ratio": 1.0, "radial_distortion_1": 0.0,
+                                  "radial_distortion_2": 0.0, "tangential_distortion_1": 0.0,
+                                  "tangential_distortion_2": 0.0}}
+    mx, my = U.undistort_maps(cal0, (60, 90))
+    assert np.array_equal(mx, np.tile(np.arange(90, dtype=np.float32), (60, 1)))
+    assert np.array_equal(my, np.tile(np.arange(60, dtype=np.float32)[:, None], (1, 90)))
+    img = np.random.default_rng(0).integers(0, 256, (480, 752, 3), dtype=np.uint8)
+    assert np.array_equal(U.remap_bilinear_u8(img, mx, my), img[:60, :90])
+    # remap known answers: half-pixel shift = rounded mean of two neighbours; 1/32-pixel quantisation; border taps read 0
+    ramp = np.arange(12, dtype=np.uint8).reshape(1, 12, 1).repeat(3, 0).repeat(3, 2) * 20
+    xs = np.array([[0.5, 3.5, 10.5, 11.0, 11.5, -0.5, -1.0, 2.0 + 1 / 64, 2.0 + 1 / 32]], np.float32)
+    out = U.remap_bilinear_u8(ramp, xs, np.ones_like(xs))[0, :, 0]
+    assert out.tolist() == [10, 70, 210, 220, 110, 0, 0, 40, 41]       # rint(1/64*32)=rint(0.5)=0 (half to even)
+    # barrel distortion of EuRoC: image corners come from further inside the distorted image; centre is a fixed point
+    mx, my = U.undistort_maps(cal, (480, 752))
+    assert 60 < mx[0, 0] < 90 and 35 < my[0, 0] < 65 and abs(mx[248, 367] - 367.0) < 0.01
+    # division model: x_u = x_d / (1 + k r_d^2) must invert the projection
+    cd = _calib("cam_calib.json")
+    mx, my = U.undistort_maps(cd, (540, 960))
+    k, f, ar = cd["intrinsics"]["div_undist_distortion"], cd["intrinsics"]["focal_length"], cd["intrinsics"]["aspect_ratio"]
+    cx, cy = cd["intrinsics"]["principal_pt_x"], cd["intrinsics"]["principal_pt_y"]
+    xd, yd = mx.astype(np.float64) - cx, my.astype(np.float64) - cy
+    den = 1.0 + k * (xd * xd + yd * yd)
+    c, r = np.meshgrid(np.arange(960.0), np.arange(540.0))
+    assert np.abs(xd / den - (c - cx)).max() < 2e-3 and np.abs(yd / den - ar * (r - cy)).max() < 2e-3

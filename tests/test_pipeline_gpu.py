@@ -91,3 +91,45 @@ def test_device_resize_pipeline_is_identical_to_host_resize(tmp_path, built_lib)
         cb = torch.load(b, map_location="cpu", weights_only=False)
         for k in ("points", "local_points", "conf", "masks", "keypoints", "colors", "camera_poses", "intrinsics"):
             assert torch.equal(ca[k], cb[k]), k
+
+
+def test_process_and_save_with_calibration_undistorts_on_device(tmp_path, built_lib):
+    """BASELINE config 4 plumbing: --cam-dist-path (EuRoC calibration) -> frames are undistorted on the GPU before pi3;
+    the frames handed to the model equal the oracle restatement of the reference's remap + ToTensor."""
+    from PIL import Image
+    from oracle import undistort_ref as U
+    from pi3_slam_amd.chunk_creator import OfflineChunkCreator, OfflineCreatorConfig
+    from pi3_slam_amd.engine import Pi3Engine
+    from pi3_slam_amd.weights import Pi3Config
+    cal_path = os.path.join(os.path.dirname(__file__), "golden", "calib_euroc_cam0_calib.json")
+    rng = np.random.default_rng(9)
+    frames = tmp_path / "frames"
+    frames.mkdir()
+    paths, raw = [], []
+    for i in range(4):
+        a = rng.integers(0, 256, (480, 752, 3), dtype=np.uint8)
+        p = str(frames / f"{i:04d}.png")
+        Image.fromarray(a).save(p)
+        paths.append(p)
+        raw.append(a)
+    small = Pi3Config(dim=128, enc_depth=1, dec_depth=2, head_depth=1, cam_dim=128, pos_grid=5)
+    engine = Pi3Engine(small, "cuda:0")
+    seen = []
+
+    class Spy:
+        def __call__(self, imgs):
+            seen.append(imgs.detach().cpu().numpy())
+            return engine.forward(imgs)
+
+    cfg = OfflineCreatorConfig(model_path="recipe", output_dir=str(tmp_path / "out"), chunk_length=4, overlap=1,
+                               do_metric_depth=False, keypoint_type="grid", max_num_keypoints=50,
+                               num_loader_workers=0, pin_memory=False, cam_dist_path=cal_path)
+    creator = OfflineChunkCreator(cfg, model=Spy(), moge_model=None)
+    assert creator.undistortion_maps is not None
+    saved = creator.process_and_save(paths)
+    assert len(saved) == 1 and seen[0].shape[:2] == (1, 4)
+    import json
+    ref = U.undistort_frames(np.stack(raw), json.load(open(cal_path)), creator.target_size)
+    mism = (seen[0][0] != ref).mean()
+    assert mism < 1e-3, mism          # maps may differ by 1 ulp -> a 1/32-pixel bucket flip on isolated pixels
+    assert np.abs(seen[0][0] - ref).max() <= 8.0 / 255.0 + 1e-6

@@ -344,3 +344,56 @@ def test_ingest_full_size_against_oracle_and_dataset_item(dev, tmp_path):
         host, devi = ds[idx], ds.load_chunk_device(idx, dev)
         assert torch.equal(host["chunk"], devi["chunk"].cpu())
         assert host["chunk_paths"] == devi["chunk_paths"] and int(host["start_idx"]) == int(devi["start_idx"])
+
+
+@pytest.mark.parametrize("calib,target", [("euroc_cam0_calib.json", (308, 406)), ("euroc_cam0_calib.json", (480, 752)),
+                                          ("cam_calib.json", (378, 504))])
+def test_undistortion_maps_and_remap_against_oracle(dev, calib, target):
+    """§8f rank 4: map builder (4 camera models) and cv2.remap restatement, kernels vs the numpy oracle."""
+    import json
+    from oracle import undistort_ref as U
+    from pi3_slam_amd.undistortion import Camera, UndistortionMaps
+    cal = json.load(open(os.path.join(GOLDEN, "calib_" + calib)))
+    cam = Camera()
+    cam.load_camera_calibration_json(cal, 1.0)
+    maps = UndistortionMaps(cam, device=str(dev))
+    mx, my = maps.get_maps(target)
+    rx, ry = U.undistort_maps(cal, target)
+    # fp64 formulas on both sides, one rounding to fp32: at most 1 ulp apart (sqrt / fma contraction differences)
+    assert np.abs(mx.cpu().numpy() - rx).max() <= 6.2e-5 and np.abs(my.cpu().numpy() - ry).max() <= 6.2e-5
+    rng = np.random.default_rng(11)
+    frames = rng.integers(0, 256, (3, cal["image_height"], cal["image_width"], 3), dtype=np.uint8)
+    out = maps.undistort_frames_device(torch.from_numpy(frames).to(dev), target)
+    # remap on the DEVICE maps (integer arithmetic from there on: bit-exact)
+    ref = np.stack([U.remap_bilinear_u8(f, mx.cpu().numpy(), my.cpu().numpy()) for f in frames])
+    ref = (ref.astype(np.float32) / np.float32(255.0)).transpose(0, 3, 1, 2)
+    assert np.array_equal(out.cpu().numpy(), ref)
+    with pytest.raises(NotImplementedError):
+        maps.undistort_frames_device(torch.zeros(1, 100, 100, 3, dtype=torch.uint8, device=dev), target)
+
+
+def test_undistortion_models_synthetic(dev):
+    """PINHOLE and FISHEYE (no example calibration in the reference): kernels vs oracle on synthetic parameters, maps
+    partly outside the image (border taps) and a skewed camera."""
+    from oracle import undistort_ref as U
+    from pi3_slam_amd.undistortion import Camera, UndistortionMaps
+    base = {"image_height": 240, "image_width": 320}
+    cals = [
+        {**base, "intrinsic_type": "PINHOLE", "intrinsics": {"aspect_ratio": 1.02, "focal_length": 210.0,
+         "principal_pt_x": 158.3, "principal_pt_y": 121.9, "radial_distortion_1": -0.21, "radial_distortion_2": 0.05,
+         "skew": 0.4}},
+        {**base, "intrinsic_type": "FISHEYE", "intrinsics": {"aspect_ratio": 0.99, "focal_length": 150.0,
+         "principal_pt_x": 160.0, "principal_pt_y": 120.0, "radial_distortion_1": -0.03, "radial_distortion_2": 0.01,
+         "radial_distortion_3": -0.002, "radial_distortion_4": 0.0003, "skew": 0.0}},
+    ]
+    img = np.random.default_rng(5).integers(0, 256, (2, 240, 320, 3), dtype=np.uint8)
+    for cal in cals:
+        cam = Camera()
+        cam.load_camera_calibration_json(cal, 1.0)
+        maps = UndistortionMaps(cam, device=str(dev))
+        mx, my = maps.get_maps((240, 320))
+        rx, ry = U.undistort_maps(cal, (240, 320))
+        assert np.abs(mx.cpu().numpy() - rx).max() <= 6.2e-5 and np.abs(my.cpu().numpy() - ry).max() <= 6.2e-5
+        out = maps.undistort_frames_device(torch.from_numpy(img).to(dev), (240, 320)).cpu().numpy()
+        ref = np.stack([U.remap_bilinear_u8(f, mx.cpu().numpy(), my.cpu().numpy()) for f in img])
+        assert np.array_equal(out, (ref.astype(np.float32) / np.float32(255.0)).transpose(0, 3, 1, 2))

@@ -128,7 +128,7 @@ def main() -> None:
                       for b in allgather_boundaries(pack_boundary(chunk, OV, KP), dev if backend == "nccl" else "cpu")]
             rel = [torch.eye(4, dtype=torch.float64, device=dev).reshape(16)]
             for r in range(1, world):
-                rel.append(relative_sim3_from_boundaries(blocks[r - 1], blocks[r], OV, dev)[13:29])
+                rel.append(relative_sim3_from_boundaries(blocks[r - 1], blocks[r], OV, dev, chunk_length=CL)[13:29])
             compose_global(torch.stack(rel))
         prev = chunk
 

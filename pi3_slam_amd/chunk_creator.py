@@ -68,7 +68,9 @@ class OfflineChunkCreator:
         os.makedirs(self.config.output_dir, exist_ok=True)
         self.chunks_dir = os.path.join(self.config.output_dir, "chunks")
         os.makedirs(self.chunks_dir, exist_ok=True)
-        dev = self.config.device if self.config.device != "cuda" else "cuda:0"
+        from .dist import ensure_process_group, local_device_index
+        self.rank, self.world = ensure_process_group()          # (0, 1) unless launched under torch.distributed.run
+        dev = self.config.device if self.config.device != "cuda" else f"cuda:{local_device_index()}"
         if not str(dev).startswith("cuda"):
             raise RuntimeError("this build runs the hot path on an MI355X only; there is no CPU path (device='cuda')")
         self.device = torch.device(dev)
@@ -245,13 +247,20 @@ class OfflineChunkCreator:
         dataset = ChunkImageDataset(image_paths, self.config.chunk_length, self.config.overlap, self.target_size,
                                     decode_only=self.config.device_resize or undist is not None)
         nw = self.config.num_loader_workers
-        loader = DataLoader(dataset, batch_size=1, shuffle=False, num_workers=nw, pin_memory=self.config.pin_memory,
-                            persistent_workers=nw > 0, prefetch_factor=1 if nw > 0 else None)
+        # chunk-parallel over the GPUs of the node: chunk c is created by rank c % world; chunks do not
+        # depend on each other (each takes its metric scale from its own first frame)
+        my_chunks = list(range(self.rank, len(dataset), self.world))
+        shard = dataset if self.world == 1 else torch.utils.data.Subset(dataset, my_chunks)
+        loader = DataLoader(shard, batch_size=1, shuffle=False, num_workers=nw, pin_memory=self.config.pin_memory,
+                            persistent_workers=nw > 0 and len(my_chunks) > 0, prefetch_factor=1 if nw > 0 else None)
         saved_files: List[str] = []
         manifest: List[Dict] = []
-        print(f"🔄 Processing {len(dataset)} chunks...")
+        print(f"🔄 Processing {len(my_chunks)} of {len(dataset)} chunks (rank {self.rank}/{self.world})...")
         infer_times, infer_frames, per_chunk_fps = [], [], []
-        for chunk_idx, batch in enumerate(loader):
+        for local_idx, batch in enumerate(loader):
+            chunk_idx = my_chunks[local_idx]
+            if self.keypoint_extractor is not None and hasattr(self.keypoint_extractor, "reseed"):
+                self.keypoint_extractor.reseed(chunk_idx)     # the random grid subset does not depend on the sharding
             start_idx = int(batch["start_idx"].item())
             end_idx = int(batch["end_idx"].item())
             if undist is not None:     # remap + ToTensor on the GPU (datasets/image_datasets.py:192-199)
@@ -294,6 +303,14 @@ class OfflineChunkCreator:
                       f"{steady[len(steady) // 2]:.2f} FPS")
         except Exception:  # noqa: BLE001
             pass
+        if self.world > 1:   # rank 0 writes the manifest of all ranks' chunks
+            from .dist import gather_objects
+            parts = gather_objects(manifest)
+            if self.rank != 0:
+                torch.distributed.barrier()
+                print(f"✅ Completed. Saved {len(saved_files)} chunks to {self.chunks_dir}")
+                return saved_files
+            manifest = sorted((m for part in parts for m in part), key=lambda m: m["chunk_index"])
         try:
             with open(os.path.join(self.config.output_dir, "chunks_manifest.json"), "w") as f:
                 json.dump(manifest, f, indent=2)
@@ -306,5 +323,7 @@ class OfflineChunkCreator:
                 json.dump(metadata, f, indent=2)
         except Exception as e:  # noqa: BLE001
             print(f"⚠️  Failed to write chunk metadata: {e}")
+        if self.world > 1:
+            torch.distributed.barrier()     # metadata is on disk before any rank starts stage 2
         print(f"✅ Completed. Saved {len(saved_files)} chunks to {self.chunks_dir}")
         return saved_files

@@ -18,6 +18,41 @@ import torch
 import torch.distributed as dist
 
 
+def ensure_process_group() -> Tuple[int, int]:
+    """(rank, world).  Under torch.distributed.run (WORLD_SIZE > 1 in the environment) the process group is created on
+    first use - backend "nccl" (= RCCL over xGMI) unless PI3_DIST_BACKEND says otherwise (the CPU / one-GPU tests use
+    gloo) - so the reference's unmodified CLIs shard across GPUs once launched with torchrun."""
+    import os
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world <= 1:
+        return 0, 1
+    backend = os.environ.get("PI3_DIST_BACKEND", "nccl" if torch.cuda.is_available() else "gloo")
+    if backend == "nccl":
+        dev = torch.device("cuda", local_device_index())
+        torch.cuda.set_device(dev)
+        dist.init_process_group("nccl", device_id=dev)
+    else:
+        dist.init_process_group(backend)
+    return dist.get_rank(), dist.get_world_size()
+
+
+def local_device_index() -> int:
+    """cuda index of this rank: LOCAL_RANK, folded onto the visible devices (several ranks may share a card in tests)."""
+    import os
+    n = max(1, torch.cuda.device_count())
+    return int(os.environ.get("LOCAL_RANK", "0")) % n
+
+
+def gather_objects(obj, dst: int = 0):
+    """All ranks' python objects on rank dst (None elsewhere); works on gloo and nccl process groups."""
+    world = dist.get_world_size()
+    out = [None] * world
+    dist.all_gather_object(out, obj)
+    return out if dist.get_rank() == dst else None
+
+
 def shard_chunks(n_chunks: int, rank: int, world: int) -> List[int]:
     """Chunk c runs on rank c % world: neighbouring chunks sit on neighbouring ranks, every wave of `world` chunks is
     complete before its all-gather."""
@@ -69,16 +104,26 @@ def allgather_boundaries(local: torch.Tensor, device) -> List[torch.Tensor]:
     return out
 
 
-def relative_sim3_from_boundaries(prev: Dict, cur: Dict, overlap: int, device, use_filter: bool = True):
-    """T_{c-1<-c} from the previous chunk's TAIL block and the current chunk's HEAD block (device kernels)."""
+def relative_sim3_from_boundaries(prev: Dict, cur: Dict, overlap: int, device, use_filter: bool = True,
+                                  chunk_length: Optional[int] = None):
+    """T_{c-1<-c} from the previous chunk's TAIL block and the current chunk's HEAD block (device kernels).
+    View pairs are the nominal (chunk_length - overlap + i, i) of create_view_graph_matches restricted to views that
+    exist (like alignment.estimate_sim3): the tail block holds the previous chunk's last min(overlap, n) views, so for a
+    short previous chunk nominal view chunk_length - overlap + i sits at tail position i + d."""
     from . import ops
-    ov = min(overlap, prev["n_frames"], cur["n_frames"])
+    n_prev, n_cur = int(prev["n_frames"]), int(cur["n_frames"])
+    ov_p = min(overlap, n_prev)
+    d = 0 if chunk_length is None else (chunk_length - overlap) - (n_prev - ov_p)
+    pairs = [(i + d, i) for i in range(overlap) if 0 <= i + d < ov_p and i < min(overlap, n_cur)]
+    if not pairs:
+        raise ValueError("no overlapping views between the two chunks")
+    ri = torch.tensor([r for r, _ in pairs], dtype=torch.long)
+    qi = torch.tensor([q for _, q in pairs], dtype=torch.long)
     ref, qry = prev["tail"], cur["head"]
-    # the previous chunk's tail holds its last min(overlap, n) views; view pairs are (cl - ov + i, i)
-    kp_r = ref["keypoints"][:ov].to(device).contiguous()
-    kp_q = qry["keypoints"][:ov].to(device).contiguous()
+    kp_r = ref["keypoints"][ri].to(device).contiguous()
+    kp_q = qry["keypoints"][qi].to(device).contiguous()
     idx = ops.sim3_match_keypoints(kp_r, kp_q)
-    return ops.sim3_umeyama(ref["points"][:ov].to(device).contiguous(), qry["points"][:ov].to(device).contiguous(),
+    return ops.sim3_umeyama(ref["points"][ri].to(device).contiguous(), qry["points"][qi].to(device).contiguous(),
                             idx, prev["last_pose"].to(device, torch.float32).contiguous(), None, None, use_filter)
 
 

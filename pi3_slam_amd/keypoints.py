@@ -22,7 +22,14 @@ class GridKeypointExtractor:
         self.device = device
         self.max_num_keypoints = max_num_keypoints
         self.grid_spacing = grid_spacing
+        self._seed = seed
         self._gen = torch.Generator().manual_seed(seed) if seed is not None else None
+
+    def reseed(self, chunk_index: int) -> None:
+        """Restart the subsampling stream for a chunk: the keypoints of chunk c then do not depend on which chunks this
+        process handled before it (chunk-parallel runs give the files of a single-process run)."""
+        if self._seed is not None:
+            self._gen.manual_seed(self._seed + 7919 * int(chunk_index))
 
     def _calculate_grid_spacing(self, H: int, W: int) -> int:
         if self.grid_spacing is not None:

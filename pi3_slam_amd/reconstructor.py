@@ -91,6 +91,11 @@ class OfflineReconstructor:
         return info
 
     def run(self) -> None:
+        from .dist import ensure_process_group
+        rank, world = ensure_process_group()
+        if world > 1:
+            self._run_distributed(rank, world)
+            return
         chunk_files = self._load_chunks()
         print(f"🔄 Reconstructing {len(chunk_files)} chunks from {self.chunk_dir}")
         for idx, path in enumerate(chunk_files):
@@ -108,6 +113,9 @@ class OfflineReconstructor:
                 self._save_chunk(data, idx)
         if not self.reconstructions:
             return
+        self._write_outputs()
+
+    def _write_outputs(self) -> None:
         try:
             pts, cols = self._extract_points_colors()
             if pts.size > 0:
@@ -126,6 +134,66 @@ class OfflineReconstructor:
             self._save_trajectory_tum(os.path.join(self.output_dir, "trajectory_tum.txt"), integer_timestamp=True)
         except Exception as e:  # noqa: BLE001
             print(f"❌ Failed to save TUM trajectory: {e}")
+
+    def _run_distributed(self, rank: int, world: int) -> None:
+        """Chunk-parallel alignment: chunk c lives on rank c % world.  Per wave of `world` chunks ONE
+        all-gather of the boundary blocks (overlap keypoints / points / validity + last pose, ~50 KB per rank), then
+        every rank computes the relative similarities T_{c-1<-c} of the wave and the prefix product
+        G_c = G_{c-1} . T_{c-1<-c} locally, applies G_c to its own chunk, and rank 0 collects the transformed chunks
+        for the trajectory / point-cloud files.  Equal to the sequential run for the closed-form Sim(3) step up to the
+        fp16 re-quantisation of the previous chunk's points (the reference's BA refinement is not part of either)."""
+        import torch.distributed as dist
+
+        from .alignment import transform_chunk
+        from .dist import (allgather_boundaries, gather_objects, pack_boundary, relative_sim3_from_boundaries,
+                           unpack_boundary)
+        files = self._load_chunks()
+        n_chunks = len(files)
+        gathered_on = self.device if dist.get_backend() == "nccl" else "cpu"
+        print(f"🔄 Reconstructing {n_chunks} chunks from {self.chunk_dir} on {world} ranks (rank {rank})")
+        G_last = np.eye(4)
+        prev_block = None
+        mine: List[Dict] = []
+        K = None
+        for w0 in range(0, n_chunks, world):
+            c = w0 + rank
+            data = torch.load(files[c], map_location="cpu", weights_only=False) if c < n_chunks else None
+            kk = torch.tensor([int(data["keypoints"].shape[1]) if data is not None else 0], device=gathered_on)
+            ks = [torch.zeros_like(kk) for _ in range(world)]
+            dist.all_gather(ks, kk)
+            K = max(int(k.item()) for k in ks)
+            if data is not None:
+                local = pack_boundary(data, self.overlap, K)
+            else:   # ragged last wave: an empty block (n_frames = 0)
+                local = torch.zeros(1 + 2 * self.overlap * K * 6 + 16)
+            blocks = [unpack_boundary(b.cpu(), self.overlap, K) for b in allgather_boundaries(local, gathered_on)]
+            for r in range(world):
+                if w0 + r >= n_chunks:
+                    break
+                if prev_block is None:
+                    G = np.eye(4)
+                else:
+                    out = relative_sim3_from_boundaries(prev_block, blocks[r], self.overlap, self.device,
+                                                        chunk_length=self.chunk_length)
+                    if float(out[29]) < 3.0:
+                        print(f"   ❌ Alignment failed for chunk {w0 + r}: {int(out[30])} common, {int(out[29])} kept")
+                        T = np.eye(4)
+                    else:
+                        T = out[13:29].reshape(4, 4).cpu().numpy().astype(np.float64)
+                    G = G_last @ T
+                if r == rank and data is not None:
+                    transform_chunk(data, torch.from_numpy(G), device=self.device)
+                    data["chunk_order"] = w0 + r
+                    mine.append(data)
+                    if self.save_per_chunk:
+                        self._save_chunk(data, w0 + r)
+                G_last, prev_block = G, blocks[r]
+        keep = ("points", "colors", "keypoints", "masks", "camera_poses", "image_paths", "chunk_order")
+        parts = gather_objects([{k: d[k] for k in keep if k in d} for d in mine])
+        if rank == 0:
+            self.reconstructions = sorted((d for part in parts for d in part), key=lambda d: d["chunk_order"])
+            self._write_outputs()
+        dist.barrier()
 
     def _save_chunk(self, data: Dict, idx: int) -> None:
         try:

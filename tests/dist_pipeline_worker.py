@@ -1,0 +1,31 @@
+"""Worker of tests/test_pipeline_gpu.py::test_two_rank_pipeline_matches_single_process: run under
+torch.distributed.run with PI3_DIST_BACKEND=gloo (both ranks share the one GPU of the test box)."""
+import glob
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from pi3_slam_amd.chunk_creator import OfflineChunkCreator, OfflineCreatorConfig  # noqa: E402
+from pi3_slam_amd.engine import Pi3Engine  # noqa: E402
+from pi3_slam_amd.reconstructor import OfflineReconstructor  # noqa: E402
+from pi3_slam_amd.weights import Pi3Config  # noqa: E402
+
+
+def main():
+    frames_dir, out_dir, recon_dir = sys.argv[1:4]
+    paths = sorted(glob.glob(os.path.join(frames_dir, "*.png")))
+    small = Pi3Config(dim=128, enc_depth=1, dec_depth=2, head_depth=1, cam_dim=128, pos_grid=5)
+    cfg = OfflineCreatorConfig(model_path="recipe", output_dir=out_dir, chunk_length=8, overlap=3, do_metric_depth=False,
+                               keypoint_type="grid", max_num_keypoints=100, num_loader_workers=0, pin_memory=False)
+    creator = OfflineChunkCreator(cfg, model=None if False else Pi3Engine(small, f"cuda:{torch.cuda.current_device()}"),
+                                  moge_model=None)
+    creator.process_and_save(paths)
+    OfflineReconstructor(out_dir, recon_dir, device=str(creator.device)).run()
+    if torch.distributed.is_initialized():
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

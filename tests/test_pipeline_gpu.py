@@ -133,3 +133,44 @@ def test_process_and_save_with_calibration_undistorts_on_device(tmp_path, built_
     mism = (seen[0][0] != ref).mean()
     assert mism < 1e-3, mism          # maps may differ by 1 ulp -> a 1/32-pixel bucket flip on isolated pixels
     assert np.abs(seen[0][0] - ref).max() <= 8.0 / 255.0 + 1e-6
+
+
+def test_two_rank_pipeline_matches_single_process(tmp_path, built_lib):
+    """SURVEY §8e in the product path: under torch.distributed.run the creator shards chunks (c % world) and the
+    reconstructor aligns with one all-gather of boundary blocks per wave.  Two gloo ranks on this box's GPU must write
+    the chunk files of a single-process run bit for bit, and the same trajectory up to the fp16 re-quantisation the
+    sequential run applies to the previous chunk's points."""
+    import subprocess
+    import sys
+    frames = tmp_path / "frames"
+    frames.mkdir()
+    _write_frames(str(frames))
+    worker = os.path.join(os.path.dirname(__file__), "dist_pipeline_worker.py")
+    env = dict(os.environ, PI3_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r1 = subprocess.run([sys.executable, worker, str(frames), str(tmp_path / "o1"), str(tmp_path / "r1")], env=env,
+                        capture_output=True, text=True, timeout=300)
+    assert r1.returncode == 0, r1.stdout[-2000:] + r1.stderr[-2000:]
+    r2 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                         "--master-addr", "127.0.0.1", "--master-port", "29571", worker, str(frames),
+                         str(tmp_path / "o2"), str(tmp_path / "r2")], env=env, capture_output=True, text=True, timeout=300)
+    assert r2.returncode == 0, r2.stdout[-2000:] + r2.stderr[-2000:]
+    f1 = sorted(os.listdir(tmp_path / "o1" / "chunks"))
+    f2 = sorted(os.listdir(tmp_path / "o2" / "chunks"))
+    assert f1 == f2 and len(f1) >= 5
+    for name in f1:
+        a = torch.load(tmp_path / "o1" / "chunks" / name, map_location="cpu", weights_only=False)
+        b = torch.load(tmp_path / "o2" / "chunks" / name, map_location="cpu", weights_only=False)
+        for k in ("points", "local_points", "conf", "masks", "keypoints", "colors", "camera_poses", "intrinsics"):
+            assert torch.equal(a[k], b[k]), (name, k)
+        assert a["chunk_index"] == b["chunk_index"] and a["start_idx"] == b["start_idx"]
+    assert json.load(open(tmp_path / "o1" / "chunks_manifest.json")) == json.load(open(tmp_path / "o2" / "chunks_manifest.json"))
+    assert json.load(open(tmp_path / "o1" / "chunk_metadata.json")) == json.load(open(tmp_path / "o2" / "chunk_metadata.json"))
+    t1 = np.loadtxt(tmp_path / "r1" / "trajectory_tum.txt")
+    t2 = np.loadtxt(tmp_path / "r2" / "trajectory_tum.txt")
+    assert t1.shape == t2.shape and t1.shape[0] == 32
+    scale = np.abs(t1[:, 1:4]).max() + 1e-9
+    assert np.abs(t1[:, 1:4] - t2[:, 1:4]).max() / scale < 2e-2       # fp16 points in the sequential chain
+    dq = np.minimum(np.abs(t1[:, 4:] - t2[:, 4:]).max(1), np.abs(t1[:, 4:] + t2[:, 4:]).max(1))
+    assert dq.max() < 2e-2

@@ -49,7 +49,7 @@ def write_ply(points: np.ndarray, colors: np.ndarray, path: str) -> None:
 class OfflineReconstructor:
     def __init__(self, chunk_dir: str, output_dir: str, chunk_length: Optional[int] = None,
                  overlap: Optional[int] = None, max_observations_per_track: int = 5, save_per_chunk: bool = False,
-                 use_inverse_depth: bool = False, device: str = "cuda:0"):
+                 use_inverse_depth: bool = False, device: str = "cuda:0", save_observations: bool = False):
         self.chunk_dir, self.output_dir = chunk_dir, output_dir
         loaded_cl = loaded_ov = None
         try:  # offline_reconstructor.py:32-46
@@ -67,6 +67,9 @@ class OfflineReconstructor:
         self.save_per_chunk = save_per_chunk
         self.use_inverse_depth = use_inverse_depth
         self.device = device
+        # save_observations: also write, per chunk, the track observations the reference builds for its bundle adjuster
+        # (ChunkPTRecon.create_recon_from_chunk, utils/chunk_reconstruction.py:162-185) as observations_%06d.pt
+        self.save_observations = save_observations
         os.makedirs(self.output_dir, exist_ok=True)
         self.recon_dir = os.path.join(self.output_dir, "reconstructions")
         os.makedirs(self.recon_dir, exist_ok=True)
@@ -111,6 +114,8 @@ class OfflineReconstructor:
             print(f"   ⏱️ Reconstruction: {dt:.3f}s for {n} frames  ->  {n / dt:.2f} FPS")
             if self.save_per_chunk:
                 self._save_chunk(data, idx)
+            if self.save_observations:
+                self._save_observations(data, idx)
         if not self.reconstructions:
             return
         self._write_outputs()
@@ -187,6 +192,8 @@ class OfflineReconstructor:
                     mine.append(data)
                     if self.save_per_chunk:
                         self._save_chunk(data, w0 + r)
+                    if self.save_observations:
+                        self._save_observations(data, w0 + r)
                 G_last, prev_block = G, blocks[r]
         keep = ("points", "colors", "keypoints", "masks", "camera_poses", "image_paths", "chunk_order")
         parts = gather_objects([{k: d[k] for k in keep if k in d} for d in mine])
@@ -194,6 +201,19 @@ class OfflineReconstructor:
             self.reconstructions = sorted((d for part in parts for d in part), key=lambda d: d["chunk_order"])
             self._write_outputs()
         dist.barrier()
+
+    def _save_observations(self, data: Dict, idx: int) -> None:
+        try:
+            from .observations import project_chunk_observations
+            if "intrinsics" not in data or data["intrinsics"] is None:
+                return
+            chunk = {"points": data["points"].to(self.device), "camera_poses": data["camera_poses"].to(self.device),
+                     "intrinsics": data["intrinsics"].to(self.device)}
+            obs = project_chunk_observations(chunk, int(data["original_width"]), int(data["original_height"]),
+                                             self.max_observations_per_track)
+            torch.save({k: v.cpu() for k, v in obs.items()}, os.path.join(self.recon_dir, f"observations_{idx:06d}.pt"))
+        except Exception as e:  # noqa: BLE001
+            print(f"   ❌ Failed to save observations {idx}: {e}")
 
     def _save_chunk(self, data: Dict, idx: int) -> None:
         try:

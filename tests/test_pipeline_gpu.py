@@ -58,9 +58,14 @@ def test_process_and_save_then_reconstruct(tmp_path, built_lib):
     assert torch.isfinite(c0["points"].float()).all() and torch.isfinite(c0["camera_poses"]).all()
     with pytest.raises(ValueError):
         creator.process_and_save([])                                             # offline_chunk_creator.py:263-264
-    rec = OfflineReconstructor(str(out), str(tmp_path / "recon"))
+    rec = OfflineReconstructor(str(out), str(tmp_path / "recon"), save_observations=True)
     assert (rec.chunk_length, rec.overlap) == (32, 8)
     rec.run()
+    obs = torch.load(tmp_path / "recon" / "reconstructions" / "observations_000000.pt", weights_only=False)
+    assert obs["uv"].shape == (obs["source_frame"].numel(), 2) and obs["source_frame"].numel() > 0
+    assert (obs["uv"][:, 0] >= 0).all() and (obs["uv"][:, 0] < 406).all() and (obs["uv"][:, 1] < 308).all()
+    assert (obs["target_frame"] != obs["source_frame"]).all()
+    assert ((obs["target_frame"] < obs["source_frame"]) | (obs["target_frame"] - obs["source_frame"] <= 2)).all()
     lines = open(tmp_path / "recon" / "trajectory_tum.txt").read().strip().split("\n")
     assert len(lines) == 1 + 32                                                  # 40 poses, 8 duplicates dropped
     vals = np.array([[float(v) for v in l.split()] for l in lines[1:]])

@@ -11,6 +11,13 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
 def _write_frames(d, n=32, w=256, h=192):
     from PIL import Image
     rng = np.random.default_rng(0)
@@ -158,7 +165,7 @@ def test_two_rank_pipeline_matches_single_process(tmp_path, built_lib):
                         capture_output=True, text=True, timeout=300)
     assert r1.returncode == 0, r1.stdout[-2000:] + r1.stderr[-2000:]
     r2 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                         "--master-addr", "127.0.0.1", "--master-port", "29571", worker, str(frames),
+                         "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), worker, str(frames),
                          str(tmp_path / "o2"), str(tmp_path / "r2")], env=env, capture_output=True, text=True, timeout=300)
     assert r2.returncode == 0, r2.stdout[-2000:] + r2.stderr[-2000:]
     f1 = sorted(os.listdir(tmp_path / "o1" / "chunks"))

@@ -48,6 +48,7 @@ class OfflineCreatorConfig:
     moge_model_path: Optional[str] = None   # local MoGe-2 model.pt, or "recipe" for synthetic weights
     keypoint_seed: Optional[int] = 0
     device_resize: bool = False             # loader workers only decode; Resize + ToTensor run on the GPU (bit-identical)
+    hip_graph: bool = False                 # replay the per-chunk pi3 forward as one captured hipGraph per chunk shape
 
 
 def _uv_tables(H: int, W: int, device) -> Tuple[torch.Tensor, torch.Tensor]:
@@ -177,7 +178,10 @@ class OfflineChunkCreator:
         num_frames = int(chunk_images.shape[1])
         t0 = time.time()
         imgs_dev = chunk_images.to(self.device, non_blocking=True)
-        pi3_result = self.model(imgs_dev)
+        if self.config.hip_graph and hasattr(self.model, "forward_graphed"):
+            pi3_result = self.model.forward_graphed(imgs_dev)     # static outputs: consumed before the next chunk
+        else:
+            pi3_result = self.model(imgs_dev)
         torch.cuda.synchronize(self.device)
         dt_inf = max(1e-6, time.time() - t0)
         fps = num_frames / dt_inf if num_frames > 0 else 0.0

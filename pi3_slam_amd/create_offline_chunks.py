@@ -52,6 +52,7 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("--moge-model-path", default=None, help="local MoGe-2 model.pt ('recipe' = synthetic weights)")
     p.add_argument("--device-resize", action="store_true", help="Resize + ToTensor on the GPU (workers decode only)")
     p.add_argument("--keypoint-seed", type=int, default=0, help="seed of the grid subsampling (-1: unseeded)")
+    p.add_argument("--hip-graph", action="store_true", help="replay the per-chunk forward as a captured hipGraph")
     return p
 
 
@@ -72,7 +73,8 @@ def main(argv=None) -> None:
         max_num_keypoints=args.max_kp, keypoint_detection_threshold=args.kp_threshold,
         estimate_camera_params=args.estimate_intrinsics, num_loader_workers=args.num_workers,
         cam_dist_path=args.cam_dist_path, moge_model_path=args.moge_model_path,
-        keypoint_seed=None if args.keypoint_seed < 0 else args.keypoint_seed, device_resize=args.device_resize)
+        keypoint_seed=None if args.keypoint_seed < 0 else args.keypoint_seed, device_resize=args.device_resize,
+        hip_graph=args.hip_graph)
     OfflineChunkCreator(cfg).process_and_save(paths[start:end])
 
 

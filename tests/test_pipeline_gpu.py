@@ -198,7 +198,7 @@ def test_cli_entry_points_full_model(tmp_path, built_lib):
     out = tmp_path / "chunks_out"
     cc.main(["--images", str(frames), "--output", str(out), "--chunk-length", "6", "--overlap", "2", "--model-path",
              "recipe", "--moge-model-path", "recipe", "--keypoints", "grid", "--max-kp", "64", "--num-workers", "0",
-             "--skip-start", "1", "--device-resize"])
+             "--skip-start", "1", "--device-resize", "--hip-graph"])
     man = json.load(open(out / "chunks_manifest.json"))
     assert [(m["start_idx"], m["end_idx"]) for m in man] == [(0, 6), (4, 9)]        # (8, 9) has < 2 frames: dropped
     ro.main(["--chunks", str(out), "--output", str(tmp_path / "rec"), "--save-observations"])

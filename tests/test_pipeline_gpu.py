@@ -205,3 +205,36 @@ def test_cli_entry_points_full_model(tmp_path, built_lib):
     lines = open(tmp_path / "rec" / "trajectory_tum.txt").read().strip().split("\n")
     assert len(lines) == 1 + 9                                   # 10 frames, the first one skipped
     assert os.path.exists(tmp_path / "rec" / "final_points.ply")
+
+
+def test_online_sliding_window_matches_offline_two_stage(tmp_path, built_lib):
+    """BASELINE config 5 plumbing: the online facade (stream -> chunks -> progressive alignment, hipGraph forward) must
+    give the trajectory of the offline two-stage flow (same kernels, no disk round trip)."""
+    from pi3_slam_amd.chunk_creator import OfflineChunkCreator, OfflineCreatorConfig
+    from pi3_slam_amd.engine import Pi3Engine
+    from pi3_slam_amd.online import Pi3SLAMOnline
+    from pi3_slam_amd.reconstructor import OfflineReconstructor
+    from pi3_slam_amd.weights import Pi3Config
+    frames = tmp_path / "frames"
+    frames.mkdir()
+    paths = _write_frames(str(frames), n=20)
+    small = Pi3Config(dim=128, enc_depth=1, dec_depth=2, head_depth=1, cam_dim=128, pos_grid=5)
+    engine = Pi3Engine(small, "cuda:0")
+    slam = Pi3SLAMOnline(model=engine, chunk_length=8, overlap=3, device="cuda:0", keypoint_type="grid",
+                         max_num_keypoints=100, estimate_camera_params=True, hip_graph=True,
+                         output_dir=str(tmp_path / "online"))
+    res = slam.process_chunks(paths)
+    assert slam.get_reconstruction_count() == len(res) == 4 and slam.get_statistics()["num_frames"] == 20
+    slam.save_trajectory_tum(str(tmp_path / "online" / "traj.txt"), integer_timestamp=True)
+    slam.save_final_result(str(tmp_path / "online" / "points.ply"))
+    cfg = OfflineCreatorConfig(model_path="recipe", output_dir=str(tmp_path / "off"), chunk_length=8, overlap=3,
+                               do_metric_depth=False, keypoint_type="grid", max_num_keypoints=100,
+                               num_loader_workers=0, pin_memory=False)
+    OfflineChunkCreator(cfg, model=engine, moge_model=None).process_and_save(paths)
+    OfflineReconstructor(str(tmp_path / "off"), str(tmp_path / "off_rec")).run()
+    t_on = np.loadtxt(tmp_path / "online" / "traj.txt")
+    t_off = np.loadtxt(tmp_path / "off_rec" / "trajectory_tum.txt")
+    assert t_on.shape == t_off.shape == (20, 8)
+    # the offline flow stores chunks as fp16 / reloads them; the online one aligns the same tensors in memory
+    assert np.abs(t_on - t_off).max() < 1e-4
+    assert "create_chunk" in slam.get_timing_statistics() and os.path.getsize(tmp_path / "online" / "points.ply") > 0

@@ -164,22 +164,22 @@ def test_undistortion_camera_quirks_and_oracle_known_answers():
 
 def test_cli_parsers_and_image_listing(tmp_path):
     """Flags and defaults of the reference CLIs (create_offline_chunks.py:44-62, reconstruct_offline.py:21-29)."""
-    from pi3_slam_amd import create_offline_chunks as cc, reconstruct_offline as ro
-    a = cc.build_parser().parse_args(["--images", "x", "--output", "y"])
+    from pi3_slam_amd import cli
+    a = cli.build_parser().parse_args(["create", "--images", "x", "--output", "y"])
     assert (a.chunk_length, a.overlap, a.device, a.metric_depth, a.keypoints, a.max_kp, a.kp_threshold,
             a.estimate_intrinsics, a.num_workers, a.skip_start, a.skip_end, a.cam_dist_path) == \
         (50, 5, "cuda", True, "grid", 200, 0.005, True, 4, 0, 0, None)
-    assert cc.build_parser().parse_args(["--images", "x", "--output", "y", "--no-metric-depth"]).metric_depth is False
-    r = ro.build_parser().parse_args(["--chunks", "c", "--output", "o"])
+    assert cli.build_parser().parse_args(["create", "--images", "x", "--output", "y", "--no-metric-depth"]).metric_depth is False
+    r = cli.build_parser().parse_args(["reconstruct", "--chunks", "c", "--output", "o"])
     assert (r.chunk_length, r.overlap, r.max_observations_per_track, r.save_per_chunk, r.use_inverse_depth) == \
         (None, None, 5, False, False)
     for n in ("b.jpg", "a.png", "c.png", "a.bmp", "z.txt"):
         (tmp_path / n).write_bytes(b"")
-    got = [os.path.basename(p) for p in cc.list_images(str(tmp_path))]
+    got = [os.path.basename(p) for p in cli.list_images(str(tmp_path))]
     assert got == ["a.png", "c.png", "b.jpg", "a.bmp"]                       # grouped by extension, each group sorted
     lst = tmp_path / "list.txt"
     lst.write_text("p1.png\n\n p2.png \n")
-    assert cc.list_images(str(lst)) == ["p1.png", "p2.png"]
-    assert [os.path.basename(p) for p in cc.list_images(str(tmp_path / "*.png"))] == ["a.png", "c.png"]
+    assert cli.list_images(str(lst)) == ["p1.png", "p2.png"]
+    assert [os.path.basename(p) for p in cli.list_images(str(tmp_path / "*.png"))] == ["a.png", "c.png"]
     with pytest.raises(SystemExit):
-        cc.main(["--images", str(tmp_path / "nothing_*.png"), "--output", str(tmp_path / "o")])
+        cli.main(["create", "--images", str(tmp_path / "nothing_*.png"), "--output", str(tmp_path / "o")])

@@ -189,19 +189,19 @@ def test_two_rank_pipeline_matches_single_process(tmp_path, built_lib):
 
 
 def test_cli_entry_points_full_model(tmp_path, built_lib):
-    """python -m pi3_slam_amd.create_offline_chunks / reconstruct_offline with the reference's flags, full-size pi3
+    """python -m pi3_slam_amd.cli create / reconstruct with the reference's flags, full-size pi3
     (recipe weights) + recipe MoGe, undistortion off, 10 frames."""
-    from pi3_slam_amd import create_offline_chunks as cc, reconstruct_offline as ro
+    from pi3_slam_amd import cli
     frames = tmp_path / "frames"
     frames.mkdir()
     _write_frames(str(frames), n=10)
     out = tmp_path / "chunks_out"
-    cc.main(["--images", str(frames), "--output", str(out), "--chunk-length", "6", "--overlap", "2", "--model-path",
+    cli.main(["create", "--images", str(frames), "--output", str(out), "--chunk-length", "6", "--overlap", "2", "--model-path",
              "recipe", "--moge-model-path", "recipe", "--keypoints", "grid", "--max-kp", "64", "--num-workers", "0",
              "--skip-start", "1", "--device-resize", "--hip-graph"])
     man = json.load(open(out / "chunks_manifest.json"))
     assert [(m["start_idx"], m["end_idx"]) for m in man] == [(0, 6), (4, 9)]        # (8, 9) has < 2 frames: dropped
-    ro.main(["--chunks", str(out), "--output", str(tmp_path / "rec"), "--save-observations"])
+    cli.main(["reconstruct", "--chunks", str(out), "--output", str(tmp_path / "rec"), "--save-observations"])
     lines = open(tmp_path / "rec" / "trajectory_tum.txt").read().strip().split("\n")
     assert len(lines) == 1 + 9                                   # 10 frames, the first one skipped
     assert os.path.exists(tmp_path / "rec" / "final_points.ply")

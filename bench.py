@@ -194,11 +194,19 @@ def main() -> None:
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg)
-        print(json.dumps(line))
+        _REAL_STDOUT.write(json.dumps(line) + "\n")
+        _REAL_STDOUT.flush()
     if world > 1:
         import torch.distributed as dist
         dist.destroy_process_group()
 
 
 if __name__ == "__main__":
-    main()
+    # stdout carries exactly ONE line, the JSON record of rank 0; the pipeline's progress prints (per-chunk inference
+    # FPS etc., on every rank) go to stderr
+    _REAL_STDOUT = sys.stdout
+    sys.stdout = sys.stderr
+    try:
+        main()
+    finally:
+        sys.stdout = _REAL_STDOUT

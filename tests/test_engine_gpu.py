@@ -173,3 +173,34 @@ def test_forward_graphed_replays_bit_identical(dev):
         torch.cuda.synchronize()
         assert all(torch.equal(out[k], ref_b[k]) for k in ref_b)
     assert len(eng._graphs) == 2
+
+
+def test_checkpoint_files_load_like_the_reference_layouts(dev, tmp_path):
+    """Pi3Engine from a model.safetensors directory (PyTorchModelHubMixin layout, pi3.py:14-16) and MoGeEngine from a
+    model.pt holding {'model_config', 'model'} (moge/model/v2.py:80-95): same outputs as the engines built from the same
+    values generated on the device."""
+    from safetensors.torch import save_file
+    from pi3_slam_amd.engine import Pi3Engine
+    from pi3_slam_amd.moge import SYNTHETIC_CONFIG, MoGeEngine, recipe_state_dict_cpu as moge_state_dict_cpu
+    from pi3_slam_amd.weights import Pi3Config, load_checkpoint, recipe_state_dict_cpu
+    cfg = Pi3Config(dim=128, enc_depth=1, dec_depth=2, head_depth=1, cam_dim=128, pos_grid=5)
+    sd = recipe_state_dict_cpu(cfg)
+    ckpt_dir = tmp_path / "pi3_ckpt"
+    ckpt_dir.mkdir()
+    save_file({k: v.contiguous() for k, v in sd.items()}, str(ckpt_dir / "model.safetensors"))
+    imgs = torch.rand(1, 3, 3, 42, 56, device=dev, generator=torch.Generator(device=dev).manual_seed(2))
+    a = Pi3Engine(cfg, str(dev)).forward(imgs)
+    b = Pi3Engine(cfg, str(dev), load_checkpoint(str(ckpt_dir))).forward(imgs)
+    assert all(torch.equal(a[k], b[k]) for k in a)
+    with pytest.raises((KeyError, AssertionError)):
+        Pi3Engine(cfg, str(dev), {k: v for k, v in sd.items() if "decoder.0." not in k})     # incomplete checkpoint
+    # MoGe: a model.pt with the checkpoint's own config
+    ref = MoGeEngine.from_pretrained("recipe", str(dev))
+    state = moge_state_dict_cpu(SYNTHETIC_CONFIG)       # numpy recipe: bit-identical to the device fill (tested)
+    pt = tmp_path / "model.pt"
+    torch.save({"model_config": SYNTHETIC_CONFIG, "model": state}, str(pt))
+    m2 = MoGeEngine.from_pretrained(str(pt), str(dev))
+    frame = torch.rand(3, 84, 112, device=dev, generator=torch.Generator(device=dev).manual_seed(4))
+    d1, d2 = ref.infer(frame)["depth"], m2.infer(frame)["depth"]
+    assert torch.equal(torch.nan_to_num(d1, posinf=1e9), torch.nan_to_num(d2, posinf=1e9))
+

@@ -191,7 +191,9 @@ class OfflineChunkCreator:
         masks = self._compute_masks(pi3_result)[0]
 
         if self.moge_model is not None:
-            moge_depth = self.moge_model.infer(imgs_dev[0, 0])["depth"]
+            infer = (self.moge_model.infer_graphed if self.config.hip_graph and hasattr(self.moge_model, "infer_graphed")
+                     else self.moge_model.infer)
+            moge_depth = infer(imgs_dev[0, 0])["depth"]
             pi3_depth = pi3_result["local_points"][0, 0][..., 2]
             scale = self._get_scale_factor_for_pi3(moge_depth, pi3_depth, masks[0])
             ops.apply_scale(scale.reshape(1), pi3_result["local_points"], pi3_result["points"],

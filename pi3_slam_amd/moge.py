@@ -486,6 +486,29 @@ class MoGeEngine:
         return out
 
     @torch.no_grad()
+    def infer_graphed(self, image: torch.Tensor, resolution_level: int = 9) -> Dict:
+        """infer() replayed as one captured hipGraph per image shape.  MoGe is ~400 small single-image kernels that run
+        while the GPU has nothing else to do (after the pi3 forward of the chunk): launched one by one they are
+        launch-latency bound; as a graph they run back to back.  Same results bit for bit; the returned tensors are the
+        graph's static outputs (valid until the next call)."""
+        if image.dim() == 4:
+            image = image[0]
+        key = (tuple(image.shape), resolution_level)
+        graphs = self.__dict__.setdefault("_graphs", {})
+        if key not in graphs:
+            static_in = image.to(self.device, torch.float32).contiguous().clone()
+            self.infer(static_in, resolution_level=resolution_level)        # allocates the cached tables
+            torch.cuda.synchronize(self.device)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                static_out = self.infer(static_in, resolution_level=resolution_level)
+            graphs[key] = (graph, static_in, static_out)
+        graph, static_in, static_out = graphs[key]
+        static_in.copy_(image, non_blocking=True)
+        graph.replay()
+        return static_out
+
+    @torch.no_grad()
     def infer(self, image: torch.Tensor, num_tokens: Optional[int] = None, resolution_level: int = 9) -> Dict:
         """MoGeModel.infer (v2.py:181-290) with the pipeline's defaults.  image (3, H, W) or (1, 3, H, W) fp32 in
         [0, 1].  Returns device tensors: depth (H, W) with +inf outside the mask, mask (H, W) bool, intrinsics (3, 3)."""
@@ -509,7 +532,9 @@ class MoGeEngine:
         focal = fs["focal"]
         fx = focal / 2 * (1 + ar ** 2) ** 0.5 / ar
         fy = focal / 2 * (1 + ar ** 2) ** 0.5
-        K = torch.zeros(3, 3, device=self.device)
-        K[0, 0], K[1, 1], K[0, 2], K[1, 2], K[2, 2] = fx[0], fy[0], 0.5, 0.5, 1.0
+        if "K_base" not in self._consts:   # the constant entries live on the device (no host scalar in a graph capture)
+            self._consts["K_base"] = torch.tensor([[0.0, 0.0, 0.5], [0.0, 0.0, 0.5], [0.0, 0.0, 1.0]], device=self.device)
+        K = self._consts["K_base"].clone()
+        K[0, 0], K[1, 1] = fx[0], fy[0]
         return {"depth": depth, "mask": mask.bool(), "intrinsics": K, "points_affine": pts, "focal": focal[0],
                 "shift": fs["shift"][0]}

@@ -45,9 +45,15 @@ int pi3_gemm(const void* A, long lda, const void* W, long ldw, int M, int N, int
 
 /* F.scaled_dot_product_attention, non-causal, head_dim 64 (pi3/models/layers/attention.py:102-107, 336-341).
  * q/k/v: bf16, element (b, s, h, d) at ptr[b*batch_stride + s*tok_stride + h*64 + d]; q PRE-SCALED by
- * 64^-0.5 * log2(e).  o: bf16 [B][S][H*64] with the given strides. */
+ * 64^-0.5 * log2(e).  o: bf16 [B][S][H*64] with the given strides.
+ * k2max_ws: caller-provided workspace of B*H floats (this library allocates nothing) for max_s |k[b,s,h,:]|^2, or
+ * NULL.  With it the long-sequence kernel takes its bounded-score path (no running max) for every wave whose scores
+ * are provably inside the fp32/bf16 exponent range, otherwise - and always when NULL - the online-max loop; both are
+ * exact.  k2max_ready = 0: the call zeroes the workspace and fills it with a pre-pass over k; 1: the workspace already
+ * holds the maxima (written by pi3_gemm's fused q/k epilogue, see pi3_gemm_qkv). */
 int pi3_attention(const void* q, const void* k, const void* v, long tok_stride, long batch_stride, void* o,
-                  long o_tok_stride, long o_batch_stride, int B, int S, int H, int head_dim, void* stream);
+                  long o_tok_stride, long o_batch_stride, int B, int S, int H, int head_dim, float* k2max_ws,
+                  int k2max_ready, void* stream);
 
 /* nn.LayerNorm(D, eps) over rows of x (block.py:282,296; vision_transformer.py:271).  If nspecial > 0 (f32 out only),
  * rows with (row % T) < nspecial are replaced by special[row % T][:]: Pi3.decode's register-token concat

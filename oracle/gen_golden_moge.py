@@ -26,7 +26,56 @@ from pi3_slam_amd.recipe import fnv1a64, recipe_unit  # noqa: E402
 CASES = {  # name: (H, W, resolution_level)
     "moge_small": (84, 112, 0),
     "moge_chunk": (308, 406, 9),      # the pipeline's frame size and default resolution level
+    # pinhole-consistent point maps (see pinhole_overrides): focal > 0, shift well conditioned -> tight depth gate
+    "moge_pinhole_small": (84, 112, 0),
+    "moge_pinhole_chunk": (308, 406, 9),
 }
+
+PINHOLE = dict(A=6.0, f0=0.9, b=0.5, c=-0.4, d=0.3, noise=0.25)
+
+
+def pinhole_overrides(sd):
+    """Edit a recipe state dict (SYNTHETIC_CONFIG) in place so that the predicted point map is what a pinhole camera
+    sees, plus a little network-dependent structure: with remap_output='exp' the map is (x z, y z, z), z = exp(z_raw),
+    so xy_raw = uv / f0 makes it EXACTLY pinhole (focal f0, shift 0) for any z_raw.  The UV planes enter the neck's
+    finest level through a 1x1 conv (v2.py:141-147); channels 0 / 1 are turned into clean carriers of A.u / A.v
+    (every other producer of those two channels on the finest level is zeroed), the points head reads xy_raw = uv / f0
+    and z_raw = b u + c v + d from them, and the remaining 30 random channels contribute `noise` x their recipe weight.
+    Random recipe weights alone give a map that no camera could have produced: the shift solve is then ill-conditioned
+    and the focal comes out negative (round-1 fixtures), which is not the regime the pipeline runs in."""
+    P = PINHOLE
+    A = P["A"]
+    import torch as _t
+
+    def rows01(name, bias=True):
+        sd[name + ".weight"][0:2] = 0.0
+        if bias:
+            sd[name + ".bias"][0:2] = 0.0
+
+    for stack in ("neck", "points_head"):
+        rows01(f"{stack}.resamplers.3.1")                 # 3x3 conv after the last transposed conv
+        rows01(f"{stack}.res_blocks.4.0.layers.5")         # second conv of the finest res block (residual branch)
+    w = sd["neck.input_blocks.4.weight"]                   # [32, 2, 1, 1] on the UV planes
+    w[0:2] = 0.0
+    w[0, 0, 0, 0], w[1, 1, 0, 0] = A, A
+    sd["neck.input_blocks.4.bias"][0:2] = 0.0
+    for name in ("neck.output_blocks.4", "points_head.input_blocks.4"):   # [32, 32, 1, 1] pass-through of ch 0, 1
+        rows01(name)
+        sd[name + ".weight"][0, 0, 0, 0] = 1.0
+        sd[name + ".weight"][1, 1, 0, 0] = 1.0
+    wo, bo = sd["points_head.output_blocks.4.weight"], sd["points_head.output_blocks.4.bias"]   # [3, 32, 1, 1]
+    wo *= P["noise"]
+    wo[:, 0:2] = 0.0
+    wo[0, 0, 0, 0] = 1.0 / (A * P["f0"])
+    wo[1, 1, 0, 0] = 1.0 / (A * P["f0"])
+    wo[2, 0, 0, 0], wo[2, 1, 0, 0] = P["b"] / A, P["c"] / A
+    bo[:] = _t.tensor([0.0, 0.0, P["d"]])
+    return sd
+
+
+def case_state_dict(name: str):
+    sd = recipe_state_dict_cpu(SYNTHETIC_CONFIG)
+    return pinhole_overrides(sd) if "pinhole" in name else sd
 
 
 def moge_image(name: str, H: int, W: int) -> torch.Tensor:
@@ -69,12 +118,15 @@ def main() -> None:
     from moge.model.v2 import MoGeModel
     from oracle import moge_ref
 
-    sd = recipe_state_dict_cpu(SYNTHETIC_CONFIG)
     model = MoGeModel(**SYNTHETIC_CONFIG).eval()
-    missing, unexpected = model.load_state_dict(sd, strict=False)
-    assert not missing and not unexpected, (missing, unexpected)
     out_dir = os.path.join(REPO, "tests", "golden")
+    only = sys.argv[1:]
     for name, (H, W, level) in CASES.items():
+        if only and name not in only:
+            continue
+        sd = case_state_dict(name)
+        missing, unexpected = model.load_state_dict(sd, strict=False)
+        assert not missing and not unexpected, (missing, unexpected)
         img = moge_image(name, H, W)
         ref = model.infer(img, resolution_level=level, use_fp16=False)
         lo, hi = SYNTHETIC_CONFIG["num_tokens_range"]
@@ -94,7 +146,19 @@ def main() -> None:
             f16 = model.forward(img[None], num_tokens=ntok)
         dz = (f16["points"][0, ..., 2].float() - fwd["points"][0, ..., 2]).abs()
         print(f"   reference bf16-autocast vs fp32 on affine z: mean {dz.mean().item():.3e} max {dz.max().item():.3e}")
-        save = dict(shape=np.array([H, W, level]), depth=ref["depth"].numpy(), mask=np.packbits(m.numpy()),
+        # the same anchor on the quantity the pipeline consumes: the reference's own infer() tail (v2.py:238-274,
+        # restated in oracle/moge_ref.infer_tail and checked against the real infer() just above) applied to the
+        # reference's bf16-autocast network outputs, against its fp32 depth
+        t16 = moge_ref.infer_tail({k: (v.float() if torch.is_tensor(v) else v) for k, v in f16.items()}, W / H)
+        both = (t16["mask"] & m).numpy()
+        rel = (np.abs(t16["depth"].numpy() - ref["depth"].numpy())[both] / ref["depth"].numpy()[both])
+        focal_ref = float(orc["focal"])
+        print(f"   focal {focal_ref:.4f} shift {float(orc['shift']):.4f};  bf16-autocast depth rel err: median "
+              f"{np.median(rel):.3e} mean {rel.mean():.3e} p99 {np.quantile(rel, 0.99):.3e};  focal16 {float(t16['focal']):.4f} "
+              f"shift16 {float(t16['shift']):.4f}")
+        save = dict(focal_shift=np.array([focal_ref, float(orc["shift"])]),
+                    bf16err_depth=np.array([np.median(rel), rel.mean(), np.quantile(rel, 0.99)]),
+                    bf16_focal_shift=np.array([float(t16["focal"]), float(t16["shift"])]),shape=np.array([H, W, level]), depth=ref["depth"].numpy(), mask=np.packbits(m.numpy()),
                     points_affine_z=fwd["points"][0, ..., 2].numpy(), mask_prob=fwd["mask"][0].numpy(),
                     metric_scale=fwd["metric_scale"].numpy(), intrinsics=ref["intrinsics"].numpy(),
                     bf16err_z=np.array([dz.mean().item(), dz.max().item()]))

@@ -206,6 +206,12 @@ def moge_infer(sd, cfg, image: torch.Tensor, resolution_level: int = 9) -> Dict[
     lo, hi = cfg.get("num_tokens_range", [1200, 3600])
     num_tokens = int(lo + (resolution_level / 9) * (hi - lo))
     out = moge_forward(sd, cfg, image, num_tokens)
+    return infer_tail(out, ar)
+
+
+def infer_tail(out: Dict[str, torch.Tensor], ar: float) -> Dict[str, torch.Tensor]:
+    """The post-network part of MoGeModel.infer (v2.py:238-274): focal / shift recovery, intrinsics, depth = z + shift,
+    x metric scale, mask -> inf.  `out`: {'points' (1,H,W,3), 'mask' (1,H,W) probabilities, 'metric_scale' (1,)}."""
     points, mask = out["points"], out.get("mask")
     mask_binary = mask > 0.5 if mask is not None else None
     focal, shift = post_ref.recover_focal_shift(points, mask_binary if mask_binary is not None

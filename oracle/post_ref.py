@@ -222,6 +222,36 @@ def umeyama(x: np.ndarray, y: np.ndarray):
     return s, R, t, M
 
 
+def horn_sim3(x: np.ndarray, y: np.ndarray):
+    """Second, independent closed form for the same least-squares problem min sum |y - (s R x + t)|^2: Horn 1987
+    ("Closed-form solution of absolute orientation using unit quaternions", JOSA A 4(4)): R from the dominant
+    eigenvector of the symmetric 4x4 matrix N built from M = sum xc yc^T (eq. 25 there), the asymmetric scale
+    s = sum yc . (R xc) / sum |xc|^2 (section 2.D, errors in y only), t = my - s R mx.  It never returns a reflection,
+    so it must agree with umeyama() (SVD + determinant fix) wherever the optimum is unique.  pytheia's own arithmetic
+    is not available offline (parity unpinned); two independent derivations agreeing is the strongest check left."""
+    x, y = np.asarray(x, np.float64), np.asarray(y, np.float64)
+    mx, my = x.mean(0), y.mean(0)
+    xc, yc = x - mx, y - my
+    Mm = xc.T @ yc                        # M_ab = sum xc_a yc_b
+    Sxx, Sxy, Sxz = Mm[0]
+    Syx, Syy, Syz = Mm[1]
+    Szx, Szy, Szz = Mm[2]
+    N = np.array([[Sxx + Syy + Szz, Syz - Szy, Szx - Sxz, Sxy - Syx],
+                  [Syz - Szy, Sxx - Syy - Szz, Sxy + Syx, Szx + Sxz],
+                  [Szx - Sxz, Sxy + Syx, -Sxx + Syy - Szz, Syz + Szy],
+                  [Sxy - Syx, Szx + Sxz, Syz + Szy, -Sxx - Syy + Szz]])
+    ev, evec = np.linalg.eigh(N)
+    w, qx, qy, qz = evec[:, np.argmax(ev)]
+    R = np.array([[1 - 2 * (qy * qy + qz * qz), 2 * (qx * qy - w * qz), 2 * (qx * qz + w * qy)],
+                  [2 * (qx * qy + w * qz), 1 - 2 * (qx * qx + qz * qz), 2 * (qy * qz - w * qx)],
+                  [2 * (qx * qz - w * qy), 2 * (qy * qz + w * qx), 1 - 2 * (qx * qx + qy * qy)]])
+    s = float((yc * (xc @ R.T)).sum() / (xc ** 2).sum())
+    t = my - s * R @ mx
+    M = np.eye(4)
+    M[:3, :3], M[:3, 3] = s * R, t
+    return s, R, t, M
+
+
 def align_chunks(pts_ref: np.ndarray, pts_qry: np.ndarray, kp_ref: np.ndarray, kp_qry: np.ndarray,
                  last_ref_pose: np.ndarray, use_filter: bool = True,
                  w_ref: Optional[np.ndarray] = None, w_qry: Optional[np.ndarray] = None):

@@ -1,7 +1,7 @@
 """Overlap-based Sim(3) chunk alignment: mirror of utils/reconstruction_alignment.py (create_view_graph_matches :16-37,
 align_and_refine_reconstructions :40-198, steps 1-3 + the transform), operating on chunk-file dictionaries instead of
-pytheia Reconstructions.  The bundle adjustment of steps 4-5 (:107-171) is third-party Ceres code behind pytheia and is
-out of scope; the returned info dict keeps the reference's keys for the parts that exist.
+pytheia Reconstructions.  The bundle adjustment of steps 4-5 (:107-171) lives in bundle_adjust.py (SURVEY.md §8f rank
+3); the returned info dict keeps the reference's keys.
 All arithmetic runs in csrc/sim3.hip."""
 from __future__ import annotations
 
@@ -17,19 +17,27 @@ def create_view_graph_matches(chunk_size: int, overlap_size: int) -> List[Tuple[
     return [(chunk_size - overlap_size + i, i) for i in range(overlap_size)]
 
 
+def _chunk_frame(chunk: Dict) -> Dict:
+    """The chunk's data in ITS OWN frame: what the chunk file holds.  transform_chunk() stashes it on the first
+    transform, so a chunk that already sits in the global frame can still be aligned on its original (fp16, chunk-frame)
+    values; see align_and_refine_reconstructions."""
+    return chunk.get("_chunk_frame") or chunk
+
+
 def _overlap_block(chunk: Dict[str, torch.Tensor], frames: List[int], device) -> Dict[str, torch.Tensor]:
     idx = torch.tensor(frames, dtype=torch.long)
+    src = _chunk_frame(chunk)
     out = {}
     for k in ("points", "keypoints", "masks"):
-        t = chunk[k]
+        t = src[k] if k == "points" else chunk[k]
         out[k] = t[idx.to(t.device)].to(device).contiguous()
     return out
 
 
 def estimate_sim3(chunk_ref: Dict, chunk_qry: Dict, view_graph_matches: List[Tuple[int, int]], device="cuda:0",
                   use_masks: bool = False, use_filter: bool = True) -> torch.Tensor:
-    """Relative similarity qry -> ref from the overlap views (steps 1-3).  Returns the f64 device vector of
-    pi3_sim3_umeyama: s, R(9), t(3), M(16), n_used, n_common, median, rms.
+    """Relative similarity qry -> ref from the overlap views (steps 1-3), BOTH chunks taken in their own (chunk-file)
+    frames.  Returns the f64 device vector of pi3_sim3_umeyama: s, R(9), t(3), M(16), n_used, n_common, median, rms.
     use_masks=True weights the pairs by both chunks' validity masks (the 'weighted' variant; the reference passes all
     common points, reconstruction_alignment.py:97)."""
     n_ref = int(chunk_ref["points"].shape[0])
@@ -41,40 +49,81 @@ def estimate_sim3(chunk_ref: Dict, chunk_qry: Dict, view_graph_matches: List[Tup
     qry = _overlap_block(chunk_qry, [q for _, q in pairs], device)
     idx = ops.sim3_match_keypoints(ref["keypoints"].to(torch.float16), qry["keypoints"].to(torch.float16))
     # "last camera" of the reference reconstruction = its last view (reconstruction_alignment.py:79)
-    last_pose = chunk_ref["camera_poses"][n_ref - 1].to(device, torch.float32).contiguous()
+    last_pose = _chunk_frame(chunk_ref)["camera_poses"][n_ref - 1].to(device, torch.float32).contiguous()
     w_ref = ref["masks"].reshape(len(pairs), -1).to(torch.uint8).contiguous() if use_masks else None
     w_qry = qry["masks"].reshape(len(pairs), -1).to(torch.uint8).contiguous() if use_masks else None
     return ops.sim3_umeyama(ref["points"].to(torch.float16), qry["points"].to(torch.float16), idx, last_pose,
                             w_ref, w_qry, use_filter)
 
 
-def transform_chunk(chunk: Dict, M4: torch.Tensor, device="cuda:0") -> None:
+def sim3_accepted(out33_cpu: torch.Tensor) -> bool:
+    """The one acceptance rule of a closed-form solve, shared by the sequential and the chunk-parallel path:
+    at least 3 pairs survived and every number of the similarity is finite."""
+    return int(out33_cpu[29].item()) >= 3 and bool(torch.isfinite(out33_cpu[:29]).all())
+
+
+def global_transform(chunk: Dict) -> torch.Tensor:
+    """4x4 f64 similarity chunk frame -> global frame accumulated on this chunk (identity if never transformed)."""
+    G = chunk.get("_sim3_global")
+    return torch.eye(4, dtype=torch.float64) if G is None else G
+
+
+def transform_chunk(chunk: Dict, M4: torch.Tensor, device="cuda:0", absolute: bool = False) -> None:
     """TransformReconstruction4 (reconstruction_alignment.py:105) on a chunk dict, in place: world points and
-    cam->world poses.  Points keep their storage dtype (fp16 in chunk files)."""
-    pts = chunk["points"].to(device, torch.float32).contiguous()
-    poses = chunk["camera_poses"].to(device, torch.float32).contiguous()
-    ops.sim3_apply(M4.to(device), pts, poses)
-    chunk["points"] = pts.to(chunk["points"].dtype).to(chunk["points"].device)
-    chunk["camera_poses"] = poses.to(chunk["camera_poses"].device)
+    cam->world poses.
+
+    The reference holds a reconstruction in Eigen doubles and applies every Sim(3) in double
+    (utils/chunk_reconstruction.py:130, reconstruction_alignment.py:105).  Here the chunk file's fp16 points are kept
+    untouched under chunk['_chunk_frame']; the accumulated similarity lives in chunk['_sim3_global'] (f64) and
+    chunk['points'] / ['camera_poses'] are always (accumulated similarity) x (original values), stored as fp32:
+    nothing is ever re-quantised to fp16 in the global frame (ulp 1.6 cm at 16-32 m) and repeated transforms do not
+    stack rounding.  absolute=True replaces the accumulated similarity by M4 instead of composing M4 with it."""
+    if "_chunk_frame" not in chunk:
+        chunk["_chunk_frame"] = {"points": chunk["points"], "camera_poses": chunk["camera_poses"]}
+    M4 = M4.detach().to(device, torch.float64).reshape(4, 4).contiguous()
+    if absolute or "_sim3_global" not in chunk:
+        G = M4
+    else:   # M4 . G_old, on the device like every other 4x4 product of the path (pi3_sim3_compose_prefix)
+        G = ops.sim3_compose_prefix(torch.stack([M4.reshape(16), chunk["_sim3_global"].to(device).reshape(16)])
+                                    .contiguous())[1].reshape(4, 4)
+    src = chunk["_chunk_frame"]
+    pts = src["points"].to(device, torch.float32).contiguous()      # fresh fp32 copies of the originals
+    poses = src["camera_poses"].to(device, torch.float32).contiguous()
+    if pts.data_ptr() == src["points"].data_ptr():
+        pts = pts.clone()
+    if poses.data_ptr() == src["camera_poses"].data_ptr():
+        poses = poses.clone()
+    ops.sim3_apply(G.contiguous(), pts, poses)
+    chunk["_sim3_global"] = G.cpu()
+    chunk["points"] = pts.to(src["points"].device)
+    chunk["camera_poses"] = poses.to(src["camera_poses"].device)
 
 
 def align_and_refine_reconstructions(chunk_ref: Dict, chunk_qry: Dict, view_graph_matches: List[Tuple[int, int]],
                                      use_inverse_depth: bool = False, device="cuda:0",
                                      use_masks: bool = False) -> Tuple[bool, Dict]:
     """Same contract as the reference (returns (False, {"error": ...}) instead of raising): chunk_qry is transformed
-    in place into chunk_ref's frame."""
+    in place into chunk_ref's frame.
+
+    chunk_ref may already sit in the global frame (progressive alignment).  The relative similarity T (qry chunk frame
+    -> ref chunk frame) is solved on both chunks' ORIGINAL fp16 values and composed with the reference's accumulated
+    similarity, G_qry = G_ref . T.  For the closed-form step this equals aligning to the transformed reference (the
+    match, the strict near-half filter and the Umeyama optimum are similarity-equivariant; tested), it is what the
+    chunk-parallel path does, and it never feeds re-rounded global-frame points into the next solve."""
     print("🔄 Starting reconstruction alignment (closed-form Sim(3) over the overlap views)...")
     try:
         out = estimate_sim3(chunk_ref, chunk_qry, view_graph_matches, device, use_masks)
         o = out.cpu()
         n_used = int(o[29].item())
-        if n_used < 3 or not torch.isfinite(o[:29]).all():
+        if not sim3_accepted(o):
             print("❌ Sim3 alignment failed")
             return False, {"error": "sim3_failed", "num_common_tracks": n_used}
-        transform_chunk(chunk_qry, out[13:29].contiguous(), device)
+        G = ops.sim3_compose_prefix(torch.stack([global_transform(chunk_ref).reshape(16).to(device),
+                                                 out[13:29]]).contiguous())[1].reshape(4, 4)
+        transform_chunk(chunk_qry, G, device, absolute=True)
         info = {"success": True, "num_common_tracks": n_used,
                 "sim3_summary": {"success": True, "alignment_error": float(o[32].item()), "scale": float(o[0].item()),
-                                 "matrix": o[13:29].reshape(4, 4).clone()},
+                                 "matrix": o[13:29].reshape(4, 4).clone(), "global_matrix": G.cpu().clone()},
                 "priors_set": 0, "bundle_adjustment": None}
         return True, info
     except Exception as e:  # noqa: BLE001 - the reference swallows and reports (reconstruction_alignment.py:194-198)

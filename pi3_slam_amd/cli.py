@@ -42,7 +42,7 @@ RECON_FLAGS: Sequence[Tuple[str, Dict]] = (
     ("--chunk-length", dict(type=int, default=None)),
     ("--overlap", dict(type=int, default=None)),
     ("--max-observations-per-track", dict(type=int, default=5)),
-    ("--device", dict(default="cuda:0")),
+    ("--device", dict(default="cuda")),
 )
 RECON_SWITCHES = (("--save-per-chunk", "per-chunk ply files as well"),
                   ("--use-inverse-depth", "accepted for compatibility (no bundle adjustment in this build)"),

@@ -267,11 +267,12 @@ __global__ __launch_bounds__(256, MIN_WAVES) void attn_fwd_kernel(AttnParams p) 
 }
 
 int pi3_attention64_launch(const void* q, const void* k, const void* v, long tok_stride, long batch_stride, void* o,
-                           long o_tok_stride, long o_batch_stride, int B, int S, int H, hipStream_t stream);
+                           long o_tok_stride, long o_batch_stride, int B, int S, int H, float* k2max_ws,
+                           int k2max_ready, hipStream_t stream);
 
 extern "C" int pi3_attention(const void* q, const void* k, const void* v, long tok_stride, long batch_stride,
                              void* o, long o_tok_stride, long o_batch_stride, int B, int S, int H, int head_dim,
-                             void* stream) {
+                             float* k2max_ws, int k2max_ready, void* stream) {
   if (!q || !k || !v || !o || B <= 0 || S <= 0 || H <= 0 || head_dim != 64) {
     pi3_set_error("pi3_attention: bad arguments B=%d S=%d H=%d head_dim=%d (head_dim must be 64)", B, S, H, head_dim);
     return PI3_ERR_ARG;
@@ -289,7 +290,7 @@ extern "C" int pi3_attention(const void* q, const void* k, const void* v, long t
   }
   if (impl == 2 || (impl == 0 && S >= 4096))
     return pi3_attention64_launch(q, k, v, tok_stride, batch_stride, o, o_tok_stride, o_batch_stride, B, S, H,
-                                  (hipStream_t)stream);
+                                  k2max_ws, k2max_ready, (hipStream_t)stream);
   AttnParams p;
   p.q = (const bf16_t*)q; p.k = (const bf16_t*)k; p.v = (const bf16_t*)v;
   p.tok_stride = tok_stride; p.batch_stride = batch_stride;
@@ -307,6 +308,7 @@ extern "C" int pi3_attention(const void* q, const void* k, const void* v, long t
     const char* e = getenv("PI3_ATTN_WAVES");
     waves = e ? atoi(e) : 3;
   }
+#ifdef PI3_DEV_ABLATIONS   // timing-only variants with WRONG results: development builds only, never in the product .so
   static int abl = -1;
   if (abl < 0) {
     const char* e = getenv("PI3_ATTN_ABL");
@@ -315,6 +317,7 @@ extern "C" int pi3_attention(const void* q, const void* k, const void* v, long t
 #define ABL_CASE(K) if (abl == K) { hipLaunchKernelGGL((attn_fwd_kernel<3, K>), dim3((unsigned)nwg), dim3(256), 0, (hipStream_t)stream, p); return pi3_check_launch("attn_fwd_abl"); }
   ABL_CASE(1) ABL_CASE(2) ABL_CASE(3) ABL_CASE(4) ABL_CASE(5) ABL_CASE(6)
 #undef ABL_CASE
+#endif
   if (waves >= 4)
     hipLaunchKernelGGL(attn_fwd_kernel<4>, dim3((unsigned)nwg), dim3(256), 0, (hipStream_t)stream, p);
   else if (waves == 2)

@@ -449,19 +449,11 @@ __global__ __launch_bounds__(256) void a64_knorm_kernel(const bf16_t* __restrict
     atomicMax((unsigned*)&out[b * H + head], __float_as_uint(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]))));
 }
 
-// per-device ring of scratch slots for k2max (one process drives one stream per device; 16 launches may be in flight)
-static float* a64_scratch(int n) {
-  static float* buf[16] = {nullptr};
-  static unsigned slot[16] = {0};
-  int dev = -1;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16 || n > 4096) return nullptr;
-  if (!buf[dev] && hipMalloc((void**)&buf[dev], 16 * 4096 * sizeof(float)) != hipSuccess) return nullptr;
-  return buf[dev] + 4096 * (slot[dev]++ & 15u);
-}
-
 // Called by pi3_attention (attn.hip) for long sequences; same argument meaning.
+// k2max_ws: caller-provided [B*H] floats (or null -> online-max loop); k2max_ready: already filled by the producer.
 int pi3_attention64_launch(const void* q, const void* k, const void* v, long tok_stride, long batch_stride, void* o,
-                           long o_tok_stride, long o_batch_stride, int B, int S, int H, hipStream_t stream) {
+                           long o_tok_stride, long o_batch_stride, int B, int S, int H, float* k2max_ws,
+                           int k2max_ready, hipStream_t stream) {
   Attn64Params p;
   p.q = (const bf16_t*)q; p.k = (const bf16_t*)k; p.v = (const bf16_t*)v;
   p.tok_stride = tok_stride; p.batch_stride = batch_stride;
@@ -492,17 +484,16 @@ int pi3_attention64_launch(const void* q, const void* k, const void* v, long tok
   hipMemsetAsync(dbgbuf, 0, 2048 * 8, stream);
   p.dbg = dbgbuf;
 #endif
-  if (nomax) {
-    float* scratch = a64_scratch(B * H);
-    if (scratch) {
-      if (hipMemsetAsync(scratch, 0, (size_t)B * H * sizeof(float), stream) != hipSuccess) {
+  if (nomax && k2max_ws) {
+    if (!k2max_ready) {
+      if (hipMemsetAsync(k2max_ws, 0, (size_t)B * H * sizeof(float), stream) != hipSuccess) {
         pi3_set_error("attn_fwd64: hipMemsetAsync failed");
         return PI3_ERR_LAUNCH;
       }
       hipLaunchKernelGGL(a64_knorm_kernel, dim3(A64_KNORM_BLOCKS, H, B), dim3(256), 0, stream, p.k, tok_stride,
-                         batch_stride, S, H, scratch);
-      p.k2max = scratch;
+                         batch_stride, S, H, k2max_ws);
     }
+    p.k2max = k2max_ws;
   }
   static int msum = -1;   // PI3_ATTN_MSUM: 1 = row sums on the matrix pipe in the bounded-score loop (A/B knob)
   if (msum < 0) {

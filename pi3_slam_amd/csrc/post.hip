@@ -169,7 +169,12 @@ extern "C" int pi3_apply_scale(const float* scale_dev, float* local_points, floa
 // :231-241.  The reference normalises with x/(W-1)*2-1 and then calls grid_sample(align_corners=False,
 // padding_mode='border'), whose CPU kernel un-normalises with (g+1)*(W/2)-0.5 and clips to [0, W-1]
 // (ATen GridSamplerKernel.cpp): effective index x*W/(W-1)-0.5.  points / local_points / colours: bilinear
-// (nw = s*e, ne = s*w, sw = n*e, se = n*w; sum in that order); conf / mask: nearest = rint (half to even).
+// (nw = s*e, ne = s*w, sw = n*e, se = n*w); conf / mask: nearest = rint (half to even).
+// Rounding order = the vectorised ATen CPU kernel as built for x86 with FMA (what the reference executes: the gather
+// runs on CPU tensors, offline_chunk_creator.py:204-228, keypoint_extraction.py:222): gcc contracts
+// (g + 1) * (W/2) - 0.5 into one fma and nw_val*nw + ne_val*ne + sw_val*sw + se_val*se into
+// fma(se_val, se, fma(sw_val, sw, fma(ne_val, ne, nw_val*nw))).  Restated with explicit fmaf here (contraction off for
+// everything else), this reproduces F.grid_sample bit for bit (tests/test_post_gpu.py gates 0 ulp / 0 LSB).
 // Colours: uint8 truncation of 255*bilinear, then fp16 (so 0..255 values).  One thread per (frame, keypoint).
 // ---------------------------------------------------------------------------------------------------------------
 struct Bil { int x0, y0; float nw, ne, sw, se; int xn, yn; };
@@ -179,8 +184,8 @@ __device__ __forceinline__ Bil bil_setup(float kx, float ky, int H, int W) {
   Bil b;
   const float gx = (kx / (float)(W - 1)) * 2.0f - 1.0f;
   const float gy = (ky / (float)(H - 1)) * 2.0f - 1.0f;
-  float x = (gx + 1.0f) * ((float)W / 2.0f) - 0.5f;
-  float y = (gy + 1.0f) * ((float)H / 2.0f) - 0.5f;
+  float x = __builtin_fmaf(gx + 1.0f, (float)W / 2.0f, -0.5f);
+  float y = __builtin_fmaf(gy + 1.0f, (float)H / 2.0f, -0.5f);
   x = fminf((float)(W - 1), fmaxf(x, 0.0f));
   y = fminf((float)(H - 1), fmaxf(y, 0.0f));
   const float xw = floorf(x), yn = floorf(y);
@@ -200,7 +205,7 @@ __device__ __forceinline__ float bil_sample(const float* __restrict__ base, long
   const float vne = xe ? p[sx] : 0.f;
   const float vsw = ys ? p[sy] : 0.f;
   const float vse = (xe && ys) ? p[sy + sx] : 0.f;
-  return ((vnw * b.nw + vne * b.ne) + vsw * b.sw) + vse * b.se;
+  return __builtin_fmaf(vse, b.se, __builtin_fmaf(vsw, b.sw, __builtin_fmaf(vne, b.ne, vnw * b.nw)));
 }
 
 __global__ __launch_bounds__(256) void gather_keypoints_kernel(

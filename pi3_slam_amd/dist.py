@@ -45,6 +45,14 @@ def local_device_index() -> int:
     return int(os.environ.get("LOCAL_RANK", "0")) % n
 
 
+def resolve_device(device: Optional[str]) -> str:
+    """'cuda' / None -> this rank's card (cuda:LOCAL_RANK): the card the nccl process group is bound to.  An explicit
+    'cuda:N' is honoured (single-process use, or tests that share one card between ranks)."""
+    if device is None or str(device) == "cuda":
+        return f"cuda:{local_device_index()}"
+    return str(device)
+
+
 def gather_objects(obj, dst: int = 0):
     """All ranks' python objects on rank dst (None elsewhere); works on gloo and nccl process groups."""
     world = dist.get_world_size()
@@ -59,7 +67,7 @@ def shard_chunks(n_chunks: int, rank: int, world: int) -> List[int]:
     return list(range(rank, n_chunks, world))
 
 
-def pack_boundary(chunk: Dict[str, torch.Tensor], overlap: int, K: int) -> torch.Tensor:
+def pack_boundary(chunk: Dict[str, torch.Tensor], overlap: int, K: int, device="cpu") -> torch.Tensor:
     """Flat fp32 boundary block of one chunk: head (first ov views) and tail (last ov views) of keypoints (as fp16 bit
     patterns widened to fp32-exact integers), world points, validity, and the last camera pose.
     Layout: [n_frames, head_kp(ov*K*2), head_pts(ov*K*3), head_mask(ov*K), tail_kp, tail_pts, tail_mask, pose(16)]."""
@@ -70,19 +78,26 @@ def pack_boundary(chunk: Dict[str, torch.Tensor], overlap: int, K: int) -> torch
         kp = chunk["keypoints"][sl].to(torch.float16).contiguous().view(torch.int16).to(torch.float32)
         pt = chunk["points"][sl].to(torch.float16).contiguous().view(torch.int16).to(torch.float32)
         mk = chunk["masks"][sl].reshape(-1).to(torch.float32)
-        out = torch.zeros(overlap * K * 6)
+        out = torch.zeros(overlap * K * 6, device=device)
+        kp, pt, mk = kp.to(device), pt.to(device), mk.to(device)
         out[: ov * K * 2] = kp.reshape(-1)
         out[overlap * K * 2: overlap * K * 2 + ov * K * 3] = pt.reshape(-1)
         out[overlap * K * 5: overlap * K * 5 + ov * K] = mk
         return out
 
     head, tail = blk(slice(0, ov)), blk(slice(n - ov, n))
-    pose = chunk["camera_poses"][n - 1].reshape(-1).to(torch.float32)
-    return torch.cat([torch.tensor([float(n)]), head, tail, pose])
+    pose = chunk["camera_poses"][n - 1].reshape(-1).to(device, torch.float32)
+    return torch.cat([torch.tensor([float(n)], device=device), head, tail, pose])
 
 
-def unpack_boundary(flat: torch.Tensor, overlap: int, K: int) -> Dict[str, torch.Tensor]:
-    n = int(flat[0].item())
+def boundary_numel(overlap: int, K: int) -> int:
+    return 1 + 2 * overlap * K * 6 + 16
+
+
+def unpack_boundary(flat: torch.Tensor, overlap: int, K: int, n_frames: Optional[int] = None) -> Dict[str, torch.Tensor]:
+    """Views into the gathered block, on whatever device it sits (no copy).  Pass n_frames when it is already known on
+    the host (it travels with the per-wave size exchange) to avoid a device sync."""
+    n = int(flat[0].item()) if n_frames is None else int(n_frames)
     sz = overlap * K * 6
 
     def blk(t):
@@ -131,3 +146,77 @@ def compose_global(rel: torch.Tensor) -> torch.Tensor:
     """rel: [n, 16] f64 relative similarities (rel[0] = identity for the first chunk) -> global G [n, 16]."""
     from . import ops
     return ops.sim3_compose_prefix(rel.contiguous())
+
+
+# ---------------------------------------------------------------------------------------------------- wave alignment
+def default_solver(overlap: int, device, chunk_length: Optional[int]):
+    """solve(prev_block, cur_block) -> f64 [17] = [accepted, T(16)] on `device`, with the device kernels."""
+    from .alignment import sim3_accepted
+
+    def solve(prev: Dict, cur: Dict) -> torch.Tensor:
+        out = relative_sim3_from_boundaries(prev, cur, overlap, device, chunk_length=chunk_length)
+        ok = sim3_accepted(out.cpu())
+        res = torch.zeros(17, dtype=torch.float64, device=device)
+        res[0] = 1.0 if ok else 0.0
+        res[1:] = out[13:29] if ok else torch.eye(4, dtype=torch.float64, device=device).reshape(16)
+        return res
+    return solve
+
+
+def align_wave(rank: int, world: int, w0: int, n_chunks: int, blocks: List[Dict], prev_tail: Optional[Dict],
+               G_last: torch.Tensor, solve, comm_device="cpu", compose=None) -> Tuple[List[torch.Tensor], List[bool]]:
+    """One wave of the chunk-parallel progressive alignment.  blocks[r] = unpacked boundary block of chunk w0 + r
+    (every rank holds all of them after the boundary all-gather).  Rank r solves ONLY its own T_{c-1<-c}
+    (c = w0 + r; the predecessor's block is blocks[r-1], or prev_tail = the last block of the previous wave for r = 0);
+    a second all-gather of 17 doubles per rank (136 B) distributes [accepted, T]; every rank then forms the global
+    transforms of the wave by the prefix product G_c = G_{c-1} . T_c.
+
+    Failure policy (same as the sequential path and the reference, offline_reconstructor.py:100-102): a chunk whose
+    solve is rejected stays in its own frame, G_c = I, and the chunks after it chain onto it.
+    Returns ([G_c for the chunks of this wave] as f64 4x4 CPU tensors, [accepted flags])."""
+    c = w0 + rank
+    mine = torch.zeros(17, dtype=torch.float64, device=comm_device)
+    mine[0] = 1.0
+    mine[1:] = torch.eye(4, dtype=torch.float64).reshape(16).to(comm_device)
+    pred = blocks[rank - 1] if rank > 0 else prev_tail
+    if c < n_chunks and pred is not None:
+        mine = solve(pred, blocks[rank]).to(comm_device)
+    rel = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(rel, mine.contiguous())
+    n_wave = min(world, n_chunks - w0)
+    rel_cpu = torch.stack(rel[:n_wave]).cpu()
+    Gs: List[torch.Tensor] = []
+    oks: List[bool] = []
+    base = G_last.to("cpu", torch.float64).reshape(4, 4).clone()
+    pending: List[torch.Tensor] = []
+
+    def flush():
+        # prefix product of the pending relative transforms onto `base`; `compose` = the device kernel
+        # (pi3_sim3_compose_prefix) when a GPU is present, else plain f64 4x4 products (CPU tests under gloo)
+        nonlocal base, pending
+        if pending:
+            stack = torch.stack([base.reshape(16)] + pending).contiguous()
+            out = compose(stack) if compose is not None else _prefix_cpu(stack)
+            for g in out[1:]:
+                Gs.append(g.reshape(4, 4).cpu())
+            base, pending = Gs[-1], []
+
+    for r in range(n_wave):
+        first_chunk = (w0 + r == 0)
+        ok = bool(rel_cpu[r, 0] > 0.5)
+        oks.append(ok or first_chunk)
+        if first_chunk or not ok:      # restart the chain: this chunk keeps its own frame
+            flush()
+            Gs.append(torch.eye(4, dtype=torch.float64))
+            base = Gs[-1]
+        else:
+            pending.append(rel_cpu[r, 1:])
+    flush()
+    return Gs, oks
+
+
+def _prefix_cpu(T: torch.Tensor) -> torch.Tensor:
+    out = [T[0].reshape(4, 4)]
+    for i in range(1, T.shape[0]):
+        out.append(out[-1] @ T[i].reshape(4, 4))
+    return torch.stack([o.reshape(16) for o in out])

@@ -91,6 +91,8 @@ class Pi3Engine:
             self._install(name, t)
         self._shape_cache = {}
         self._buf = {}
+        self._pinned = set()      # buffer keys referenced by a captured graph (see _buffer)
+        self._pinning = False
 
     @classmethod
     def from_pretrained(cls, path: str, device: str = "cuda:0") -> "Pi3Engine":
@@ -149,9 +151,15 @@ class Pi3Engine:
         return consts
 
     def _buffer(self, name: str, shape, dtype) -> torch.Tensor:
+        """Persistent activation buffer, one per (name, shape, dtype).  A buffer that a captured hipGraph has baked
+        into its kernel arguments is PINNED: it is never evicted, so replaying an older graph after other shapes have
+        run cannot touch memory the caching allocator handed to somebody else.  Un-pinned buffers of other shapes are
+        dropped when a new shape asks for the same name (eager runs keep only one working set)."""
         key = (name, tuple(shape), dtype)
+        if self._pinning:
+            self._pinned.add(key)
         if key not in self._buf:
-            for k in [k for k in self._buf if k[0] == name]:
+            for k in [k for k in self._buf if k[0] == name and k not in self._pinned]:
                 del self._buf[k]
             self._buf[key] = torch.empty(shape, device=self.device, dtype=dtype)
         return self._buf[key]
@@ -276,11 +284,15 @@ class Pi3Engine:
         graphs = self.__dict__.setdefault("_graphs", {})
         if key not in graphs:
             static_in = imgs.to(self.device, dtype=torch.float32).contiguous().clone()
-            self.forward(static_in)
-            torch.cuda.synchronize(self.device)
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                static_out = self.forward(static_in)
+            self._pinning = True          # every buffer this shape touches stays alive as long as the engine
+            try:
+                self.forward(static_in)
+                torch.cuda.synchronize(self.device)
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    static_out = self.forward(static_in)
+            finally:
+                self._pinning = False
             graphs[key] = (graph, static_in, static_out)
         graph, static_in, static_out = graphs[key]
         static_in.copy_(imgs, non_blocking=True)

@@ -20,7 +20,7 @@ _vp, _i, _l, _f, _u64 = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_ulonglong
 # name -> argtypes; every function returns int (0 = ok) except the two noted below.  Mirrors include/pi3slam_hip.h.
 SIGNATURES = {
     "pi3_gemm": [_vp, _l, _vp, _l, _i, _i, _i, _i, _vp, _vp, _vp, _l, _vp, _l, _i, _i, _i, _i, _i, _vp, _l, _f, _i, _vp],
-    "pi3_attention": [_vp, _vp, _vp, _l, _l, _vp, _l, _l, _i, _i, _i, _i, _vp],
+    "pi3_attention": [_vp, _vp, _vp, _l, _l, _vp, _l, _l, _i, _i, _i, _i, _vp, _i, _vp],
     "pi3_layernorm": [_vp, _l, _i, _i, _vp, _vp, _f, _vp, _l, _i, _i, _i, _vp, _vp],
     "pi3_qknorm_rope": [_vp, _l, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _i, _vp],
     "pi3_cast_rows": [_vp, _l, _vp, _l, _l, _i, _i, _vp],

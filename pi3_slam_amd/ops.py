@@ -49,15 +49,24 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, M: Optional[int
     return out
 
 
-def attention(qkv: torch.Tensor, out: torch.Tensor, B: int, S: int, H: int) -> torch.Tensor:
-    """qkv: packed [B*S, 3*H*64] bf16 (q pre-scaled by QSCALE); out: [B*S, H*64] bf16."""
+def attention(qkv: torch.Tensor, out: torch.Tensor, B: int, S: int, H: int,
+              k2max: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """qkv: packed [B*S, 3*H*64] bf16 (q pre-scaled by QSCALE); out: [B*S, H*64] bf16.
+    k2max: f32 [B*H] already holding max_s |k|^2 per (batch, head) (written by the fused qkv epilogue); None -> a
+    workspace is taken from torch's allocator and the call fills it with its own pre-pass."""
     lib = _L.load()
     assert qkv.dtype == torch.bfloat16 and out.dtype == torch.bfloat16 and qkv.dim() == 2 and out.dim() == 2
     assert qkv.shape[0] >= B * S and qkv.shape[1] == 3 * H * 64 and qkv.stride(1) == 1 and out.stride(1) == 1
     ts = qkv.stride(0)
     base = qkv.data_ptr()
+    ready = 1
+    if k2max is None:
+        ready = 0
+        k2max = torch.empty(B * H, device=qkv.device, dtype=torch.float32) if S >= 4096 else None
+    else:
+        assert k2max.dtype == torch.float32 and k2max.numel() >= B * H and k2max.is_contiguous()
     rc = lib.pi3_attention(base, base + 2 * H * 64, base + 4 * H * 64, ts, S * ts, out.data_ptr(), out.stride(0),
-                           S * out.stride(0), B, S, H, 64, _L.stream_ptr())
+                           S * out.stride(0), B, S, H, 64, _L.ptr(k2max), ready, _L.stream_ptr())
     _L.check(rc, "pi3_attention")
     return out
 
@@ -429,3 +438,32 @@ def remap_bilinear_u8(frames_u8: torch.Tensor, map_x: torch.Tensor, map_y: torch
                                    map_y.contiguous().data_ptr(), H, W, dst.data_ptr(), _L.stream_ptr())
     _L.check(rc, "pi3_remap_bilinear_u8")
     return dst
+
+
+# ---------------------------------------------------------------------------------------------------- device guard
+# Every wrapper launches on torch's CURRENT stream, i.e. on the current device.  A tensor that lives on another card
+# (e.g. 'cuda:0' data in a rank bound to cuda:3) would hand that card's pointers to a kernel running elsewhere: fail
+# loudly instead.  Checked on the first tensor argument of each call (all tensors of a call share a device by contract).
+def _guarded(fn):
+    import functools
+
+    @functools.wraps(fn)
+    def wrapper(*args, **kwargs):
+        for a in args:
+            if isinstance(a, torch.Tensor):
+                if not a.is_cuda:
+                    raise _L.Pi3HipError(f"{fn.__name__}: expected a device tensor, got {a.device}")
+                if a.device.index != torch.cuda.current_device():
+                    raise _L.Pi3HipError(
+                        f"{fn.__name__}: tensor on {a.device} but the current device (and stream) is "
+                        f"cuda:{torch.cuda.current_device()}; wrap the call in torch.cuda.device(t.device)")
+                break
+        return fn(*args, **kwargs)
+    return wrapper
+
+
+for _name, _fn in list(globals().items()):
+    if callable(_fn) and getattr(_fn, "__module__", None) == __name__ and not _name.startswith("_") \
+            and _fn.__code__.co_flags is not None and _name not in ("undistort_maps",):
+        globals()[_name] = _guarded(_fn)
+del _name, _fn

@@ -49,7 +49,7 @@ def write_ply(points: np.ndarray, colors: np.ndarray, path: str) -> None:
 class OfflineReconstructor:
     def __init__(self, chunk_dir: str, output_dir: str, chunk_length: Optional[int] = None,
                  overlap: Optional[int] = None, max_observations_per_track: int = 5, save_per_chunk: bool = False,
-                 use_inverse_depth: bool = False, device: str = "cuda:0", save_observations: bool = False):
+                 use_inverse_depth: bool = False, device: str = "cuda", save_observations: bool = False):
         self.chunk_dir, self.output_dir = chunk_dir, output_dir
         loaded_cl = loaded_ov = None
         try:  # offline_reconstructor.py:32-46
@@ -66,7 +66,10 @@ class OfflineReconstructor:
         self.max_observations_per_track = max_observations_per_track
         self.save_per_chunk = save_per_chunk
         self.use_inverse_depth = use_inverse_depth
-        self.device = device
+        from .dist import resolve_device
+        self.device = resolve_device(device)     # 'cuda' -> this rank's card (the one the process group is bound to)
+        if torch.cuda.is_available():
+            torch.cuda.set_device(self.device)   # every kernel wrapper launches on the current device's stream
         # save_observations: also write, per chunk, the track observations the reference builds for its bundle adjuster
         # (ChunkPTRecon.create_recon_from_chunk, utils/chunk_reconstruction.py:162-185) as observations_%06d.pt
         self.save_observations = save_observations
@@ -140,62 +143,66 @@ class OfflineReconstructor:
         except Exception as e:  # noqa: BLE001
             print(f"❌ Failed to save TUM trajectory: {e}")
 
-    def _run_distributed(self, rank: int, world: int) -> None:
-        """Chunk-parallel alignment: chunk c lives on rank c % world.  Per wave of `world` chunks ONE
-        all-gather of the boundary blocks (overlap keypoints / points / validity + last pose, ~50 KB per rank), then
-        every rank computes the relative similarities T_{c-1<-c} of the wave and the prefix product
-        G_c = G_{c-1} . T_{c-1<-c} locally, applies G_c to its own chunk, and rank 0 collects the transformed chunks
-        for the trajectory / point-cloud files.  Equal to the sequential run for the closed-form Sim(3) step up to the
-        fp16 re-quantisation of the previous chunk's points (the reference's BA refinement is not part of either)."""
+    def _run_distributed(self, rank: int, world: int, solve=None) -> None:
+        """Chunk-parallel alignment: chunk c lives on rank c % world.  Per wave of `world` chunks:
+          1. a 2-int all-gather of (K, n_frames) sizes the blocks;
+          2. ONE all-gather of the boundary blocks (overlap keypoints / points / validity + last pose, ~50 KB per rank;
+             the blocks stay on the device under nccl = RCCL over xGMI);
+          3. rank r solves only its own T_{c-1<-c}; a 136-byte all-gather distributes the [accepted, T] records;
+          4. every rank forms G_c = G_{c-1} . T_c by the prefix product (dist.align_wave) and applies G_c to its chunk.
+        Rank 0 collects the transformed chunks for the trajectory / point-cloud files.  Equal to the sequential run:
+        both solve on chunk-frame fp16 values and compose (alignment.align_and_refine_reconstructions).
+        `solve` (tests): replaces the device solver, see dist.default_solver."""
         import torch.distributed as dist
 
+        from . import ops
         from .alignment import transform_chunk
-        from .dist import (allgather_boundaries, gather_objects, pack_boundary, relative_sim3_from_boundaries,
-                           unpack_boundary)
+        from .dist import (align_wave, allgather_boundaries, boundary_numel, default_solver, gather_objects,
+                           pack_boundary, unpack_boundary)
         files = self._load_chunks()
         n_chunks = len(files)
-        gathered_on = self.device if dist.get_backend() == "nccl" else "cpu"
+        on_gpu = dist.get_backend() == "nccl"
+        comm_dev = self.device if on_gpu else "cpu"
+        if solve is None:
+            solve = default_solver(self.overlap, self.device, self.chunk_length)
+            compose = lambda T: ops.sim3_compose_prefix(T.to(self.device))   # noqa: E731
+        else:
+            compose = None
         print(f"🔄 Reconstructing {n_chunks} chunks from {self.chunk_dir} on {world} ranks (rank {rank})")
-        G_last = np.eye(4)
-        prev_block = None
+        G_last = torch.eye(4, dtype=torch.float64)
+        prev_tail = None
         mine: List[Dict] = []
-        K = None
         for w0 in range(0, n_chunks, world):
             c = w0 + rank
             data = torch.load(files[c], map_location="cpu", weights_only=False) if c < n_chunks else None
-            kk = torch.tensor([int(data["keypoints"].shape[1]) if data is not None else 0], device=gathered_on)
-            ks = [torch.zeros_like(kk) for _ in range(world)]
-            dist.all_gather(ks, kk)
-            K = max(int(k.item()) for k in ks)
+            sz = torch.tensor([int(data["keypoints"].shape[1]), int(data["points"].shape[0])] if data is not None
+                              else [0, 0], device=comm_dev)
+            szs = [torch.zeros_like(sz) for _ in range(world)]
+            dist.all_gather(szs, sz)
+            szs = [t.tolist() for t in szs]
+            K = max(k for k, _ in szs)
             if data is not None:
-                local = pack_boundary(data, self.overlap, K)
+                local = pack_boundary(data, self.overlap, K, device=comm_dev)
             else:   # ragged last wave: an empty block (n_frames = 0)
-                local = torch.zeros(1 + 2 * self.overlap * K * 6 + 16)
-            blocks = [unpack_boundary(b.cpu(), self.overlap, K) for b in allgather_boundaries(local, gathered_on)]
-            for r in range(world):
-                if w0 + r >= n_chunks:
-                    break
-                if prev_block is None:
-                    G = np.eye(4)
-                else:
-                    out = relative_sim3_from_boundaries(prev_block, blocks[r], self.overlap, self.device,
-                                                        chunk_length=self.chunk_length)
-                    if float(out[29]) < 3.0:
-                        print(f"   ❌ Alignment failed for chunk {w0 + r}: {int(out[30])} common, {int(out[29])} kept")
-                        T = np.eye(4)
-                    else:
-                        T = out[13:29].reshape(4, 4).cpu().numpy().astype(np.float64)
-                    G = G_last @ T
-                if r == rank and data is not None:
-                    transform_chunk(data, torch.from_numpy(G), device=self.device)
-                    data["chunk_order"] = w0 + r
-                    mine.append(data)
-                    if self.save_per_chunk:
-                        self._save_chunk(data, w0 + r)
-                    if self.save_observations:
-                        self._save_observations(data, w0 + r)
-                G_last, prev_block = G, blocks[r]
-        keep = ("points", "colors", "keypoints", "masks", "camera_poses", "image_paths", "chunk_order")
+                local = torch.zeros(boundary_numel(self.overlap, K), device=comm_dev)
+            blocks = [unpack_boundary(b, self.overlap, K, n_frames=szs[r][1])
+                      for r, b in enumerate(allgather_boundaries(local, comm_dev))]
+            Gs, oks = align_wave(rank, world, w0, n_chunks, blocks, prev_tail, G_last, solve, comm_dev, compose)
+            for r, ok in enumerate(oks):
+                if not ok and rank == 0:
+                    print(f"   ❌ Alignment failed for chunk {w0 + r}: it stays in its own frame")
+            if data is not None:
+                transform_chunk(data, Gs[rank], device=self.device, absolute=True)
+                data["chunk_order"] = c
+                data["alignment_ok"] = bool(oks[rank])
+                mine.append(data)
+                if self.save_per_chunk:
+                    self._save_chunk(data, c)
+                if self.save_observations:
+                    self._save_observations(data, c)
+            n_wave = len(Gs)
+            G_last, prev_tail = Gs[-1], blocks[n_wave - 1]
+        keep = ("points", "colors", "keypoints", "masks", "camera_poses", "image_paths", "chunk_order", "alignment_ok")
         parts = gather_objects([{k: d[k] for k in keep if k in d} for d in mine])
         if rank == 0:
             self.reconstructions = sorted((d for part in parts for d in part), key=lambda d: d["chunk_order"])

@@ -58,3 +58,118 @@ def test_allgather_boundaries_world2():
     g = torch.Generator().manual_seed(103)
     pts = torch.randn(6, K, 3, generator=g).half()
     assert abs(res[0][2][3] - pts[-ov:].float().sum().item()) < 1e-6
+
+
+# ------------------------------------------------------------------------------------------------ wave alignment
+def _synthetic_chunks(n_chunks, cl, ov, K, bad_chunk=None):
+    """Chunk dicts (chunk-file layout) cut from one world: chunk c = S_c^-1 (world).  bad_chunk's keypoints are shifted
+    so that it shares no track with its predecessor (its alignment must fail and restart the chain)."""
+    import numpy as np
+    rng = np.random.default_rng(0)
+    n_frames = cl + (n_chunks - 1) * (cl - ov)
+    world_pts = rng.standard_normal((n_frames, K, 3)) + np.array([0, 0, 4.0])
+    kp = (rng.random((K, 2)) * 300).astype(np.float16)
+    chunks, sims = [], []
+    for c in range(n_chunks):
+        start = c * (cl - ov)
+        n = min(cl, n_frames - start) if c < n_chunks - 1 else cl - 2      # short last chunk
+        ang, s = 0.3 * c, 1.0 + 0.1 * c
+        R = np.array([[np.cos(ang), -np.sin(ang), 0], [np.sin(ang), np.cos(ang), 0], [0, 0, 1.0]])
+        t = np.array([0.5 * c, -0.3 * c, 0.1 * c])
+        pts = (((world_pts[start:start + n] - t) @ R) / s).astype(np.float16)
+        poses = np.tile(np.eye(4, dtype=np.float32), (n, 1, 1))
+        poses[:, :3, 3] = ((np.stack([[0.1 * (start + j), 0, 0] for j in range(n)]) - t) @ R) / s
+        k = np.tile(kp, (n, 1, 1))
+        if c == bad_chunk:
+            k[:ov] = (k[:ov].astype(np.float32) + 1000).astype(np.float16)     # only its head: the tail still pairs
+        chunks.append(dict(points=torch.from_numpy(pts), keypoints=torch.from_numpy(k),
+                           masks=torch.ones(n, K, 1, dtype=torch.bool), camera_poses=torch.from_numpy(poses)))
+        M = np.eye(4); M[:3, :3] = s * R; M[:3, 3] = t
+        sims.append(M)
+    return chunks, sims
+
+
+def _oracle_solver(ov, cl):
+    """[accepted, T] with the CPU oracle (tests may use oracle/; the product's default solver is the HIP kernel)."""
+    import numpy as np
+    from oracle import post_ref
+
+    def solve(prev, cur):
+        n_prev, n_cur = prev["n_frames"], cur["n_frames"]
+        ov_p = min(ov, n_prev)
+        d = (cl - ov) - (n_prev - ov_p)
+        pairs = [(i + d, i) for i in range(ov) if 0 <= i + d < ov_p and i < min(ov, n_cur)]
+        ri, qi = [r for r, _ in pairs], [q for _, q in pairs]
+        ref, qry = prev["tail"], cur["head"]
+        res = torch.zeros(17, dtype=torch.float64)
+        res[1:] = torch.eye(4, dtype=torch.float64).reshape(16)
+        try:
+            out = post_ref.align_chunks(ref["points"][ri].numpy(), qry["points"][qi].numpy(), ref["keypoints"][ri].numpy(),
+                                        qry["keypoints"][qi].numpy(), prev["last_pose"].numpy(), True)
+        except Exception:  # noqa: BLE001 - empty pair set
+            return res
+        if out["n_used"] >= 3 and np.isfinite(out["M"]).all():
+            res[0] = 1.0
+            res[1:] = torch.from_numpy(out["M"].reshape(16))
+        return res
+    return solve
+
+
+def _wave_worker(rank, world, port, n_chunks, cl, ov, K, bad, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from pi3_slam_amd.dist import align_wave, allgather_boundaries, boundary_numel, pack_boundary, unpack_boundary
+    chunks, _ = _synthetic_chunks(n_chunks, cl, ov, K, bad)
+    solve = _oracle_solver(ov, cl)
+    G_last, prev_tail, Gall, okall = torch.eye(4, dtype=torch.float64), None, [], []
+    for w0 in range(0, n_chunks, world):
+        c = w0 + rank
+        local = pack_boundary(chunks[c], ov, K) if c < n_chunks else torch.zeros(boundary_numel(ov, K))
+        blocks = [unpack_boundary(b, ov, K) for b in allgather_boundaries(local, "cpu")]
+        Gs, oks = align_wave(rank, world, w0, n_chunks, blocks, prev_tail, G_last, solve)
+        Gall += Gs
+        okall += oks
+        G_last, prev_tail = Gs[-1], blocks[len(Gs) - 1]
+    dist.barrier()
+    q.put((rank, torch.stack(Gall).numpy(), okall))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_chunks,bad", [(5, None), (4, 2)])
+def test_align_wave_world2_equals_sequential_composition(n_chunks, bad):
+    """World-size-2 chunk-parallel alignment (each rank solves its own T, 136-byte all-gather, prefix product with a
+    restart at a rejected chunk, ragged last wave) == the sequential chain computed in one process."""
+    import numpy as np
+    world, cl, ov, K = 2, 8, 3, 30
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_wave_worker, args=(r, world, port, n_chunks, cl, ov, K, bad, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=180) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert np.array_equal(res[0][1], res[1][1]) and res[0][2] == res[1][2]       # every rank holds the same transforms
+    G, oks = res[0][1], res[0][2]
+    assert len(G) == n_chunks
+    # sequential reference in this process
+    from pi3_slam_amd.dist import pack_boundary, unpack_boundary
+    chunks, sims = _synthetic_chunks(n_chunks, cl, ov, K, bad)
+    solve = _oracle_solver(ov, cl)
+    blocks = [unpack_boundary(pack_boundary(ch, ov, K), ov, K) for ch in chunks]
+    Gseq = [np.eye(4)]
+    for c in range(1, n_chunks):
+        r = solve(blocks[c - 1], blocks[c])
+        Gseq.append(Gseq[-1] @ r[1:].numpy().reshape(4, 4) if r[0] > 0.5 else np.eye(4))
+    np.testing.assert_allclose(G, np.stack(Gseq), rtol=1e-12, atol=1e-12)
+    assert oks == [c == 0 or c != bad for c in range(n_chunks)]
+    # and the chain recovers the ground-truth similarities (chunk 0 = world frame up to S_0 = identity)
+    for c in range(n_chunks):
+        base = c if bad is None or c < bad else None
+        if base is not None:
+            np.testing.assert_allclose(G[c], sims[c], atol=2e-2)
+        else:     # chunks from the rejected one on live in the rejected chunk's frame
+            np.testing.assert_allclose(G[c], np.linalg.inv(sims[bad]) @ sims[c], atol=2e-2)

@@ -5,10 +5,13 @@ Stated tolerance: (a) the network output (affine point map z): mean/max absolute
 bf16-autocast deviation stored with the vectors (bf16err_z); (b) the binary mask: <= 0.5 % of the pixels may flip
 (logits near 0); (c) the focal/shift recovery (scipy LM restated on the device) fed with the REFERENCE's fp32 point map:
 focal and shift within 1e-4 relative of what the reference's infer() produced; (d) depth algebra of v2.py:255-274 exact
-on the device's own inputs.  With random (recipe) weights the predicted point map is not pinhole-consistent, which
-makes the shift recovery ill-conditioned (a 0.2 % change of the map moves the optimum by several %), so the end-to-end
-metric depth is only gated loosely (median relative error < 15 %); with a trained model the map is pinhole-like and the
-recovery is well-conditioned.
+on the device's own inputs; (e) END TO END, on the pinhole-consistent fixtures (oracle/gen_golden_moge.pinhole_overrides:
+focal ~0.9 > 0, shift well conditioned - the regime a trained model runs in): `depth`, the only key the pipeline
+reads (offline_chunk_creator.py:184), within 2x the reference's own bf16-autocast-vs-fp32 deviation of depth (median,
+mean and 99th percentile of the relative error, stored with the vectors), focal and shift within 2x the reference's own
+bf16 deviation of them.  The purely random-weight fixtures (moge_small / moge_chunk) produce a map no camera could have
+produced (their focal solves negative); they keep gating the network output, the mask and the depth algebra, not the
+ill-posed solve.
 """
 import os
 
@@ -47,8 +50,60 @@ def test_moge_infer_against_reference_vectors(engine, name):
     # (d) depth = (z + shift) * metric_scale on the device's own z / shift / scale
     own = (z + out["shift"].item()) * float(g["metric_scale"][0])
     np.testing.assert_allclose(depth[mask], own[mask], rtol=2e-2)       # metric_scale itself carries bf16 error
+
+
+@pytest.fixture(scope="module")
+def pinhole_engine(built_lib):
+    from oracle.gen_golden_moge import case_state_dict
+    from pi3_slam_amd.moge import SYNTHETIC_CONFIG, MoGeEngine
+    return MoGeEngine(SYNTHETIC_CONFIG, "cuda:0", case_state_dict("moge_pinhole_small"))
+
+
+@pytest.mark.parametrize("name", ["moge_pinhole_small", "moge_pinhole_chunk"])
+def test_moge_depth_end_to_end_on_pinhole_consistent_map(pinhole_engine, name):
+    """(e) of the module docstring: tight gate on `depth`, focal > 0."""
+    from oracle.gen_golden_moge import CASES, moge_image
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    H, W, level = CASES[name]
+    out = pinhole_engine.infer(moge_image(name, H, W), resolution_level=level)
+    torch.cuda.synchronize()
+    focal_ref, shift_ref = g["focal_shift"]
+    focal, shift = out["focal"].item(), out["shift"].item()
+    assert focal > 0.5 and focal_ref > 0.5
+    tol_f = 2.0 * abs(g["bf16_focal_shift"][0] - focal_ref) + 1e-3 * abs(focal_ref)
+    tol_s = 2.0 * abs(g["bf16_focal_shift"][1] - shift_ref) + 1e-3
+    assert abs(focal - focal_ref) <= tol_f, (focal, focal_ref, tol_f)
+    assert abs(shift - shift_ref) <= tol_s, (shift, shift_ref, tol_s)
+    mask_ref = np.unpackbits(g["mask"])[: H * W].reshape(H, W).astype(bool)
+    mask = out["mask"].cpu().numpy()
+    assert (mask != mask_ref).mean() < 5e-3
+    both = mask & mask_ref
+    depth = out["depth"].cpu().numpy()
     rel = np.abs(depth[both] - g["depth"][both]) / g["depth"][both]
-    assert np.median(rel) < 0.15, np.median(rel)
+    med, mean, p99 = g["bf16err_depth"]
+    got = (np.median(rel), rel.mean(), np.quantile(rel, 0.99))
+    assert got[0] <= 2.0 * med and got[1] <= 2.0 * mean and got[2] <= 2.0 * p99, (got, (med, mean, p99))
+    z = out["points_affine"][..., 2].cpu().numpy()
+    d = np.abs(z - g["points_affine_z"])
+    assert d.mean() <= 2.0 * g["bf16err_z"][0] and d.max() <= 2.0 * g["bf16err_z"][1]
+
+
+def test_moge_infer_graphed_equals_infer(engine):
+    """The hipGraph replay used by OfflineCreatorConfig.hip_graph returns exactly what the eager launches return, on
+    the capture run, on a replay with new pixels, and after another shape was captured in between."""
+    g = torch.Generator(device="cuda:0").manual_seed(5)
+    a, b = (torch.rand(3, 84, 112, device="cuda:0", generator=g) for _ in range(2))
+    c = torch.rand(3, 70, 98, device="cuda:0", generator=g)
+    keys = ("depth", "mask", "intrinsics", "points_affine")
+    for img in (a, b, c, a):
+        ref = {k: engine.infer(img, resolution_level=0)[k].clone() for k in keys}
+        out = engine.infer_graphed(img, resolution_level=0)
+        torch.cuda.synchronize()
+        for k in keys:
+            x, y = out[k], ref[k]
+            if x.dtype.is_floating_point:
+                x, y = torch.nan_to_num(x, posinf=1e30), torch.nan_to_num(y, posinf=1e30)
+            assert torch.equal(x, y), k
 
 
 def test_moge_focal_shift_on_reference_pointmap(engine):

@@ -89,15 +89,19 @@ def test_umeyama_known_answers():
     assert abs(np.linalg.det(Rp) - 1.0) < 1e-9
 
 
-@pytest.mark.parametrize("name", ["moge_small", "moge_chunk"])
+@pytest.mark.parametrize("name", ["moge_small", "moge_chunk", "moge_pinhole_small", "moge_pinhole_chunk"])
 def test_moge_oracle_matches_reference_vectors(name):
-    """MoGe-2 restatement vs the real MoGeModel class (synthetic model_config + recipe weights)."""
+    """MoGe-2 restatement vs the real MoGeModel class (synthetic model_config + recipe weights; the 'pinhole' cases
+    edit a few 1x1 convolutions so the predicted map is camera-consistent: focal > 0, well-conditioned shift)."""
     from oracle import moge_ref
-    from oracle.gen_golden_moge import CASES as MCASES, moge_image
-    from pi3_slam_amd.moge import SYNTHETIC_CONFIG, recipe_state_dict_cpu
+    from oracle.gen_golden_moge import CASES as MCASES, case_state_dict, moge_image
+    from pi3_slam_amd.moge import SYNTHETIC_CONFIG
     g = np.load(os.path.join(GOLDEN, name + ".npz"))
     H, W, level = MCASES[name]
-    out = moge_ref.moge_infer(recipe_state_dict_cpu(SYNTHETIC_CONFIG), SYNTHETIC_CONFIG, moge_image(name, H, W), level)
+    out = moge_ref.moge_infer(case_state_dict(name), SYNTHETIC_CONFIG, moge_image(name, H, W), level)
+    if "pinhole" in name:
+        assert g["focal_shift"][0] > 0.5 and abs(float(out["focal"]) - g["focal_shift"][0]) < 1e-4
+        assert abs(float(out["shift"]) - g["focal_shift"][1]) < 1e-4
     mask = np.unpackbits(g["mask"])[: H * W].reshape(H, W).astype(bool)
     assert np.array_equal(out["mask"].numpy(), mask)
     np.testing.assert_allclose(out["points_affine"][..., 2].numpy(), g["points_affine_z"], rtol=1e-4, atol=1e-5)
@@ -132,3 +136,51 @@ def test_ingest_oracle_and_host_tables_match_pillow_vectors(name):
         b0, k0 = ingest_ref.resample_coeffs(n_in, n_out)
         b1, k1 = resample_coeffs(n_in, n_out)
         assert np.array_equal(b0, b1) and np.array_equal(k0, k1)
+
+
+# ------------------------------------------------------------------------------------------------ Sim(3): two closed forms
+def _sim3_cloud(rng, n, kind):
+    x = rng.standard_normal((n, 3)) * np.array([2.0, 1.0, 0.5]) + np.array([0.3, -0.2, 4.0])
+    if kind == "planar":
+        x[:, 2] = 4.0 + 0.3 * x[:, 0] - 0.1 * x[:, 1]
+    ang = 0.7
+    R = np.array([[np.cos(ang), -np.sin(ang), 0], [np.sin(ang), np.cos(ang), 0], [0, 0, 1.0]]) @ \
+        np.array([[1, 0, 0], [0, np.cos(0.3), -np.sin(0.3)], [0, np.sin(0.3), np.cos(0.3)]])
+    y = 1.7 * x @ R.T + np.array([0.5, 2.0, -1.0])
+    if kind == "mirrored":           # the data is a reflection: the best PROPER rotation is wanted (det fix / quaternion)
+        y = y * np.array([1.0, 1.0, -1.0])
+    if kind in ("noisy", "mirrored", "planar"):
+        y = y + 1e-2 * rng.standard_normal(y.shape)
+    return x, y, (1.7, R)
+
+
+@pytest.mark.parametrize("kind", ["exact", "noisy", "mirrored", "planar"])
+@pytest.mark.parametrize("n", [3, 4, 50, 4000])
+def test_sim3_umeyama_equals_horn_quaternion(kind, n):
+    """Sim(3) parity is UNPINNED (pytheia absent, the reference holds no vectors): the SVD form (Umeyama 1991) and the
+    quaternion form (Horn 1987) are derived independently and must agree to 1e-10 wherever the optimum is unique."""
+    rng = np.random.default_rng(n * 7 + len(kind))
+    x, y, (s0, R0) = _sim3_cloud(rng, n, kind)
+    s1, R1, t1, M1 = post_ref.umeyama(x, y)
+    s2, R2, t2, M2 = post_ref.horn_sim3(x, y)
+    for R in (R1, R2):
+        np.testing.assert_allclose(R @ R.T, np.eye(3), atol=1e-12)
+        assert abs(np.linalg.det(R) - 1.0) < 1e-12
+    np.testing.assert_allclose(M1, M2, atol=1e-10, rtol=1e-10)
+    assert abs(s1 - s2) < 1e-10
+    if kind == "exact":
+        assert abs(s1 - s0) < 1e-10 and np.abs(R1 - R0).max() < 1e-10
+
+
+def test_sim3_closed_forms_on_collinear_points():
+    """Collinear points leave the rotation about the line free: both forms must still return a proper rotation and
+    reach the same (minimal) residual, scale and mapped points."""
+    rng = np.random.default_rng(0)
+    lam = rng.standard_normal(40)
+    x = np.outer(lam, [1.0, 2.0, -0.5]) + np.array([0.1, 0.2, 3.0])
+    y = 0.8 * np.outer(lam, [0.0, 1.0, 1.0]) / np.sqrt(2) * np.linalg.norm([1.0, 2.0, -0.5]) + np.array([1.0, 0.0, 0.0])
+    outs = [post_ref.umeyama(x, y), post_ref.horn_sim3(x, y)]
+    for s, R, t, M in outs:
+        assert abs(np.linalg.det(R) - 1.0) < 1e-9 and np.abs(R @ R.T - np.eye(3)).max() < 1e-9
+        assert abs(s - 0.8) < 1e-9
+        np.testing.assert_allclose(s * x @ R.T + t, y, atol=1e-9)

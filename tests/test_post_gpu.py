@@ -49,11 +49,12 @@ def test_masks_scale_gather_against_reference_vectors(dev, name):
         assert np.array_equal(out["masks"].cpu().numpy(), g[f"imasks_{tag}"])                   # nearest: exact
         assert np.array_equal(out["conf"].cpu().numpy(), g[f"iconf_{tag}"])                     # nearest: exact
         assert np.array_equal(out["keypoints"].cpu().numpy(), g[f"kp_{tag}"].astype(np.float16))
-        assert _fp16_close(out["points"], torch.from_numpy(g[f"ipoints_{tag}"]))
-        assert _fp16_close(out["local_points"], torch.from_numpy(g[f"ilocal_{tag}"]))
+        # bilinear: the kernel restates ATen's FMA order, so fp16 values and uint8 colours are bit-exact as well
+        assert _fp16_close(out["points"], torch.from_numpy(g[f"ipoints_{tag}"]), max_ulp=0, max_frac=0.0)
+        assert _fp16_close(out["local_points"], torch.from_numpy(g[f"ilocal_{tag}"]), max_ulp=0, max_frac=0.0)
         col = out["colors"].cpu().float().numpy()
         ref = g[f"colors_{tag}"].astype(np.float32)
-        assert np.abs(col - ref).max() <= 1.0 and (col != ref).mean() < 5e-3                    # uint8 truncation edge
+        assert np.array_equal(col, ref), ((col != ref).mean(), np.abs(col - ref).max())
 
 
 def test_masks_edge_cases(dev):
@@ -165,6 +166,118 @@ def test_sim3_against_oracle(dev, permute, use_filter):
     np.testing.assert_allclose(out[13:29].reshape(4, 4), ref["M"], atol=1e-11)
     np.testing.assert_allclose(out[32], ref["rms"], rtol=1e-9)
     assert abs(out[0] - s) < 5e-3 and np.abs(out[1:10].reshape(3, 3) - R).max() < 5e-3      # recovers the truth
+
+
+def _solve_pairs(dev, x, y, use_filter=False, pose=None, kp=None):
+    """Push explicit point pairs (qry x -> ref y) through the match + filter + closed-form kernels."""
+    from pi3_slam_amd import ops
+    n = len(x)
+    if kp is None:
+        kp = (np.arange(2 * n, dtype=np.float32).reshape(1, n, 2) * 0.5).astype(np.float16)
+    kr = kq = kp
+    pose = np.eye(4, dtype=np.float32) if pose is None else pose
+    idx = ops.sim3_match_keypoints(torch.from_numpy(kr).to(dev), torch.from_numpy(kq).to(dev))
+    out = ops.sim3_umeyama(torch.from_numpy(y.astype(np.float16)[None]).to(dev),
+                           torch.from_numpy(x.astype(np.float16)[None]).to(dev), idx,
+                           torch.from_numpy(pose).to(dev), None, None, use_filter).cpu().numpy()
+    return idx.cpu().numpy(), out
+
+
+@pytest.mark.parametrize("kind", ["mirrored", "planar", "collinear", "three_points"])
+def test_sim3_degenerate_configurations(dev, kind):
+    """Parity unpinned (pytheia absent): the kernel (Horn quaternion, Jacobi) must agree with BOTH oracle closed forms
+    (SVD Umeyama and numpy Horn) where the optimum is unique, and return a proper rotation with the minimal residual
+    where it is not (collinear)."""
+    from oracle import post_ref
+    rng = np.random.default_rng(11)
+    n = 3 if kind == "three_points" else 60
+    x = (rng.standard_normal((n, 3)) * np.array([2.0, 1.0, 0.5]) + np.array([0.0, 0.0, 4.0]))
+    ang = 0.5
+    R0 = np.array([[np.cos(ang), 0, np.sin(ang)], [0, 1, 0], [-np.sin(ang), 0, np.cos(ang)]])
+    if kind == "planar":
+        x[:, 2] = 4.0 + 0.25 * x[:, 0]
+    if kind == "collinear":
+        x = np.outer(rng.standard_normal(n), [1.0, 0.5, -0.25]) + np.array([0.0, 0.0, 4.0])
+    y = 1.25 * x @ R0.T + np.array([0.25, -0.5, 1.0])
+    if kind == "mirrored":
+        y = y * np.array([1.0, -1.0, 1.0])
+    x16, y16 = x.astype(np.float16).astype(np.float64), y.astype(np.float16).astype(np.float64)   # what the kernel sees
+    _, out = _solve_pairs(dev, x, y)
+    s, R, t, M = out[0], out[1:10].reshape(3, 3), out[10:13], out[13:29].reshape(4, 4)
+    assert int(out[29]) == n and np.isfinite(out[:33]).all()
+    assert np.abs(R @ R.T - np.eye(3)).max() < 1e-12 and abs(np.linalg.det(R) - 1.0) < 1e-12
+    s1, R1, t1, M1 = post_ref.umeyama(x16, y16)
+    s2, R2, t2, M2 = post_ref.horn_sim3(x16, y16)
+    rms = lambda s_, R_, t_: np.sqrt((((s_ * x16 @ R_.T) + t_ - y16) ** 2).sum(1).mean())
+    if kind == "collinear":       # rotation about the line is free: same residual, same mapped points
+        np.testing.assert_allclose(out[32], rms(s1, R1, t1), atol=1e-9)
+        np.testing.assert_allclose(s * x16 @ R.T + t, s1 * x16 @ R1.T + t1, atol=1e-6)
+    else:
+        np.testing.assert_allclose(M, M1, atol=1e-9, rtol=1e-9)
+        np.testing.assert_allclose(M, M2, atol=1e-9, rtol=1e-9)
+        np.testing.assert_allclose(out[32], rms(s1, R1, t1), rtol=1e-7, atol=1e-12)
+
+
+def test_sim3_too_few_pairs_and_everything_filtered(dev):
+    """< 3 usable pairs -> identity + the count (the host turns that into (False, {...}) like
+    reconstruction_alignment.py:99-101); the strict '<' median filter (:78-86) drops EVERY pair when all reference
+    points are equidistant from the last camera."""
+    from pi3_slam_amd.alignment import align_and_refine_reconstructions
+    rng = np.random.default_rng(2)
+    x = rng.standard_normal((2, 3)) + [0, 0, 3.0]
+    _, out = _solve_pairs(dev, x, x * 2.0)
+    assert int(out[29]) == 2 and np.array_equal(out[13:29].reshape(4, 4), np.eye(4)) and out[0] == 1.0
+    # every pair filtered: reference points on a sphere of radius exactly 2 (fp16-representable) around the camera
+    dirs = np.array([[1, 0, 0], [0, 1, 0], [0, 0, 1], [-1, 0, 0], [0, -1, 0], [0, 0, -1]], np.float64)
+    y = 2.0 * dirs
+    _, out = _solve_pairs(dev, dirs, y, use_filter=True)
+    assert int(out[30]) == 6 and int(out[29]) == 0 and out[31] == 2.0
+    assert np.array_equal(out[13:29].reshape(4, 4), np.eye(4))
+    # no common keypoint at all
+    from pi3_slam_amd import ops
+    kr = np.zeros((1, 4, 2), np.float16); kq = np.ones((1, 4, 2), np.float16)
+    idx = ops.sim3_match_keypoints(torch.from_numpy(kr).to(dev), torch.from_numpy(kq).to(dev))
+    assert (idx.cpu().numpy() == -1).all()
+    # host surface: failure is reported, not raised
+    K = 5
+    mk = lambda pts: {"points": torch.from_numpy(np.tile(pts.astype(np.float16), (3, 1, 1))),
+                      "keypoints": torch.from_numpy(np.tile((np.arange(2 * K).reshape(K, 2) + 1000 * (pts[0, 0] > 0)).astype(np.float16), (3, 1, 1))),
+                      "masks": torch.ones(3, K, 1, dtype=torch.bool), "camera_poses": torch.eye(4).repeat(3, 1, 1)}
+    a, b = mk(rng.standard_normal((K, 3)) - 5.0), mk(np.abs(rng.standard_normal((K, 3))) + 5.0)
+    ok, info = align_and_refine_reconstructions(a, b, [(1, 0), (2, 1)], device=str(dev))
+    assert ok is False and "error" in info
+
+
+def test_sim3_duplicated_keypoints_take_the_first_reference_track(dev):
+    """Two reference keypoints with identical pixels: the qry keypoint pairs with the FIRST one (oracle semantics)."""
+    from oracle import post_ref
+    from pi3_slam_amd import ops
+    rng = np.random.default_rng(4)
+    ov, K = 2, 16
+    kr = (rng.random((ov, K, 2)) * 200).astype(np.float16)
+    kr[:, 9] = kr[:, 2]                      # duplicate of keypoint 2 later in the list
+    kr[:, 12] = kr[:, 2]
+    kq = kr[:, ::-1].copy()
+    pr = rng.standard_normal((ov, K, 3)).astype(np.float16)
+    pq = rng.standard_normal((ov, K, 3)).astype(np.float16)
+    idx = ops.sim3_match_keypoints(torch.from_numpy(kr).to(dev), torch.from_numpy(kq).to(dev)).cpu().numpy()
+    ref = post_ref.align_chunks(pr, pq, kr, kq, np.eye(4, dtype=np.float32), False)
+    assert np.array_equal(idx, ref["idx"])
+    assert idx[0, K - 1 - 9] == 2 and idx[0, K - 1 - 12] == 2 and idx[0, K - 1 - 2] == 2
+    out = ops.sim3_umeyama(torch.from_numpy(pr).to(dev), torch.from_numpy(pq).to(dev),
+                           torch.from_numpy(idx).to(dev), torch.eye(4, device=dev), None, None, False).cpu().numpy()
+    np.testing.assert_allclose(out[13:29].reshape(4, 4), ref["M"], atol=1e-10)
+    _, _, _, M2 = post_ref.horn_sim3(*[np.array(v, np.float64) for v in _pairs_of(ref["idx"], pq, pr)])
+    np.testing.assert_allclose(out[13:29].reshape(4, 4), M2, atol=1e-9)
+
+
+def _pairs_of(idx, pq, pr):
+    xs, ys = [], []
+    for v in range(idx.shape[0]):
+        for j in range(idx.shape[1]):
+            if idx[v, j] >= 0:
+                xs.append(pq[v, j].astype(np.float64)); ys.append(pr[v, idx[v, j]].astype(np.float64))
+    return xs, ys
 
 
 def test_sim3_apply_and_prefix(dev):

@@ -27,7 +27,7 @@ extern "C" {
 #define PI3_ERR_WORKSPACE (-3)
 
 const char* pi3_last_error(void);
-int pi3_abi_version(void);
+int pi3_abi_version(void);   /* 2 */
 int pi3_device_count(void);
 
 /* ---- transformer blocks -------------------------------------------------------------------------------------- */
@@ -42,6 +42,19 @@ int pi3_device_count(void);
 int pi3_gemm(const void* A, long lda, const void* W, long ldw, int M, int N, int K, int in_dtype, const float* bias,
              const float* gamma, const float* resid, long ldr, void* out, long ldo, int out_dtype, int act, int rpg,
              int gstride, int goff, const float* addtab, long ldadd, float qscale, int qcols, void* stream);
+
+/* The packed qkv projection of a transformer block with everything FlashAttentionRope.forward does to q and k before the
+ * attention call fused into its epilogue (pi3/models/layers/attention.py:323-334; replaces the reference's
+ * nn.Linear + q_norm / k_norm LayerNorm(64) + RoPE2D (= the optional curope.rope_2d, pi3/models/curope/curope.cpp:49-68)
+ * + the softmax scale):
+ *   qkv[M][3*H*64] bf16 = A[M][K] . W[3*H*64][K]^T + bias;  per head of q and k: LayerNorm over the 64 dims (eps; only
+ *   when qw/qb/kw/kb are given), RoPE-2D with positions pos[row % T] = (y, x) and the table cs[npos][16][2] = (cos, sin)
+ *   (only when pos/cs are given), q *= qscale.
+ * k2max (optional, attn_B*H floats, caller-owned): receives max_s |k[b, s, h, :]|^2 for the attention call that follows
+ * (rows = attn_B batches of attn_S tokens) - pass it to pi3_attention with k2max_ready = 1. */
+int pi3_gemm_qkv(const void* A, long lda, const void* W, long ldw, int M, int K, int H, const float* bias, void* qkv,
+                 long ldo, int T, const int* pos, const float* cs, const float* qw, const float* qb, const float* kw,
+                 const float* kb, float eps, float qscale, float* k2max, int attn_B, int attn_S, void* stream);
 
 /* F.scaled_dot_product_attention, non-causal, head_dim 64 (pi3/models/layers/attention.py:102-107, 336-341).
  * q/k/v: bf16, element (b, s, h, d) at ptr[b*batch_stride + s*tok_stride + h*64 + d]; q PRE-SCALED by
@@ -141,8 +154,12 @@ int pi3_focal_shift(const float* local_points, const float* conf, const unsigned
 int pi3_conv3x3(const void* img, long ldc, int B, int H, int W, int C, const void* wgt, int N, const float* bias,
                 const float* resid, long ldr, void* out, long ldo, int out_dtype, int act, void* stream);
 
-/* nn.GroupNorm(G, C) statistics of x f32 [B][HW][ldx] -> stats f64 [B][G][2] (sum, sum of squares). */
-int pi3_groupnorm_stats(const float* x, long ldx, int B, int HW, int C, int G, double* stats, void* stream);
+/* nn.GroupNorm(G, C) statistics of x f32 [B][HW][ldx] -> stats f64 [B][G][2] (sum, sum of squares).  Deterministic
+ * two-pass reduction (no floating-point atomics) through the caller's workspace ws of at least
+ * pi3_groupnorm_ws_doubles(B, HW, C) doubles. */
+long pi3_groupnorm_ws_doubles(int B, int HW, int C);
+int pi3_groupnorm_stats(const float* x, long ldx, int B, int HW, int C, int G, double* stats, double* ws,
+                        long ws_doubles, void* stream);
 
 /* GroupNorm affine + activation (0 none, 2 ReLU) -> bf16 NHWC staging image [B][HW][ldo], channels [C, Cpad) zeroed. */
 int pi3_groupnorm_apply(const float* x, long ldx, int B, int HW, int C, int Cpad, int G, const double* stats,

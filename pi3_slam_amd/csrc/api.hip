@@ -25,7 +25,7 @@ int pi3_check_launch(const char* what) {
 
 extern "C" const char* pi3_last_error(void) { return g_err; }
 
-extern "C" int pi3_abi_version(void) { return 1; }
+extern "C" int pi3_abi_version(void) { return 2; }   // 2: caller-provided workspaces (attention, group-norm statistics)
 
 // Number of visible devices (does not create a context); used by the loader to fail loudly on a box without a GPU.
 extern "C" int pi3_device_count(void) {

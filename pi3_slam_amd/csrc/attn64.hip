@@ -449,6 +449,15 @@ __global__ __launch_bounds__(256) void a64_knorm_kernel(const bf16_t* __restrict
     atomicMax((unsigned*)&out[b * H + head], __float_as_uint(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]))));
 }
 
+// max_s |k[b, s, h, :]|^2 into out[B*H] (must be zeroed): the pre-pass of the bounded-score path, also used by the
+// two-pass form of pi3_gemm_qkv.
+int pi3_attention_knorm_launch(const void* k, long tok_stride, long batch_stride, int B, int S, int H, float* out,
+                               hipStream_t stream) {
+  hipLaunchKernelGGL(a64_knorm_kernel, dim3(A64_KNORM_BLOCKS, H, B), dim3(256), 0, stream, (const bf16_t*)k, tok_stride,
+                     batch_stride, S, H, out);
+  return pi3_check_launch("a64_knorm");
+}
+
 // Called by pi3_attention (attn.hip) for long sequences; same argument meaning.
 // k2max_ws: caller-provided [B*H] floats (or null -> online-max loop); k2max_ready: already filled by the producer.
 int pi3_attention64_launch(const void* q, const void* k, const void* v, long tok_stride, long batch_stride, void* o,

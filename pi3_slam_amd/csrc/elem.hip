@@ -165,6 +165,17 @@ __global__ __launch_bounds__(256) void qknorm_rope_kernel(bf16_t* qkv, long rows
   }
 }
 
+int pi3_qknorm_rope_launch(void* qkv, long rows, int H, int T, const int* pos, const float* cs, const float* qw,
+                           const float* qb, const float* kw, const float* kb, float eps, float qscale, int do_rope,
+                           hipStream_t stream) {
+  const long nvec = rows * 2 * H;
+  long blocks = (nvec + 31) / 32;
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  hipLaunchKernelGGL(qknorm_rope_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, (bf16_t*)qkv, rows, H, T, pos,
+                     cs, qw, qb, kw, kb, eps, qscale, do_rope);
+  return pi3_check_launch("qknorm_rope");
+}
+
 extern "C" int pi3_qknorm_rope(void* qkv, long rows, int H, int T, const int* pos, const float* cs, const float* qw,
                                const float* qb, const float* kw, const float* kb, float eps, float qscale,
                                int do_rope, void* stream) {
@@ -173,12 +184,7 @@ extern "C" int pi3_qknorm_rope(void* qkv, long rows, int H, int T, const int* po
     pi3_set_error("pi3_qknorm_rope: bad arguments rows=%ld H=%d T=%d", rows, H, T);
     return PI3_ERR_ARG;
   }
-  const long nvec = rows * 2 * H;
-  long blocks = (nvec + 31) / 32;
-  if (blocks > 256 * 16) blocks = 256 * 16;
-  hipLaunchKernelGGL(qknorm_rope_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (bf16_t*)qkv,
-                     rows, H, T, pos, cs, qw, qb, kw, kb, eps, qscale, do_rope);
-  return pi3_check_launch("qknorm_rope");
+  return pi3_qknorm_rope_launch(qkv, rows, H, T, pos, cs, qw, qb, kw, kb, eps, qscale, do_rope, (hipStream_t)stream);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -191,6 +191,7 @@ extern "C" int pi3_gemm(const void* A, long lda, const void* W, long ldw, int M,
   p.rpg = rpg; p.gstride = gstride; p.goff = goff; p.addtab = addtab; p.ldadd = ldadd;
   p.qscale = qscale; p.qcols = qcols;
   p.cH = 0; p.cW = 0; p.cC = 0;
+  p.qk_mode = 0; p.qk_k2max = nullptr;
   hipStream_t s = (hipStream_t)stream;
   if (in_dtype == 0) {  // large bf16 GEMMs: 256x256 pipelined kernel (PI3_GEMM_IMPL=1 forces the 128x128 kernel)
     static int impl = -1;
@@ -217,6 +218,69 @@ extern "C" int pi3_gemm(const void* A, long lda, const void* W, long ldw, int M,
   return PI3_ERR_ARG;
 }
 
+// The packed qkv projection of a transformer block with what follows it on q and k fused into the epilogue
+// (FlashAttentionRope.forward, pi3/models/layers/attention.py:323-334; BlockRope, layers/block.py:310-335):
+//   qkv = x W^T + b  (bf16) ;  q, k <- LayerNorm_64(q), LayerNorm_64(k) per head (if qw) ;  q, k <- RoPE2D(q, k, pos)
+//   (if pos) ;  q <- q * qscale ;  k2max[(row / attnS) * H + head] = max |k|^2 (if k2max: consumed by pi3_attention).
+// Large problems run the 256x256 kernel with the fused epilogue (no second pass over the 395 MB qkv buffer); others
+// run the plain GEMM followed by the stand-alone pi3_qknorm_rope pass (+ the key-norm pre-pass): same results up to
+// fp32 summation order inside the LayerNorm statistic.
+int pi3_qknorm_rope_launch(void* qkv, long rows, int H, int T, const int* pos, const float* cs, const float* qw,
+                           const float* qb, const float* kw, const float* kb, float eps, float qscale, int do_rope,
+                           hipStream_t stream);
+int pi3_attention_knorm_launch(const void* k, long tok_stride, long batch_stride, int B, int S, int H, float* out,
+                               hipStream_t stream);
+
+extern "C" int pi3_gemm_qkv(const void* A, long lda, const void* W, long ldw, int M, int K, int H, const float* bias,
+                            void* qkv, long ldo, int T, const int* pos, const float* cs, const float* qw,
+                            const float* qb, const float* kw, const float* kb, float eps, float qscale,
+                            float* k2max, int attn_B, int attn_S, void* stream) {
+  const int N = 3 * H * 64;
+  if (!A || !W || !qkv || M <= 0 || K <= 0 || H <= 0 || T <= 0 || (K % 64) || (N % BN) || ldo != N ||
+      ((qw != nullptr) != (kw != nullptr)) || ((qw != nullptr) != (qb != nullptr)) || ((kw != nullptr) != (kb != nullptr)) ||
+      ((pos != nullptr) != (cs != nullptr)) || (k2max && (attn_B <= 0 || attn_S <= 0 || (long)attn_B * attn_S != M))) {
+    pi3_set_error("pi3_gemm_qkv: bad arguments M=%d K=%d H=%d T=%d (packed [M][3*H*64] output, K %% 64 == 0)", M, K, H, T);
+    return PI3_ERR_ARG;
+  }
+  if ((lda * 2) % 16 || (ldw * 2) % 16 || ((uintptr_t)A & 15) || ((uintptr_t)W & 15) || ((uintptr_t)qkv & 15)) {
+    pi3_set_error("pi3_gemm_qkv: operands must be 16-byte aligned with 16-byte-multiple row strides");
+    return PI3_ERR_ARG;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  if (k2max && hipMemsetAsync(k2max, 0, (size_t)attn_B * H * sizeof(float), s) != hipSuccess) {
+    pi3_set_error("pi3_gemm_qkv: hipMemsetAsync failed");
+    return PI3_ERR_LAUNCH;
+  }
+  GemmParams p;
+  p.A = A; p.lda = lda; p.W = W; p.ldw = ldw; p.M = M; p.N = N; p.K = K;
+  p.bias = bias; p.gamma = nullptr; p.resid = nullptr; p.ldr = 0; p.out = qkv; p.ldo = ldo;
+  p.rpg = 0; p.gstride = 0; p.goff = 0; p.addtab = nullptr; p.ldadd = 0; p.qscale = 1.f; p.qcols = 0;
+  p.cH = 0; p.cW = 0; p.cC = 0;
+  p.qk_mode = 1; p.qk_H = H; p.qk_T = T; p.qk_pos = pos; p.qk_cs = cs;
+  p.qk_qw = qw; p.qk_qb = qb; p.qk_kw = kw; p.qk_kb = kb; p.qk_eps = eps; p.qk_qscale = qscale;
+  p.qk_k2max = k2max; p.qk_attnS = attn_S > 0 ? attn_S : M;
+  static int fuse = -1;   // PI3_QKV_FUSE: 0 = always the two-pass form (A/B knob; both forms are correct)
+  if (fuse < 0) {
+    const char* e = getenv("PI3_QKV_FUSE");
+    fuse = e ? atoi(e) : 1;
+  }
+  if (fuse) {
+    const int rc = pi3_gemm256_try(p, 0, 0, s);
+    if (rc <= 0) return rc;
+  }
+  // two-pass form: plain projection, then the in-place q/k pass, then the key-norm pre-pass
+  p.qk_mode = 0; p.qk_k2max = nullptr;
+  int rc = pi3_gemm256_try(p, 0, 0, s);
+  if (rc > 0) rc = launch_gemm<true, true, 0>(p, s);
+  if (rc != 0) return rc;
+  rc = pi3_qknorm_rope_launch(qkv, M, H, T, pos, cs, qw, qb, kw, kb, eps, qscale, pos != nullptr, s);
+  if (rc != 0) return rc;
+  if (k2max)
+    return pi3_attention_knorm_launch((const char*)qkv + (size_t)H * 64 * 2, ldo, (long)attn_S * ldo, attn_B, attn_S, H,
+                                      k2max, s);
+  return PI3_OK;
+}
+
 // 3x3 convolution, stride 1, replicate padding, as an implicit GEMM on an NHWC bf16 image (nn.Conv2d(..., 3, padding=1,
 // padding_mode='replicate') in moge/model/modules.py:47-60,146-164).  img: bf16 [B][H][W][ldc] with C % 64 == 0 used
 // channels; wgt: bf16 [N][9*C], k = (ky*3 + kx)*C + ci; out rows = pixels.  Epilogue as pi3_gemm (bias, resid, act).
@@ -234,6 +298,7 @@ extern "C" int pi3_conv3x3(const void* img, long ldc, int B, int H, int W, int C
   p.bias = bias; p.gamma = nullptr; p.resid = resid; p.ldr = ldr; p.out = out; p.ldo = ldo;
   p.rpg = 0; p.gstride = 0; p.goff = 0; p.addtab = nullptr; p.ldadd = 0; p.qscale = 1.f; p.qcols = 0;
   p.cH = H; p.cW = W; p.cC = C;
+  p.qk_mode = 0; p.qk_k2max = nullptr;
   hipStream_t s = (hipStream_t)stream;
   if (out_dtype == 0 && act == 0) return launch_gemm<true, true, 0, true>(p, s);
   if (out_dtype == 1 && act == 0) return launch_gemm<true, false, 0, true>(p, s);

@@ -51,11 +51,38 @@ __device__ __forceinline__ void g2_stage_half(const char* gbase, long ld_bytes, 
 // tail is not hidden behind another block's math).  bias / qscale / activation / LayerScale are applied in registers
 // before the transpose; residual and table adds in the streaming pass (coalesced 16-byte loads).
 // Row pitch 144 B (bf16) / 272 B (f32): 16-byte aligned for ds_read_b128, at most 2-way write conflicts.
-template <bool OUT_BF16, int ACT>
+// QK (bf16 output only): the wave's 64 columns are exactly one head of q, k or v (n_base % 64 == 0) and the lane holds,
+// for each of its 8 rows m, 16 of the head's 64 dims: d = ni*16 + nq + r.  The RoPE partner of dim d < 16 (d + 16) and
+// of 32 <= d < 48 (d + 16) sits in the SAME lane (tiles ni and ni + 1, same r); the LayerNorm row statistic is an
+// in-lane sum of 16 values + two shuffles (lanes frow, frow+16, frow+32, frow+48).  Rounding points as the stand-alone
+// pi3_qknorm_rope pass (and the reference under autocast): the Linear output is rounded to bf16 first.
+template <bool OUT_BF16, int ACT, bool QK = false>
 __device__ __forceinline__ void g2_epilogue_lds(const GemmParams& p, f32x4 (&acc)[4][8], int m_base, int n_base,
                                                 char* wl, int lane) {
   const int frow = lane & 15;
   const int nq = (lane >> 4) * 4;
+  // ---- fused q/k head epilogue state
+  int qk_part = 2, qk_head = 0;
+  f32x4 lnw[4], lnb[4];
+  bool qk_ln = false;
+  float k2 = 0.f, k2n = 0.f;  // running max_rows |k|^2 of this lane (k heads only): first / next attention batch
+  long qk_split = 0;          // first row of the next attention batch (the wave's 128 rows span at most two: attnS >= 128)
+  if constexpr (QK) {
+    const int hh = n_base >> 6;
+    qk_part = hh / p.qk_H;
+    qk_head = hh - qk_part * p.qk_H;
+    const float* w = qk_part == 0 ? p.qk_qw : p.qk_kw;
+    const float* b = qk_part == 0 ? p.qk_qb : p.qk_kb;
+    qk_ln = (qk_part < 2) && (w != nullptr);
+    if (p.qk_k2max) qk_split = ((long)(m_base / p.qk_attnS) + 1) * p.qk_attnS;
+    if (qk_ln) {
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) {
+        lnw[ni] = *(const f32x4*)(w + ni * 16 + nq);
+        lnb[ni] = *(const f32x4*)(b + ni * 16 + nq);
+      }
+    }
+  }
   f32x4 bias4[4], gamma4[4];
 #pragma unroll
   for (int ni = 0; ni < 4; ++ni) {
@@ -80,6 +107,83 @@ __device__ __forceinline__ void g2_epilogue_lds(const GemmParams& p, f32x4 (&acc
     for (int mq = 0; mq < MI_PER_PASS; ++mq) {
       const int mi = pass * MI_PER_PASS + mq;
       char* rowp = wl + (mq * 16 + frow) * PITCH;
+      if constexpr (QK) {
+        if (qk_part < 2) {
+          f32x4 x[4];
+#pragma unroll
+          for (int ni = 0; ni < 4; ++ni) {
+            const f32x4 v = acc[ni][mi] + bias4[ni];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) x[ni][r] = (float)(bf16_t)v[r];       // the Linear output is a bf16 tensor
+          }
+          if (qk_ln) {
+            float s = 0.f;
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) s += (x[ni][0] + x[ni][1]) + (x[ni][2] + x[ni][3]);
+            s += __shfl_xor(s, 16, 64);
+            s += __shfl_xor(s, 32, 64);
+            const float mean = s * (1.0f / 64.0f);
+            float q = 0.f;
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                x[ni][r] -= mean;
+                q += x[ni][r] * x[ni][r];
+              }
+            q += __shfl_xor(q, 16, 64);
+            q += __shfl_xor(q, 32, 64);
+            const float rstd = rsqrtf(q * (1.0f / 64.0f) + p.qk_eps);
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) x[ni] = x[ni] * rstd * lnw[ni] + lnb[ni];
+          }
+          if (p.qk_pos) {
+            const int m = m_base + pass * ROWS_PER_PASS + mq * 16 + frow;
+            const int t = (m < p.M ? m : p.M - 1) % p.qk_T;
+            const int py = p.qk_pos[2 * t], px = p.qk_pos[2 * t + 1];
+            const float* ty = p.qk_cs + ((long)py * 16 + nq) * 2;     // (cos, sin) of freq nq .. nq+3
+            const float* tx = p.qk_cs + ((long)px * 16 + nq) * 2;
+            const f32x4 cy0 = *(const f32x4*)ty, cy1 = *(const f32x4*)(ty + 4);
+            const f32x4 cx0 = *(const f32x4*)tx, cx1 = *(const f32x4*)(tx + 4);
+            const float cyv[4] = {cy0[0], cy0[2], cy1[0], cy1[2]}, syv[4] = {cy0[1], cy0[3], cy1[1], cy1[3]};
+            const float cxv[4] = {cx0[0], cx0[2], cx1[0], cx1[2]}, sxv[4] = {cx0[1], cx0[3], cx1[1], cx1[3]};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float a0 = x[0][r], a1 = x[1][r], b0 = x[2][r], b1 = x[3][r];
+              x[0][r] = a0 * cyv[r] - a1 * syv[r];      // dim j < 16:  x cos - partner sin
+              x[1][r] = a1 * cyv[r] + a0 * syv[r];      // dim j + 16:  x cos + partner sin
+              x[2][r] = b0 * cxv[r] - b1 * sxv[r];
+              x[3][r] = b1 * cxv[r] + b0 * sxv[r];
+            }
+          }
+          const float sc = qk_part == 0 ? p.qk_qscale : 1.0f;
+          float ksq = 0.f;
+#pragma unroll
+          for (int ni = 0; ni < 4; ++ni) {
+            u32x2 o;
+            o[0] = pack_bf16x2(x[ni][0] * sc, x[ni][1] * sc);
+            o[1] = pack_bf16x2(x[ni][2] * sc, x[ni][3] * sc);
+            *(u32x2*)(rowp + (ni * 16 + nq) * 2) = o;
+            if (qk_part == 1) {      // |k|^2 of the STORED (bf16) values, as the attention kernel will read them
+#pragma unroll
+              for (int e = 0; e < 2; ++e) {
+                const float lo = __uint_as_float(o[e] << 16), hi = __uint_as_float(o[e] & 0xffff0000u);
+                ksq += lo * lo + hi * hi;
+              }
+            }
+          }
+          if (qk_part == 1 && p.qk_k2max) {
+            ksq += __shfl_xor(ksq, 16, 64);
+            ksq += __shfl_xor(ksq, 32, 64);
+            const int m = m_base + pass * ROWS_PER_PASS + mq * 16 + frow;
+            if (m < p.M) {
+              if (m < qk_split) k2 = fmaxf(k2, ksq);
+              else k2n = fmaxf(k2n, ksq);
+            }
+          }
+          continue;
+        }
+      }
 #pragma unroll
       for (int ni = 0; ni < 4; ++ni) {
         f32x4 v = acc[ni][mi] + bias4[ni];
@@ -130,6 +234,18 @@ __device__ __forceinline__ void g2_epilogue_lds(const GemmParams& p, f32x4 (&acc
       }
     }
   }
+  if constexpr (QK) {
+    if (qk_part == 1 && p.qk_k2max) {
+      // one atomic per wave and attention batch (non-negative floats order like their bit patterns)
+      const int b_lo = m_base / p.qk_attnS;
+      const float mx = wave_max(k2), mxn = wave_max(k2n);
+      if (lane == 0 && m_base < p.M) {
+        atomicMax((unsigned*)&p.qk_k2max[(long)b_lo * p.qk_H + qk_head], __float_as_uint(mx));
+        if (qk_split <= (long)min(m_base + 127, p.M - 1))
+          atomicMax((unsigned*)&p.qk_k2max[(long)(b_lo + 1) * p.qk_H + qk_head], __float_as_uint(mxn));
+      }
+    }
+  }
 }
 
 // NOEPI: timing-only ablation (no output) to separate the main loop from the epilogue.
@@ -138,7 +254,7 @@ __device__ __forceinline__ void g2_epilogue_lds(const GemmParams& p, f32x4 (&acc
 // other is in its load segment, instead of both loading and then both competing for the matrix pipe.  The staging
 // schedule already keeps every restage >= 2 phases after the last read of the region and reads a staged tile a phase
 // after the vmcnt wait that retires it, which is what the half-phase lag of the second group needs.
-template <bool OUT_BF16, int ACT, bool NOEPI = false, bool STAG = false>
+template <bool OUT_BF16, int ACT, bool NOEPI = false, bool STAG = false, bool QK = false>
 __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -272,17 +388,17 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
     // bf16 outputs go through the LDS transpose (8-byte pieces per lane otherwise); f32 outputs already store 64-byte
     // row segments per 4 lanes straight from the accumulators, and the LDS round trip measured slower for them
     if constexpr (OUT_BF16)
-      g2_epilogue_lds<OUT_BF16, ACT>(p, acc, bm * G2_BM + wm * 128, bn * G2_BN + wn * 64, smem + wave * G2_EPI_WAVE,
-                                     lane);
+      g2_epilogue_lds<OUT_BF16, ACT, QK>(p, acc, bm * G2_BM + wm * 128, bn * G2_BN + wn * 64,
+                                         smem + wave * G2_EPI_WAVE, lane);
     else
       gemm_epilogue<OUT_BF16, ACT, 4, 8>(p, acc, bm * G2_BM + wm * 128, bn * G2_BN + wn * 64, lane);
   }
 }
 
-template <bool OUT_BF16, int ACT, bool NOEPI = false, bool STAG = false>
+template <bool OUT_BF16, int ACT, bool NOEPI = false, bool STAG = false, bool QK = false>
 static int launch256(const GemmParams& p, hipStream_t stream) {
   const int nbm = (p.M + G2_BM - 1) / G2_BM, nbn = p.N / G2_BN;
-  auto kern = gemm256_kernel<OUT_BF16, ACT, NOEPI, STAG>;
+  auto kern = gemm256_kernel<OUT_BF16, ACT, NOEPI, STAG, QK>;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS_TOTAL);
@@ -296,11 +412,21 @@ static int launch256(const GemmParams& p, hipStream_t stream) {
 int pi3_gemm256_try(const GemmParams& p, int out_dtype, int act, hipStream_t stream) {
   if ((p.N % G2_BN) != 0 || (p.K % 64) != 0 || p.M < 1024) return 1;
   if (out_dtype == 0 && (p.resid || p.addtab)) return 1;   // the bf16 streaming pass carries no residual / table add
+  if (p.qk_mode) {   // fused q/k head epilogue: bf16 output, no activation, one head per wave column block
+    if (out_dtype != 0 || act != 0 || p.gamma || p.rpg || p.N != 3 * p.qk_H * 64 ||
+        (p.qk_k2max && p.qk_attnS < 128))
+      return 1;
+    return launch256<true, 0, false, true, true>(p, stream);
+  }
+#ifdef PI3_DEV_ABLATIONS   // timing-only variant that writes NOTHING: development builds only
   static int abl = -1;
   if (abl < 0) {
     const char* e = getenv("PI3_GEMM_ABL");
     abl = e ? atoi(e) : 0;
   }
+#else
+  constexpr int abl = 0;
+#endif
   static int stag = -1;   // PI3_GEMM_STAG: 0 = all eight waves in lockstep (A/B knob)
   if (stag < 0) {
     const char* e = getenv("PI3_GEMM_STAG");

@@ -16,6 +16,17 @@ struct GemmParams {
   // implicit-GEMM 3x3 convolution, replicate padding (moge/model/modules.py:47-60): A is an NHWC image
   // [B][cH][cW][cC] (cC % 64 == 0), row m = pixel, K = 9 * cC with k = (ky*3 + kx) * cC + ci; cW == 0 -> plain GEMM
   int cH, cW, cC;
+  // fused q/k epilogue of the packed qkv projection (gemm256 only; FlashAttentionRope.forward,
+  // pi3/models/layers/attention.py:323-334): columns [0, H*64) = q, [H*64, 2*H*64) = k, rest = v.  For q and k heads:
+  // per-head LayerNorm(64) (optional: qk_w != null), RoPE-2D (optional), softmax scale folded into q, and max_s |k|^2
+  // per (attention batch, head) for the bounded-score attention path (optional: k2max != null).
+  int qk_mode;               // 0 = off
+  int qk_H, qk_T;            // heads; tokens per frame (row % T indexes pos)
+  const int* qk_pos;         // [T][2] (y, x) or null (no RoPE)
+  const float* qk_cs;        // [npos][16][2] (cos, sin)
+  const float* qk_qw; const float* qk_qb; const float* qk_kw; const float* qk_kb;   // LayerNorm(64) affine or null
+  float qk_eps, qk_qscale;
+  float* qk_k2max; int qk_attnS;   // k2max[(row / attnS) * H + head]
 };
 
 

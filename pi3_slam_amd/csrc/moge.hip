@@ -8,22 +8,25 @@
 
 // ---------------------------------------------------------------------------------------------------------------
 // GroupNorm statistics (nn.GroupNorm(G, C), modules.py:47-56: G = C/32 'group_norm' or G = 1 'layer_norm').
-// x: f32 [B][HW][ldx]; stats: f64 [B][G][2] (sum, sum of squares), must be zeroed by the caller.
-// A wave walks pixels; lane l owns channels l, l+64, ... (a fixed group per (lane, j)), fp32 partials per pixel chunk,
-// fp64 across chunks, LDS f64 atomics per block, one global f64 atomic per (block, group).
+// x: f32 [B][HW][ldx]; stats: f64 [B][G][2] (sum, sum of squares).
+// DETERMINISTIC by construction (no floating-point atomics: an order-dependent last bit here flips a bf16 rounding
+// downstream once in a while, and chunk files must not depend on block scheduling):
+//   pass 1  a wave walks pixels; lane l owns channels l, l+64, ...; fp32 partials per 64-pixel chunk, fp64 across
+//           chunks; the block's four waves are combined in wave order through LDS and the block writes its
+//           per-CHANNEL partials to the caller's workspace ws[b][block][2][C];
+//   pass 2  one workgroup per sample: thread c sums channel c over the blocks in block order, then one wave per group
+//           adds the group's channels in a fixed order (lane-strided, then a fixed shuffle tree).
 // ---------------------------------------------------------------------------------------------------------------
 #define GN_MAXJ 16  // C <= 1024
+#define GN_MAXBLOCKS 512
 // NJ = channels per lane (C <= 64 NJ): compile-time so that the pixel loop carries no per-channel branches and four
 // pixels' loads are in flight per lane (the first version walked one pixel at a time under 16 predicated channel slots
 // and was latency-bound: 185 us for 30 MB)
 template <int NJ>
 __global__ __launch_bounds__(256) void groupnorm_stats_kernel(const float* __restrict__ x, long ldx, int HW, int C,
-                                                              int G, double* __restrict__ stats) {
-  __shared__ double acc[2 * 64];  // G <= 64 groups per sample handled (C <= 1024, cpg >= 16)
+                                                              double* __restrict__ ws) {
+  __shared__ double part[3][2][64 * NJ];   // waves 1..3 hand their per-channel sums to wave 0
   const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int cpg = C / G;
-  for (int i = tid; i < 2 * G; i += 256) acc[i] = 0.0;
-  __syncthreads();
   double s[NJ], q[NJ];
   int ch[NJ];       // clamped channel: loads stay in bounds, lanes past C are dropped at the end
 #pragma unroll
@@ -53,44 +56,89 @@ __global__ __launch_bounds__(256) void groupnorm_stats_kernel(const float* __res
         const bool live = p + u < pe;
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
-          const float t = live ? v[u][j] : 0.f;   // same summation order as before: pixel by pixel, fp32 in the chunk
+          const float t = live ? v[u][j] : 0.f;   // pixel by pixel, fp32 in the chunk
           fs[j] += t;
           fq[j] += t * t;
         }
       }
     }
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) { s[j] += (double)fs[j]; q[j] += (double)fq[j]; }   // lanes past C are dropped below
+    for (int j = 0; j < NJ; ++j) { s[j] += (double)fs[j]; q[j] += (double)fq[j]; }
   }
+  if (wave > 0) {
 #pragma unroll
-  for (int j = 0; j < NJ; ++j) {
-    const int c = lane + 64 * j;
-    if (c < C) {
-      const int g = c / cpg;
-      atomicAdd(&acc[2 * g], s[j]);
-      atomicAdd(&acc[2 * g + 1], q[j]);
+    for (int j = 0; j < NJ; ++j) {
+      part[wave - 1][0][lane + 64 * j] = s[j];
+      part[wave - 1][1][lane + 64 * j] = q[j];
     }
   }
   __syncthreads();
-  for (int i = tid; i < 2 * G; i += 256) atomicAdd(&stats[(long)b * 2 * G + i], acc[i]);
+  if (wave == 0) {
+    double* o = ws + ((long)b * gridDim.x + blockIdx.x) * 2 * C;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int c = lane + 64 * j;
+      if (c < C) {
+        double ss = s[j], qq = q[j];
+#pragma unroll
+        for (int w = 0; w < 3; ++w) { ss += part[w][0][c]; qq += part[w][1][c]; }   // wave order 0, 1, 2, 3
+        o[c] = ss;
+        o[C + c] = qq;
+      }
+    }
+  }
 }
 
-extern "C" int pi3_groupnorm_stats(const float* x, long ldx, int B, int HW, int C, int G, double* stats,
-                                   void* stream) {
-  if (!x || !stats || B <= 0 || HW <= 0 || C <= 0 || G <= 0 || (C % G) || C > 64 * GN_MAXJ || G > 64) {
+__global__ __launch_bounds__(256) void groupnorm_finalize_kernel(const double* __restrict__ ws, int nblk, int C, int G,
+                                                                 double* __restrict__ stats) {
+  __shared__ double tot[2][64 * GN_MAXJ];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const double* w = ws + (long)b * nblk * 2 * C;
+  for (int c = tid; c < 2 * C; c += 256) {          // index c runs over [sum | sumsq][channel]: coalesced across lanes
+    double a = 0.0;
+    for (int k = 0; k < nblk; ++k) a += w[(long)k * 2 * C + c];   // block order
+    tot[c >= C][c >= C ? c - C : c] = a;
+  }
+  __syncthreads();
+  const int cpg = C / G;
+  for (int g = wave; g < G; g += 4) {
+    double ss = 0.0, qq = 0.0;
+    for (int c = lane; c < cpg; c += 64) { ss += tot[0][g * cpg + c]; qq += tot[1][g * cpg + c]; }
+    ss = wave_sum_f64(ss);
+    qq = wave_sum_f64(qq);
+    if (lane == 0) {
+      stats[((long)b * G + g) * 2] = ss;
+      stats[((long)b * G + g) * 2 + 1] = qq;
+    }
+  }
+}
+
+static inline int gn_blocks(int HW) {
+  int bx = (HW + 511) / 512;
+  return bx > GN_MAXBLOCKS ? GN_MAXBLOCKS : bx;
+}
+
+extern "C" long pi3_groupnorm_ws_doubles(int B, int HW, int C) { return (long)B * gn_blocks(HW) * 2 * C; }
+
+extern "C" int pi3_groupnorm_stats(const float* x, long ldx, int B, int HW, int C, int G, double* stats, double* ws,
+                                   long ws_doubles, void* stream) {
+  if (!x || !stats || !ws || B <= 0 || HW <= 0 || C <= 0 || G <= 0 || (C % G) || C > 64 * GN_MAXJ) {
     pi3_set_error("pi3_groupnorm_stats: bad arguments C=%d G=%d", C, G);
     return PI3_ERR_ARG;
   }
-  (void)hipMemsetAsync(stats, 0, sizeof(double) * 2 * G * B, (hipStream_t)stream);
-  int bx = (HW + 511) / 512;
-  if (bx > 512) bx = 512;
+  if (ws_doubles < pi3_groupnorm_ws_doubles(B, HW, C)) {
+    pi3_set_error("pi3_groupnorm_stats: workspace of %ld doubles, need %ld", ws_doubles, pi3_groupnorm_ws_doubles(B, HW, C));
+    return PI3_ERR_WORKSPACE;
+  }
+  const int bx = gn_blocks(HW);
   const dim3 grid(bx, B), block(256);
   hipStream_t st = (hipStream_t)stream;
-  if (C <= 64) hipLaunchKernelGGL(groupnorm_stats_kernel<1>, grid, block, 0, st, x, ldx, HW, C, G, stats);
-  else if (C <= 128) hipLaunchKernelGGL(groupnorm_stats_kernel<2>, grid, block, 0, st, x, ldx, HW, C, G, stats);
-  else if (C <= 256) hipLaunchKernelGGL(groupnorm_stats_kernel<4>, grid, block, 0, st, x, ldx, HW, C, G, stats);
-  else if (C <= 512) hipLaunchKernelGGL(groupnorm_stats_kernel<8>, grid, block, 0, st, x, ldx, HW, C, G, stats);
-  else hipLaunchKernelGGL(groupnorm_stats_kernel<16>, grid, block, 0, st, x, ldx, HW, C, G, stats);
+  if (C <= 64) hipLaunchKernelGGL(groupnorm_stats_kernel<1>, grid, block, 0, st, x, ldx, HW, C, ws);
+  else if (C <= 128) hipLaunchKernelGGL(groupnorm_stats_kernel<2>, grid, block, 0, st, x, ldx, HW, C, ws);
+  else if (C <= 256) hipLaunchKernelGGL(groupnorm_stats_kernel<4>, grid, block, 0, st, x, ldx, HW, C, ws);
+  else if (C <= 512) hipLaunchKernelGGL(groupnorm_stats_kernel<8>, grid, block, 0, st, x, ldx, HW, C, ws);
+  else hipLaunchKernelGGL(groupnorm_stats_kernel<16>, grid, block, 0, st, x, ldx, HW, C, ws);
+  hipLaunchKernelGGL(groupnorm_finalize_kernel, dim3(B), dim3(256), 0, st, ws, bx, C, G, stats);
   return pi3_check_launch("groupnorm_stats");
 }
 

@@ -20,6 +20,7 @@ _vp, _i, _l, _f, _u64 = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_ulonglong
 # name -> argtypes; every function returns int (0 = ok) except the two noted below.  Mirrors include/pi3slam_hip.h.
 SIGNATURES = {
     "pi3_gemm": [_vp, _l, _vp, _l, _i, _i, _i, _i, _vp, _vp, _vp, _l, _vp, _l, _i, _i, _i, _i, _i, _vp, _l, _f, _i, _vp],
+    "pi3_gemm_qkv": [_vp, _l, _vp, _l, _i, _i, _i, _vp, _vp, _l, _i, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _i, _i, _vp],
     "pi3_attention": [_vp, _vp, _vp, _l, _l, _vp, _l, _l, _i, _i, _i, _i, _vp, _i, _vp],
     "pi3_layernorm": [_vp, _l, _i, _i, _vp, _vp, _f, _vp, _l, _i, _i, _i, _vp, _vp],
     "pi3_qknorm_rope": [_vp, _l, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _i, _vp],
@@ -36,7 +37,7 @@ SIGNATURES = {
     "pi3_gather_keypoints": [_vp] * 6 + [_i] * 4 + [_vp] * 7,
     "pi3_focal_shift": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp],
     "pi3_conv3x3": [_vp, _l, _i, _i, _i, _i, _vp, _i, _vp, _vp, _l, _vp, _l, _i, _i, _vp],
-    "pi3_groupnorm_stats": [_vp, _l, _i, _i, _i, _i, _vp, _vp],
+    "pi3_groupnorm_stats": [_vp, _l, _i, _i, _i, _i, _vp, _vp, _l, _vp],
     "pi3_groupnorm_apply": [_vp, _l, _i, _i, _i, _i, _i, _vp, _vp, _vp, _f, _i, _vp, _l, _vp],
     "pi3_convt_scatter": [_vp, _l, _i, _i, _i, _i, _i, _i, _vp, _l, _vp],
     "pi3_uv_affine": [_vp, _l, _i, _i, _i, _i, _vp, _l, _i, _vp, _vp, _vp, _i, _vp],
@@ -74,6 +75,8 @@ def load(require_gpu: bool = True) -> C.CDLL:
         lib.pi3_last_error.argtypes = []
         lib.pi3_abi_version.restype = _i
         lib.pi3_device_count.restype = _i
+        lib.pi3_groupnorm_ws_doubles.restype = _l
+        lib.pi3_groupnorm_ws_doubles.argtypes = [_i, _i, _i]
         for name, argt in SIGNATURES.items():
             if os.environ.get("PI3_DEV_PARTIAL") and not hasattr(lib, name):
                 continue  # development builds of a subset of the kernels only

@@ -49,6 +49,26 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, M: Optional[int
     return out
 
 
+def gemm_qkv(a: torch.Tensor, w: torch.Tensor, qkv: torch.Tensor, *, M: int, H: int, bias: Optional[torch.Tensor],
+             T: int, pos: Optional[torch.Tensor] = None, cs: Optional[torch.Tensor] = None, qw=None, qb=None, kw=None,
+             kb=None, eps: float = 1e-5, qscale: float = QSCALE, k2max: Optional[torch.Tensor] = None,
+             attn_B: int = 0, attn_S: int = 0) -> torch.Tensor:
+    """qkv projection + per-head q/k LayerNorm(64) + RoPE-2D + softmax-scale fold (+ max |k|^2 per (batch, head) into
+    k2max) in one launch where the 256x256 kernel applies, else projection + the stand-alone passes."""
+    lib = _L.load()
+    assert a.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and qkv.dtype == torch.bfloat16
+    assert a.stride(1) == 1 and w.stride(1) == 1 and qkv.is_contiguous() and qkv.shape[1] == 3 * H * 64
+    assert w.shape[0] == 3 * H * 64
+    if pos is not None:
+        assert pos.dtype == torch.int32 and pos.is_contiguous() and cs is not None
+    rc = lib.pi3_gemm_qkv(a.data_ptr(), a.stride(0), w.data_ptr(), w.stride(0), M, w.shape[1], H, _L.ptr(bias),
+                          qkv.data_ptr(), qkv.stride(0), T, _L.ptr(pos), _L.ptr(cs) if pos is not None else None,
+                          _L.ptr(qw), _L.ptr(qb), _L.ptr(kw), _L.ptr(kb), float(eps), float(qscale), _L.ptr(k2max),
+                          attn_B, attn_S, _L.stream_ptr())
+    _L.check(rc, "pi3_gemm_qkv")
+    return qkv
+
+
 def attention(qkv: torch.Tensor, out: torch.Tensor, B: int, S: int, H: int,
               k2max: Optional[torch.Tensor] = None) -> torch.Tensor:
     """qkv: packed [B*S, 3*H*64] bf16 (q pre-scaled by QSCALE); out: [B*S, H*64] bf16.
@@ -322,7 +342,10 @@ def conv3x3(img: torch.Tensor, H: int, W: int, C: int, wgt: torch.Tensor, bias: 
 def groupnorm_stats(x: torch.Tensor, HW: int, C: int, G: int, stats: torch.Tensor) -> None:
     lib = _L.load()
     assert x.dtype == torch.float32 and stats.dtype == torch.float64 and stats.numel() >= 2 * G
-    rc = lib.pi3_groupnorm_stats(x.data_ptr(), x.stride(0), 1, HW, C, G, stats.data_ptr(), _L.stream_ptr())
+    n_ws = int(lib.pi3_groupnorm_ws_doubles(1, HW, C))
+    ws = torch.empty(n_ws, device=x.device, dtype=torch.float64)     # per-block channel partials (deterministic sum)
+    rc = lib.pi3_groupnorm_stats(x.data_ptr(), x.stride(0), 1, HW, C, G, stats.data_ptr(), ws.data_ptr(), n_ws,
+                                 _L.stream_ptr())
     _L.check(rc, "pi3_groupnorm_stats")
 
 

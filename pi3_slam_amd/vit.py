@@ -19,23 +19,30 @@ def run_block(w: Dict[str, torch.Tensor], prefix: str, x: torch.Tensor, S: int, 
     xn, qkv, ao, hid = bufs
     ops.layernorm(x, w[f"{prefix}.norm1.weight"], w[f"{prefix}.norm1.bias"], xn, eps, rows=S)
     fused = rope or qk_norm
-    ops.gemm(xn, w[f"{prefix}.attn.qkv.weight"], qkv, M=S, bias=w[f"{prefix}.attn.qkv.bias"],
-             qscale=1.0 if fused else ops.QSCALE, qcols=0 if fused else D)
+    k2max = None
     if fused:
-        ops.qknorm_rope(qkv, S, heads, T, pos, cs,
-                        w.get(f"{prefix}.attn.q_norm.weight") if qk_norm else None,
-                        w.get(f"{prefix}.attn.q_norm.bias") if qk_norm else None,
-                        w.get(f"{prefix}.attn.k_norm.weight") if qk_norm else None,
-                        w.get(f"{prefix}.attn.k_norm.bias") if qk_norm else None,
-                        eps=1e-5 if qk_norm else eps, qscale=ops.QSCALE, do_rope=rope)
+        # q/k LayerNorm(64) + RoPE-2D + softmax scale (+ max |k|^2 for the long-sequence attention) ride in the qkv
+        # epilogue: one launch, no second pass over the packed qkv buffer
+        if attn_S >= 4096:
+            k2max = torch.empty(attn_B * heads, device=x.device, dtype=torch.float32)
+        ops.gemm_qkv(xn, w[f"{prefix}.attn.qkv.weight"], qkv[:S], M=S, H=heads, bias=w[f"{prefix}.attn.qkv.bias"], T=T,
+                     pos=pos if rope else None, cs=cs if rope else None,
+                     qw=w.get(f"{prefix}.attn.q_norm.weight") if qk_norm else None,
+                     qb=w.get(f"{prefix}.attn.q_norm.bias") if qk_norm else None,
+                     kw=w.get(f"{prefix}.attn.k_norm.weight") if qk_norm else None,
+                     kb=w.get(f"{prefix}.attn.k_norm.bias") if qk_norm else None,
+                     eps=1e-5, qscale=ops.QSCALE, k2max=k2max, attn_B=attn_B, attn_S=attn_S)
+    else:
+        ops.gemm(xn, w[f"{prefix}.attn.qkv.weight"], qkv, M=S, bias=w[f"{prefix}.attn.qkv.bias"], qscale=ops.QSCALE,
+                 qcols=D)
     if attn_events is not None:  # bench.py: HIP events on the launch stream around the dominant kernel
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        ops.attention(qkv, ao, attn_B, attn_S, heads)
+        ops.attention(qkv, ao, attn_B, attn_S, heads, k2max=k2max)
         e1.record()
         attn_events.append((e0, e1))
     else:
-        ops.attention(qkv, ao, attn_B, attn_S, heads)
+        ops.attention(qkv, ao, attn_B, attn_S, heads, k2max=k2max)
     ops.gemm(ao, w[f"{prefix}.attn.proj.weight"], x, M=S, bias=w[f"{prefix}.attn.proj.bias"],
              gamma=w[f"{prefix}.ls1.gamma"] if ls else None, resid=x)
     ops.layernorm(x, w[f"{prefix}.norm2.weight"], w[f"{prefix}.norm2.bias"], xn, eps, rows=S)

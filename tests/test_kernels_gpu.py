@@ -177,6 +177,61 @@ def test_qknorm_rope_matches_fp32_reference(dev):
         assert torch.equal(qkv.view(rows, 3, H, 64)[:, 2], qkv0.view(rows, 3, H, 64)[:, 2])     # v untouched
 
 
+@pytest.mark.parametrize("use_norm,use_rope", [(True, True), (False, True), (True, False)])
+def test_fused_qkv_epilogue_matches_fp32_reference_and_two_pass_form(dev, use_norm, use_rope):
+    """pi3_gemm_qkv on the 256x256 kernel (q/k LayerNorm(64) + RoPE-2D + scale + max|k|^2 fused into the projection's
+    epilogue) against (a) a plain fp32 torch reference of the same op and (b) the two-pass form (pi3_gemm +
+    pi3_qknorm_rope): identical up to fp32 summation order inside the LayerNorm statistic (<= 1 bf16 ulp, rare).
+    M is not a multiple of 256 and the rows form two attention batches that split inside a tile."""
+    from oracle import pi3_ref
+    from pi3_slam_amd import ops
+    torch.manual_seed(7)
+    H, T, K = 4, 41, 256                      # N = 3 * 4 * 64 = 768 = 3 column tiles
+    attn_B, attn_S = 2, 41 * 33               # 2 x 1353 rows: the batch boundary falls inside a 256-row tile
+    M = attn_B * attn_S
+    a = torch.randn(M, K, device=dev).bfloat16()
+    w = (torch.randn(3 * H * 64, K, device=dev) / K ** 0.5).bfloat16()
+    bias = torch.randn(3 * H * 64, device=dev) * 0.1
+    pos = torch.zeros(T, 2, dtype=torch.int32)
+    for t in range(5, T):
+        pos[t, 0], pos[t, 1] = (t - 5) // 6 + 1, (t - 5) % 6 + 1
+    inv = 1.0 / (100.0 ** (torch.arange(0, 32, 2).float() / 32))
+    ang = torch.arange(8).float()[:, None] * inv[None]
+    cs = torch.stack([ang.cos(), ang.sin()], -1).contiguous().to(dev)
+    qw, qb, kw, kb = [(torch.randn(64) * 0.2 + (1 if i % 2 == 0 else 0)).to(dev) for i in range(4)]
+    norm = dict(qw=qw, qb=qb, kw=kw, kb=kb) if use_norm else {}
+    posd = pos.to(dev) if use_rope else None
+    # (1) fused
+    qkv = torch.empty(M, 3 * H * 64, device=dev, dtype=torch.bfloat16)
+    k2 = torch.full((attn_B * H,), -1.0, device=dev)
+    ops.gemm_qkv(a, w, qkv, M=M, H=H, bias=bias, T=T, pos=posd, cs=cs if use_rope else None, eps=1e-5, k2max=k2,
+                 attn_B=attn_B, attn_S=attn_S, **norm)
+    # (2) two passes
+    qkv2 = torch.empty_like(qkv)
+    ops.gemm(a, w, qkv2, M=M, bias=bias)
+    ops.qknorm_rope(qkv2, M, H, T, posd, cs if use_rope else None, norm.get("qw"), norm.get("qb"), norm.get("kw"),
+                    norm.get("kb"), eps=1e-5, do_rope=use_rope)
+    torch.cuda.synchronize()
+    d = (qkv.view(torch.int16).int() - qkv2.view(torch.int16).int()).abs()
+    assert int(d.max()) <= 1 and float((d > 0).float().mean()) < 5e-3, (int(d.max()), float((d > 0).float().mean()))
+    assert torch.equal(qkv.view(M, 3, H, 64)[:, 2], qkv2.view(M, 3, H, 64)[:, 2])                 # v: plain projection
+    # max |k|^2 per (batch, head) of the STORED k (what the attention kernel reads)
+    kk = qkv.view(attn_B, attn_S, 3, H, 64)[:, :, 1].float()
+    ref_k2 = (kk * kk).sum(-1).amax(1).reshape(-1)
+    assert torch.allclose(k2, ref_k2, rtol=1e-5), (k2, ref_k2)
+    # (3) fp32 torch reference of the op
+    x = torch.nn.functional.linear(a.float(), w.float(), bias).bfloat16().float().cpu().view(M // T, T, 3, H, 64)
+    q, k = x[:, :, 0].transpose(1, 2), x[:, :, 1].transpose(1, 2)
+    if use_norm:
+        q = torch.nn.functional.layer_norm(q, (64,), qw.cpu(), qb.cpu(), 1e-5)
+        k = torch.nn.functional.layer_norm(k, (64,), kw.cpu(), kb.cpu(), 1e-5)
+    if use_rope:
+        xpos = pos.long()[None].expand(M // T, T, 2)
+        q, k = pi3_ref.rope2d(q, xpos), pi3_ref.rope2d(k, xpos)
+    got = qkv.float().cpu().view(M // T, T, 3, H, 64)
+    assert rel(got[:, :, 0], q.transpose(1, 2) * ops.QSCALE)[0] < 5e-3 and rel(got[:, :, 1], k.transpose(1, 2))[0] < 5e-3
+
+
 def test_recipe_fill_bit_identical_to_numpy(dev):
     from pi3_slam_amd import ops
     from pi3_slam_amd.recipe import fnv1a64, recipe_tensor

@@ -95,15 +95,19 @@ def test_moge_infer_graphed_equals_infer(engine):
     a, b = (torch.rand(3, 84, 112, device="cuda:0", generator=g) for _ in range(2))
     c = torch.rand(3, 70, 98, device="cuda:0", generator=g)
     keys = ("depth", "mask", "intrinsics", "points_affine")
-    for img in (a, b, c, a):
-        ref = {k: engine.infer(img, resolution_level=0)[k].clone() for k in keys}
+    keys = keys + ("shift", "focal")
+    bad = []
+    for it, img in enumerate((a, b, c, a)):
+        ref = {k: v.clone() for k, v in engine.infer(img, resolution_level=0).items() if k in keys}
         out = engine.infer_graphed(img, resolution_level=0)
         torch.cuda.synchronize()
         for k in keys:
             x, y = out[k], ref[k]
             if x.dtype.is_floating_point:
                 x, y = torch.nan_to_num(x, posinf=1e30), torch.nan_to_num(y, posinf=1e30)
-            assert torch.equal(x, y), k
+            if not torch.equal(x, y):
+                bad.append((it, k, (x.float() - y.float()).abs().max().item()))
+    assert not bad, bad
 
 
 def test_moge_focal_shift_on_reference_pointmap(engine):

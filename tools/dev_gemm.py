@@ -52,3 +52,23 @@ for (N, K, kind) in [(3072, 1024, "qkv"), (1024, 1024, "proj"), (4096, 1024, "fc
     tot += ms
     print(f"IMPL={os.environ.get('PI3_GEMM_IMPL','0')} {kind:5s} M={M} N={N} K={K}: {ms:.3f} ms  {2.0*M*N*K/ms/1e9:.1f} TF/s")
 print(f"IMPL={os.environ.get('PI3_GEMM_IMPL','0')} block total {tot:.3f} ms")
+
+# fused q/k epilogue (decoder block: qk-norm + RoPE + scale + max|k|^2) against the two-pass form it replaces
+H, T = 16, 643
+a = torch.randn(M, 1024, device=dev).bfloat16()
+w = (torch.randn(3072, 1024, device=dev) / 32).bfloat16()
+bias = torch.randn(3072, device=dev) * 0.1
+pos = torch.zeros(T, 2, dtype=torch.int32)
+pos[5:, 0] = (torch.arange(T - 5) // 29 + 1).int(); pos[5:, 1] = (torch.arange(T - 5) % 29 + 1).int()
+pos = pos.to(dev)
+inv = 1.0 / (100.0 ** (torch.arange(0, 32, 2).float() / 32))
+ang = torch.arange(30).float()[:, None] * inv[None]
+cs = torch.stack([ang.cos(), ang.sin()], -1).contiguous().to(dev)
+qw, qb, kw, kb = [(torch.randn(64) * 0.2 + (1 if i % 2 == 0 else 0)).to(dev) for i in range(4)]
+qkv = torch.empty(M, 3072, device=dev, dtype=torch.bfloat16)
+k2 = torch.empty(H, device=dev)
+fused = lambda: ops.gemm_qkv(a, w, qkv, M=M, H=H, bias=bias, T=T, pos=pos, cs=cs, qw=qw, qb=qb, kw=kw, kb=kb, k2max=k2, attn_B=1, attn_S=M)
+def two_pass():
+    ops.gemm(a, w, qkv, M=M, bias=bias)
+    ops.qknorm_rope(qkv, M, H, T, pos, cs, qw, qb, kw, kb, eps=1e-5)
+print(f"qkv fused epilogue: {timeit(fused):.3f} ms   two-pass (gemm + qknorm_rope, no key-norm pre-pass): {timeit(two_pass):.3f} ms")

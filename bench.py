@@ -1,19 +1,27 @@
 """Headline benchmark of the hot path (BASELINE.json): frames/s end-to-end for chunk creation + overlap alignment at
-chunk_length=100, overlap=20, 4:3 input -> 308x406 (what calculate_target_size makes of a 512x384 frame).
+chunk_length=100, overlap=20, 512x384 input (-> 308x406 by the reference's calculate_target_size rule).
 
     python bench.py [--gpus N] [--steps K] [--warmup W]        (N > 1: launched by torch.distributed.run, one rank/GPU)
 
-One "step" = one chunk of 100 synthetic frames already resident in HBM: pi3 forward -> masks -> MoGe metric scale (if a
-MoGe engine is available) -> per-frame intrinsics (LM) -> grid keypoints (K=200) gather + fp16 pack -> D2H of the packed
-chunk -> overlap Sim(3) alignment against the previous chunk (+ for N > 1 an RCCL all-gather of the boundary blocks and
-the prefix composition).  Prints ONE JSON line on rank 0.
+One "step" = one chunk of 100 synthetic frames through the PRODUCT path (OfflineChunkCreator.process_chunks), starting
+from the decoded uint8 frames in pinned host memory, as SURVEY.md §8(d) defines the metric:
+    H2D of the frames -> device resize + ToTensor (pi3_ingest_frames) -> pi3 forward -> masks -> MoGe metric scale ->
+    per-frame intrinsics (LM) -> grid keypoints (K=200) gather + fp16 pack -> packed D2H -> chunk dict on the host ->
+    closed-form Sim(3) overlap alignment against the previous chunk and its application
+(N > 1: one chunk per rank per step, then the wave alignment: RCCL all-gather of the boundary blocks, each rank's own
+solve, a 136-byte all-gather of the transforms, prefix composition, application).  The stages of consecutive chunks
+overlap exactly as in production (copy stream / compute stream / host), so the K timed steps include one pipeline fill.
+Prints ONE JSON line on rank 0.  Extra keys (N = 1): per-stage milliseconds, the 378x504 and K=400 variants, the
+from-disk rate of process_and_save(), and the CPU baseline of the whole path.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import shutil
 import sys
+import tempfile
 import time
 
 import torch
@@ -21,33 +29,91 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-CL, OV, H, W, KP = 100, 20, 308, 406, 200
+CL, OV, SRC_H, SRC_W, H, W, KP = 100, 20, 384, 512, 308, 406, 200
 PEAK_BF16_DENSE_TFLOPS = 2500.0   # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md)
-# HBM-side bytes of ONE global-attention launch from rocprofv3 PMC passes (profiles/r01c_attention_pmc.csv):
-# FETCH_SIZE 643 097 KB (x2: gfx950 reports half of a wide coalesced read stream) + WRITE_SIZE 128 601 KB.
-# Algorithmic bytes are 527 MB (q, k, v read once + o written); L2 hit rate 95.8 % on the K/V re-reads.
+# HBM-side bytes of ONE global-attention launch, from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this
+# kernel (profiles/r01c_attention_pmc.csv; tools/pmc_summary.py): FETCH_SIZE 643 097 KB (x2: gfx950 reports half of a
+# wide coalesced read stream) + WRITE_SIZE 128 601 KB.  PMC counters cannot be read from inside this process, so the
+# JSON cites the committed profile; algorithmic bytes are 527 MB (q, k, v read once + o written), L2 hit rate 95.8 %.
 ATTN_TRAFFIC_BYTES = (2 * 643096.75 + 128600.9) * 1024.0
+ATTN_TRAFFIC_SOURCE = "profiles/r01c_attention_pmc.csv"
 
 
-def cpu_baseline(engine_cfg, n_frames: int = 4):
-    """The oracle (CPU restatement of the reference forward, fp32 eager) timed on this box's host cores on a bounded
-    sample of the same workload.  Weights are produced on the device by the same recipe and copied over (values do
-    not matter for timing; this avoids a minute of numpy)."""
-    from oracle import pi3_ref
+def synthetic_frames_u8(n: int, h: int, w: int, seed: int) -> torch.Tensor:
+    """n smooth synthetic frames (low-frequency structure + noise), uint8 [n, h, w, 3], pinned."""
+    g = torch.Generator().manual_seed(seed)
+    yy = torch.linspace(0, 1, h)[None, :, None, None]
+    xx = torch.linspace(0, 1, w)[None, None, :, None]
+    ph = torch.rand(n, 1, 1, 3, generator=g) * 6.28
+    img = 0.5 + 0.25 * torch.sin(7 * xx + 3 * yy + ph) * torch.cos(5 * yy - ph) + 0.1 * torch.rand(n, h, w, 3, generator=g)
+    out = (img.clamp(0, 1) * 255).to(torch.uint8).contiguous()
+    return out.pin_memory() if torch.cuda.is_available() else out
+
+
+def cpu_baseline(engine_cfg, n_frames: int):
+    """The oracle (CPU restatement of the reference) timed on this box's host cores over the WHOLE path on a bounded
+    sample: pi3 forward (fp32, flash SDPA as BASELINE.md §3.2), masks, MoGe metric scale (oracle forward + focal/shift),
+    per-frame intrinsics (scipy LM), grid keypoints + gather + colours, and the numpy closed-form Sim(3) on a 20 x 200
+    overlap block.  Per-chunk stages (MoGe, alignment) are charged pro rata (n_frames / 100) so the figure is the rate of
+    a 100-frame chunk with the forward measured at n_frames (its global attention is quadratic in the frame count, so
+    the true 100-frame CPU rate is lower still)."""
+    import numpy as np
+    from oracle import moge_ref, pi3_ref, post_ref
+    from pi3_slam_amd.moge import SYNTHETIC_CONFIG, moge_param_shapes, moge_recipe_params
+    from pi3_slam_amd import ops
+    from pi3_slam_amd.recipe import fnv1a64
     from pi3_slam_amd.weights import param_shapes, recipe_fill_device
-    sd = {}
-    for name, shape in param_shapes(engine_cfg).items():
-        sd[name] = recipe_fill_device(name, shape, "cuda:0").cpu()
-    imgs = torch.rand(1, n_frames, 3, H, W)
+    sd = {name: recipe_fill_device(name, shape, "cuda:0").cpu() for name, shape in param_shapes(engine_cfg).items()}
+    msd = {}
+    for name, shape in moge_param_shapes(SYNTHETIC_CONFIG).items():     # same recipe as the device engine
+        off, sc = moge_recipe_params(name, shape)
+        t = torch.empty(shape, device="cuda:0", dtype=torch.float32)
+        ops.recipe_fill(t, fnv1a64("moge." + name), off, sc)
+        msd[name] = t.cpu()
+    from pi3_slam_amd.weights import IMAGE_MEAN, IMAGE_STD
+    msd["encoder.image_mean"] = torch.tensor(IMAGE_MEAN).view(1, 3, 1, 1)
+    msd["encoder.image_std"] = torch.tensor(IMAGE_STD).view(1, 3, 1, 1)
     threads = min(torch.get_num_threads(), len(os.sched_getaffinity(0)), 16)  # the GPU box grants 16 cores per GPU
     torch.set_num_threads(threads)
+    imgs = torch.rand(1, n_frames, 3, H, W, generator=torch.Generator().manual_seed(0))
+    pi3_ref.SDPA_FLASH = True
+    t = {}
     t0 = time.perf_counter()
-    pi3_ref.pi3_forward(sd, imgs, engine_cfg)
-    dt = time.perf_counter() - t0
-    return {"value": n_frames / dt, "unit": "frames/s", "cores": threads, "kind": "port",
-            "sample": f"oracle pi3 forward only (no post-processing), {n_frames} frames {H}x{W}, fp32 eager torch CPU, "
-                      f"{dt:.1f} s; global attention is quadratic in the frame count, so the CPU rate at 100 frames "
-                      f"is lower still (BASELINE.md)"}
+    out = pi3_ref.pi3_forward(sd, imgs, engine_cfg)
+    t["forward"] = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    lp, conf, pts = out["local_points"][0], out["conf"][0], out["points"][0]
+    masks = post_ref.compute_masks(conf, lp)
+    t["masks"] = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    md = moge_ref.moge_infer(msd, SYNTHETIC_CONFIG, imgs[0, 0], 9)["depth"]
+    m0 = masks[0] & torch.isfinite(md)
+    if m0.any():
+        post_ref.scale_factor(md, lp[0][..., 2], m0)
+    t["moge"] = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    post_ref.estimate_camera_parameters(lp, conf)
+    t["intrinsics"] = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    kp = post_ref.grid_keypoints(n_frames, H, W, KP, torch.Generator().manual_seed(0))
+    post_ref.interpolate_at_keypoints(pts, lp, conf, masks, kp, H, W)
+    post_ref.keypoint_colors(imgs[0], kp)
+    t["gather"] = time.perf_counter() - t0
+    rng = np.random.default_rng(1)
+    world = rng.standard_normal((OV, KP, 3)) + np.array([0, 0, 4.0])
+    kp16 = (rng.random((OV, KP, 2)) * 300).astype(np.float16)
+    t0 = time.perf_counter()
+    post_ref.align_chunks(world.astype(np.float16), (world * 0.8 + 0.1).astype(np.float16), kp16, kp16,
+                          np.eye(4, dtype=np.float32), True)
+    t["align"] = time.perf_counter() - t0
+    per_frames = t["forward"] + t["masks"] + t["intrinsics"] + t["gather"]
+    per_chunk = t["moge"] + t["align"]
+    total = per_frames + per_chunk * n_frames / CL
+    return {"value": n_frames / total, "unit": "frames/s", "cores": threads, "kind": "port",
+            "sample": f"oracle whole path on {n_frames} frames {H}x{W}, fp32 torch CPU with flash SDPA, {threads} threads: "
+                      + ", ".join(f"{k} {v:.2f} s" for k, v in t.items())
+                      + f"; per-chunk stages (moge, align) charged x {n_frames}/{CL}; the global attention is quadratic "
+                        f"in the frame count, so the 100-frame CPU rate is lower still (BASELINE.md)"}
 
 
 def main() -> None:
@@ -56,6 +122,8 @@ def main() -> None:
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-frames", type=int, default=8, help="frames of the CPU baseline sample (8: ~30 s; 32 = BASELINE configs[0])")
+    ap.add_argument("--no-extras", action="store_true", help="skip the 378x504 / K=400 / from-disk extras")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -78,12 +146,12 @@ def main() -> None:
         _w = torch.zeros(1, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(_w)
         dist.all_gather([torch.empty_like(_w) for _ in range(world)], _w)
+    comm_dev = dev if backend == "nccl" else "cpu"
 
     from pi3_slam_amd import ops
-    from pi3_slam_amd.alignment import create_view_graph_matches, estimate_sim3
+    from pi3_slam_amd.alignment import align_and_refine_reconstructions, create_view_graph_matches, transform_chunk
     from pi3_slam_amd.chunk_creator import OfflineChunkCreator, OfflineCreatorConfig
-    from pi3_slam_amd.dist import (allgather_boundaries, compose_global, pack_boundary,
-                                   relative_sim3_from_boundaries, unpack_boundary)
+    from pi3_slam_amd.dist import (align_wave, allgather_boundaries, default_solver, pack_boundary, unpack_boundary)
     from pi3_slam_amd.engine import Pi3Engine
     from pi3_slam_amd.weights import Pi3Config
 
@@ -96,51 +164,60 @@ def main() -> None:
     except Exception as e:  # noqa: BLE001
         if rank == 0:
             print(f"[bench] MoGe engine unavailable ({e}); metric scaling is NOT in the timed region", file=sys.stderr)
-    cc = OfflineCreatorConfig(model_path="recipe", output_dir="/tmp/pi3_bench_out", chunk_length=CL, overlap=OV,
-                              device=str(dev), do_metric_depth=moge is not None, keypoint_type="grid",
-                              max_num_keypoints=KP, num_loader_workers=0)
-    creator = OfflineChunkCreator(cc, model=engine, moge_model=moge)
-    creator.target_size = (H, W)
 
-    g = torch.Generator(device=dev).manual_seed(1234 + rank)
-    frames = torch.rand(1, CL, 3, H, W, device=dev, generator=g)      # synthetic, resident in HBM
+    def make_creator(kp: int, out_dir: str = "/tmp/pi3_bench_out", workers: int = 0):
+        cc = OfflineCreatorConfig(model_path="recipe", output_dir=out_dir, chunk_length=CL, overlap=OV,
+                                  device=str(dev), do_metric_depth=moge is not None, keypoint_type="grid",
+                                  max_num_keypoints=kp, num_loader_workers=workers, device_resize=True)
+        return OfflineChunkCreator(cc, model=engine, moge_model=moge)
+
+    creator = make_creator(KP)
+    creator.target_size = (H, W)
+    frames_u8 = synthetic_frames_u8(CL, SRC_H, SRC_W, 1234 + rank)        # decoded frames, pinned host memory
     paths = [[f"frame_{i:06d}.png"] for i in range(CL)]
     matches = create_view_graph_matches(CL, OV)
     attn_events = []
-    prev = None
+    align_stream = torch.cuda.Stream(dev, priority=-1)   # the tiny alignment kernels slot in beside the next chunk's forward
+    solve = default_solver(OV, dev, CL)
 
-    def step(timed: bool):
-        nonlocal prev
-        # route the events through the creator's model call
-        if timed:
-            orig = creator.model.forward
-            creator.model = _EventedModel(engine, attn_events)
-        chunk = creator._process_single_chunk(frames, paths)
-        if timed:
-            creator.model = engine
-        if world == 1:
-            if prev is not None:
-                out = estimate_sim3(prev, chunk, matches, str(dev))
-                ops.sim3_apply(out[13:29].contiguous(), chunk["points"].to(dev, torch.float32).contiguous(),
-                               chunk["camera_poses"].to(dev).contiguous())
-        else:
-            blocks = [unpack_boundary(b.cpu(), OV, KP)
-                      for b in allgather_boundaries(pack_boundary(chunk, OV, KP), dev if backend == "nccl" else "cpu")]
-            rel = [torch.eye(4, dtype=torch.float64, device=dev).reshape(16)]
-            for r in range(1, world):
-                rel.append(relative_sim3_from_boundaries(blocks[r - 1], blocks[r], OV, dev, chunk_length=CL)[13:29])
-            compose_global(torch.stack(rel))
-        prev = chunk
-
-    class _EventedModel:
+    class _EventedModel:   # HIP events on the launch stream around the dominant kernel (global attention)
         def __init__(self, eng, events):
             self.eng, self.events = eng, events
 
         def __call__(self, imgs):
             return self.eng.forward(imgs, global_attn_events=self.events)
 
-    for _ in range(args.warmup):
-        step(False)
+    def run(cr, src, n_steps: int, timed: bool, kind: str = "u8"):
+        """n_steps chunks through the pipelined product path + alignment; returns the per-chunk _metrics."""
+        state = {"prev": None, "G_last": torch.eye(4, dtype=torch.float64), "prev_tail": None, "wave": 0}
+        cr.model = _EventedModel(engine, attn_events) if timed else engine
+        items = ({"frames": src, "kind": kind, "paths": paths, "meta": {"chunk_index": i}} for i in range(n_steps))
+        stats = []
+        for meta, chunk in cr.process_chunks(items):
+            t0 = time.perf_counter()
+            with torch.cuda.stream(align_stream):
+                if world == 1:
+                    if state["prev"] is not None:
+                        ok, _ = align_and_refine_reconstructions(state["prev"], chunk, matches, device=str(dev))
+                        assert ok
+                    state["prev"] = chunk
+                else:
+                    kk = int(chunk["keypoints"].shape[1])
+                    blocks = [unpack_boundary(b, OV, kk, n_frames=CL)
+                              for b in allgather_boundaries(pack_boundary(chunk, OV, kk, device=comm_dev), comm_dev)]
+                    w0 = state["wave"] * world
+                    Gs, _ = align_wave(rank, world, w0, w0 + world, blocks, state["prev_tail"], state["G_last"], solve,
+                                       comm_dev, lambda T: ops.sim3_compose_prefix(T.to(dev)))
+                    transform_chunk(chunk, Gs[rank], device=str(dev), absolute=True)
+                    state["G_last"], state["prev_tail"], state["wave"] = Gs[-1], blocks[-1], state["wave"] + 1
+            m = dict(chunk["_metrics"])
+            m["align_host_s"] = time.perf_counter() - t0
+            stats.append(m)
+        cr.model = engine
+        return stats
+
+    import contextlib
+    quiet = contextlib.redirect_stdout(open(os.devnull, "w")) if rank != 0 else contextlib.nullcontext()
 
     def sync_all():
         torch.cuda.synchronize(dev)
@@ -149,15 +226,17 @@ def main() -> None:
             dist.barrier()
             torch.cuda.synchronize(dev)
 
-    sync_all()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(True)
-    sync_all()
-    dt = time.perf_counter() - t0
+    with quiet:
+        if args.warmup > 0:
+            run(creator, frames_u8, args.warmup, False)
+        sync_all()
+        t0 = time.perf_counter()
+        stats = run(creator, frames_u8, args.steps, True)
+        sync_all()
+        dt = time.perf_counter() - t0
     if world > 1:
         import torch.distributed as dist
-        tt = torch.tensor([dt], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
+        tt = torch.tensor([dt], device=comm_dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
@@ -168,6 +247,7 @@ def main() -> None:
         attn_ms = sum(a.elapsed_time(b) for a, b in attn_events) / max(1, len(attn_events))
         achieved = attn_flops / (attn_ms * 1e-3) / 1e12
         fl = engine.flops(1, CL, H, W)
+        mean = lambda k: 1e3 * sum(s.get(k, 0.0) for s in stats) / max(1, len(stats))   # noqa: E731
         line = {
             "metric": "frames/sec end-to-end (chunk create+align), 512x384 cl=100 ov=20",
             "value": world * CL * args.steps / dt,
@@ -181,24 +261,91 @@ def main() -> None:
             "vs_baseline": None,
             "dtype": "bf16",
             "data": "synthetic",
-            "config": {"workload": "configs[1]-shaped synthetic chunk: 100 frames 308x406 (512x384 after "
-                                   "calculate_target_size), cl=100 ov=20, grid keypoints K=200, recipe weights",
+            "config": {"workload": "configs[1]-shaped synthetic chunk: 100 frames 512x384 uint8 in pinned host memory -> "
+                                   "308x406 (calculate_target_size), cl=100 ov=20, grid keypoints K=200, recipe weights",
                        "chunks_per_step_per_gpu": 1, "parallelism": f"chunk-parallel x{world}",
+                       "timed_from": "pinned host uint8 frames (H2D + device resize inside the timed region)",
                        "moge_metric_scale_in_timed_region": moge is not None,
                        "algorithmic_tflop_per_chunk": fl["total"] / 1e12},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_DENSE_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_BF16_DENSE_TFLOPS, "traffic": ATTN_TRAFFIC_BYTES,
-                         "kernel": "attn_fwd64_kernel<8, true, true> + key-norm pre-pass (global attention, S=64300, 16 heads, d=64)",
+                         "traffic_source": ATTN_TRAFFIC_SOURCE,
+                         "kernel": "attn_fwd64_kernel<8, true, true> (global attention, S=64300, 16 heads, d=64)",
                          "launch_ms": attn_ms, "launches_timed": len(attn_events),
                          "end_to_end_tflops": fl["total"] * args.steps / dt / 1e12},
+            "stages_ms": {"stage_in_h2d_resize": mean("stage_in_s"), "pi3_forward": mean("infer_s"),
+                          "post_masks_scale_intrinsics_gather": mean("post_s"), "align_host_wait": mean("align_host_s"),
+                          "note": "GPU-event times per chunk (copy stream / compute stream); stages of consecutive chunks "
+                                  "overlap, so they do not add up to ms_per_step"},
         }
+        if world == 1 and not args.no_extras:
+            with contextlib.redirect_stdout(sys.stderr):
+                line["extras"] = extras(engine, moge, make_creator, run, dev)
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(cfg)
+            line["cpu_baseline"] = cpu_baseline(cfg, args.cpu_frames)
         _REAL_STDOUT.write(json.dumps(line) + "\n")
         _REAL_STDOUT.flush()
     if world > 1:
         import torch.distributed as dist
         dist.destroy_process_group()
+
+
+def extras(engine, moge, make_creator, run, dev):
+    """Variants BASELINE.md §3 names, each a short run outside the headline number."""
+    out = {}
+
+    def timed(cr, src, n, kind):
+        run(cr, src, 1, False, kind)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        run(cr, src, n, False, kind)
+        torch.cuda.synchronize(dev)
+        return (time.perf_counter() - t0) / n
+
+    # K = 400 grid keypoints (spacing 16, 432 -> 400)
+    cr = make_creator(400)
+    cr.target_size = (H, W)
+    s = timed(cr, synthetic_frames_u8(CL, SRC_H, SRC_W, 77), 3, "u8")
+    out["k400"] = {"frames_per_s": CL / s, "ms_per_step": s * 1e3}
+    # direct 378x504 tensors ("nominal 512x384 pixel count", 912.8 TFLOP per chunk): resident fp32 frames
+    cr = make_creator(KP)
+    cr.target_size = (378, 504)
+    big = torch.rand(1, CL, 3, 378, 504, device=dev)
+    s = timed(cr, big, 2, "float")
+    out["direct_378x504"] = {"frames_per_s": CL / s, "ms_per_step": s * 1e3,
+                             "algorithmic_tflop_per_chunk": engine.flops(1, CL, 378, 504)["total"] / 1e12}
+    del big
+    # from disk: PNG files -> loader workers (decode only) -> the same pipeline -> chunk files written by the writer thread
+    from PIL import Image
+    tmp = tempfile.mkdtemp(prefix="pi3_bench_disk_")
+    try:
+        n_distinct, n_files = 100, 660                       # 8 full chunks (stride 80) + a 20-frame tail
+        fr = synthetic_frames_u8(n_distinct, SRC_H, SRC_W, 5).numpy()
+        os.makedirs(os.path.join(tmp, "frames"))
+        files = []
+        for i in range(n_files):                              # 100 distinct images, the rest are hard links to them
+            p = os.path.join(tmp, "frames", f"frame_{i:05d}.png")
+            if i < n_distinct:
+                Image.fromarray(fr[i]).save(p, compress_level=1)
+            else:
+                os.link(files[i % n_distinct], p)
+            files.append(p)
+        cr = make_creator(KP, os.path.join(tmp, "out"), workers=min(8, max(2, len(os.sched_getaffinity(0)) // 2)))
+        cr.process_and_save(files[:120])                      # tables, graphs of both chunk shapes: untimed
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        saved = cr.process_and_save(files)
+        dt = time.perf_counter() - t0
+        nfr, steady = cr.last_run["frames"], cr.last_run["wall_after_first_chunk_decoded_s"]
+        out["from_disk_process_and_save"] = {
+            "frames_per_s": nfr / steady, "frames_per_s_incl_loader_start": nfr / dt, "frames": nfr, "chunks": len(saved),
+            "wall_s": dt, "wall_after_first_chunk_decoded_s": steady, "loader_workers": cr.config.num_loader_workers,
+            "note": "660 PNG files 512x384 (100 distinct), decoded by the loader workers, device resize, chunk files written "
+                    "by the writer thread.  frames_per_s counts from the moment the first decoded chunk leaves the loader "
+                    "(worker processes forked and first 100 PNGs decoded), frames_per_s_incl_loader_start from the call"}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    return out
 
 
 if __name__ == "__main__":

@@ -1,36 +1,46 @@
-"""OfflineChunkCreator: drop-in mirror of slam/offline_chunk_creator.py (same config dataclass, same methods, same
-chunk_*.pt / chunks_manifest.json / chunk_metadata.json layout), with every arithmetic step on the MI355X:
+"""OfflineChunkCreator: drop-in for slam/offline_chunk_creator.py — same config dataclass, same public and
+underscore methods, same chunk_*.pt / chunks_manifest.json / chunk_metadata.json layout — with every arithmetic step
+on the MI355X and the host kept off the critical path.
 
-    frames (1,N,3,H,W) --H2D--> Pi3Engine.forward --> masks --> MoGe metric scale --> intrinsics (LM per frame)
-                                --> grid keypoints --> gather + fp16 pack --> D2H of N*K*~20 B --> torch.save
+One chunk is three stages, and consecutive chunks overlap them (the reference overlaps only the loader,
+offline_chunk_creator.py:279-287):
 
-The reference copies the four dense maps (350 MB at N=100) to the host and samples them there
-(offline_chunk_creator.py:204-213, 228); here only the packed per-keypoint tensors cross PCIe.
-Error conventions are the reference's: model / keypoint / intrinsics / save failures are printed and the run goes on
-with the feature disabled (offline_chunk_creator.py:77-79, 92-94, 199-201, 242-243, 330-331).
+    stage-in   (copy stream)     pinned frames --H2D--> [device resize / undistortion] -> imgs (1,N,3,H,W) fp32
+    launch     (compute stream)  Pi3Engine.forward -> masks -> metric scale (MoGe runs beside the forward on its own
+                                 stream: it needs only frame 0) -> intrinsics (LM per frame) -> grid keypoints gather +
+                                 fp16 pack -> ONE packed D2H into a pinned buffer
+    finish     (host)            wait for the chunk's event, cut the pinned buffer into the result dict, hand it to the
+                                 writer thread (torch.save)
+
+While the GPU runs chunk k the host finishes chunk k-1 and the copy stream brings in chunk k+1.  The reference copies
+the four dense maps (350 MB at N=100) to the host and samples them there (offline_chunk_creator.py:204-213, 228); here
+only ~1 MB of per-keypoint values crosses PCIe.  Failure policy as in the reference: a model / keypoint / intrinsics /
+save problem is reported and the run continues without that feature (offline_chunk_creator.py:77-79, 92-94, 199-201,
+242-243, 330-331).
 """
 from __future__ import annotations
 
 import json
 import os
 import time
-from dataclasses import dataclass
-from typing import Dict, List, Optional, Tuple
+from concurrent.futures import ThreadPoolExecutor
+from dataclasses import dataclass, field
+from typing import Dict, Iterable, Iterator, List, Optional, Tuple
 
 import torch
 from torch.utils.data import DataLoader
 
 from . import ops
 from .engine import Pi3Engine
-from .image_io import ChunkImageDataset, calculate_target_size, ingest_frames_device
-from .undistortion import create_undistortion_maps
+from .image_io import ChunkImageDataset, ThreadedChunkLoader, calculate_target_size, ingest_frames_device
 from .keypoints import create_keypoint_extractor
+from .undistortion import create_undistortion_maps
 from .weights import Pi3Config
 
 
 @dataclass
 class OfflineCreatorConfig:
-    """Same fields and defaults as slam/offline_chunk_creator.py:36-50, plus the knobs the reference hard-codes."""
+    """Fields and defaults of slam/offline_chunk_creator.py:36-50, then the knobs the reference hard-codes."""
     model_path: str
     output_dir: str
     chunk_length: int = 100
@@ -49,10 +59,22 @@ class OfflineCreatorConfig:
     keypoint_seed: Optional[int] = 0
     device_resize: bool = False             # loader workers only decode; Resize + ToTensor run on the GPU (bit-identical)
     hip_graph: bool = False                 # replay the per-chunk pi3 forward as one captured hipGraph per chunk shape
+    overlap_stages: bool = True             # False: stage-in, launch and finish of a chunk run back to back (A/B knob)
+
+
+_UV_CACHE: Dict = {}
 
 
 def _uv_tables(H: int, W: int, device) -> Tuple[torch.Tensor, torch.Tensor]:
-    """normalized_view_plane_uv (utils/geometry_torch.py:39-51) as two 1-D fp32 tables (constants per image size)."""
+    """normalized_view_plane_uv (utils/geometry_torch.py:39-51) as two 1-D fp32 tables (constants per image size, built
+    once: a pageable H2D copy per chunk would stall the host behind the whole forward pass)."""
+    key = (H, W, str(device))
+    if key not in _UV_CACHE:
+        _UV_CACHE[key] = _uv_tables_build(H, W, device)
+    return _UV_CACHE[key]
+
+
+def _uv_tables_build(H: int, W: int, device) -> Tuple[torch.Tensor, torch.Tensor]:
     ar = W / H
     sx = ar / (1 + ar ** 2) ** 0.5
     sy = 1 / (1 + ar ** 2) ** 0.5
@@ -61,72 +83,98 @@ def _uv_tables(H: int, W: int, device) -> Tuple[torch.Tensor, torch.Tensor]:
     return u.to(device), v.to(device)
 
 
+@dataclass
+class _Staged:
+    """A chunk whose frames are on the device, or on their way there on the copy stream."""
+    imgs: torch.Tensor                       # (1, N, 3, H, W) fp32
+    ready: Optional[torch.cuda.Event]        # recorded on the copy stream after the last stage-in kernel; None = usable now
+    paths: List
+    meta: Dict = field(default_factory=dict)
+    keep: tuple = ()                         # host tensors the asynchronous upload still reads
+
+
+@dataclass
+class _InFlight:
+    """A chunk whose kernels and packed D2H are queued; `done` fires when the pinned buffer holds the results."""
+    pinned: Optional[torch.Tensor]
+    layout: List[Tuple[str, torch.dtype, tuple, int, int]]
+    done: torch.cuda.Event
+    timing: Dict[str, torch.cuda.Event]
+    host: Dict                               # values that never left the host (paths, zero descriptors, ...)
+    dense: Optional[Dict[str, torch.Tensor]]  # device tensors of the no-keypoint fallback (copied in finish)
+    meta: Dict
+    t_launch: float = 0.0
+
+
 class OfflineChunkCreator:
-    """Create per-chunk pi3 results (with MoGe scaling and keypoints) and save them to disk."""
+    """Per-chunk pi3 results (metric-scaled by MoGe, sampled at grid keypoints) written as chunk files."""
 
     def __init__(self, config: OfflineCreatorConfig, model: Optional[Pi3Engine] = None, moge_model=None):
         self.config = config
-        os.makedirs(self.config.output_dir, exist_ok=True)
-        self.chunks_dir = os.path.join(self.config.output_dir, "chunks")
+        self.chunks_dir = os.path.join(config.output_dir, "chunks")
         os.makedirs(self.chunks_dir, exist_ok=True)
-        from .dist import ensure_process_group, local_device_index
+        from .dist import ensure_process_group, resolve_device
         self.rank, self.world = ensure_process_group()          # (0, 1) unless launched under torch.distributed.run
-        dev = self.config.device if self.config.device != "cuda" else f"cuda:{local_device_index()}"
-        if not str(dev).startswith("cuda"):
+        dev = resolve_device(config.device)
+        if not dev.startswith("cuda"):
             raise RuntimeError("this build runs the hot path on an MI355X only; there is no CPU path (device='cuda')")
         self.device = torch.device(dev)
+        torch.cuda.set_device(self.device)
 
-        # pi3 (offline_chunk_creator.py:65): a local checkpoint directory/file, or "recipe" for synthetic weights
+        # pi3 weights: a local checkpoint directory / file (offline_chunk_creator.py:65) or "recipe" (synthetic)
         if model is not None:
             self.model = model
-        elif self.config.model_path == "recipe":
-            self.model = Pi3Engine(Pi3Config(), str(self.device))
+        elif config.model_path == "recipe":
+            self.model = Pi3Engine(Pi3Config(), dev)
         else:
-            self.model = Pi3Engine.from_pretrained(self.config.model_path, str(self.device))
+            self.model = Pi3Engine.from_pretrained(config.model_path, dev)
 
-        # MoGe (offline_chunk_creator.py:70-79): failure disables metric scaling, it does not abort
+        # MoGe is optional equipment: without it chunks keep pi3's own scale (offline_chunk_creator.py:70-79)
         self.moge_model = moge_model
-        if self.moge_model is None and self.config.do_metric_depth:
-            try:
-                from .moge import MoGeEngine
-                if not self.config.moge_model_path:
-                    raise FileNotFoundError("no local MoGe-2 checkpoint configured (moge_model_path)")
-                self.moge_model = MoGeEngine.from_pretrained(self.config.moge_model_path, str(self.device))
-                print("   MoGe loaded for metric scaling")
-            except Exception as e:  # noqa: BLE001 - same degrade-don't-crash policy as the reference
-                print(f"⚠️  Failed to initialize MoGe: {e}. Continuing without metric depth.")
-                self.moge_model = None
-
+        if self.moge_model is None and config.do_metric_depth:
+            self.moge_model = self._optional("MoGe metric depth", self._load_moge)
         self.keypoint_extractor = None
-        if self.config.keypoint_type and self.config.keypoint_type.lower() != "none":
-            try:
-                self.keypoint_extractor = create_keypoint_extractor(
-                    keypoint_type=self.config.keypoint_type, max_num_keypoints=self.config.max_num_keypoints,
-                    detection_threshold=self.config.keypoint_detection_threshold, device=str(self.device),
-                    seed=self.config.keypoint_seed)
-                print(f"   Keypoint extractor: {self.config.keypoint_type}")
-            except Exception as e:  # noqa: BLE001
-                print(f"⚠️  Failed to initialize keypoint extractor: {e}. Continuing without keypoints.")
-                self.keypoint_extractor = None
+        if config.keypoint_type and config.keypoint_type.lower() != "none":
+            self.keypoint_extractor = self._optional("keypoint extractor", lambda: create_keypoint_extractor(
+                keypoint_type=config.keypoint_type, max_num_keypoints=config.max_num_keypoints,
+                detection_threshold=config.keypoint_detection_threshold, device=dev, seed=config.keypoint_seed))
+            if self.keypoint_extractor is not None:
+                print(f"   Keypoint extractor: {config.keypoint_type}")
+        # frame undistortion (offline_chunk_creator.py:98-112): maps are built and applied on the device
+        self.undistortion_maps = None
+        if config.cam_dist_path:
+            if os.path.exists(config.cam_dist_path):
+                self.undistortion_maps = self._optional(f"undistortion maps ({config.cam_dist_path})",
+                                                        lambda: create_undistortion_maps(config.cam_dist_path, dev))
+            else:
+                print(f"⚠️  calibration file {config.cam_dist_path} does not exist: frames are used as they are")
 
         self.target_size: Optional[Tuple[int, int]] = None
-        # Undistortion maps (optional), offline_chunk_creator.py:98-112: built and applied on the device
-        self.undistortion_maps = None
-        if getattr(self.config, "cam_dist_path", None):
-            try:
-                if os.path.exists(self.config.cam_dist_path):
-                    print(f"🔧 Creating undistortion maps from: {self.config.cam_dist_path}")
-                    self.undistortion_maps = create_undistortion_maps(self.config.cam_dist_path, str(self.device))
-                    if self.undistortion_maps is not None:
-                        print("✅ Undistortion maps ready; images will be undistorted before Pi3 inference")
-                    else:
-                        print("⚠️  Failed to create undistortion maps; proceeding without undistortion")
-                else:
-                    print(f"⚠️  Calibration file not found: {self.config.cam_dist_path}")
-            except Exception as e:  # noqa: BLE001
-                print(f"⚠️  Undistortion map creation failed: {e}")
+        self._copy_stream = torch.cuda.Stream(self.device)
+        self._moge_stream = torch.cuda.Stream(self.device)
+        self._pinned_pool: Dict[int, List[torch.Tensor]] = {}
 
-    # ------------------------------------------------------------------ device steps (same names as the reference)
+    @staticmethod
+    def _optional(what: str, make):
+        """Build an optional component; report and carry on without it when that fails."""
+        try:
+            obj = make()
+            if obj is None:
+                print(f"⚠️  {what}: not available, continuing without it")
+            return obj
+        except Exception as e:  # noqa: BLE001
+            print(f"⚠️  {what}: {e}; continuing without it")
+            return None
+
+    def _load_moge(self):
+        from .moge import MoGeEngine
+        if not self.config.moge_model_path:
+            raise FileNotFoundError("no local MoGe-2 checkpoint configured (moge_model_path)")
+        eng = MoGeEngine.from_pretrained(self.config.moge_model_path, str(self.device))
+        print("   MoGe loaded for metric scaling")
+        return eng
+
+    # ------------------------------------------------------------------ device steps (the reference's method names)
     @staticmethod
     def _compute_masks(pi3_result: Dict[str, torch.Tensor]) -> torch.Tensor:
         """(B, N, H, W) bool — offline_chunk_creator.py:114-119."""
@@ -136,16 +184,20 @@ class OfflineChunkCreator:
         return m.view(B, N, H, W).bool()
 
     @staticmethod
-    def _get_scale_factor_for_pi3(moge_metric_depth: torch.Tensor, pi3_metric_depth: torch.Tensor,
+    def _ratio_median(moge_metric_depth: torch.Tensor, pi3_metric_depth: torch.Tensor,
+                      mask: torch.Tensor) -> torch.Tensor:
+        """Device tensor [median(moge/pi3 over the mask), number of masked pixels]."""
+        assert pi3_metric_depth.stride(-1) in (1, 3)
+        m8 = mask.contiguous().view(torch.uint8) if mask.dtype == torch.bool else mask.contiguous()
+        return ops.masked_ratio_median(moge_metric_depth.contiguous(), pi3_metric_depth, pi3_metric_depth.stride(-1),
+                                       m8, moge_metric_depth.numel())
+
+    @classmethod
+    def _get_scale_factor_for_pi3(cls, moge_metric_depth: torch.Tensor, pi3_metric_depth: torch.Tensor,
                                   mask: torch.Tensor) -> torch.Tensor:
         """0-dim device tensor — offline_chunk_creator.py:121-127.  pi3_metric_depth may be a strided view of
         local_points[..., 2]."""
-        assert pi3_metric_depth.stride(-1) in (1, 3)
-        n = moge_metric_depth.numel()
-        m8 = mask.contiguous().view(torch.uint8) if mask.dtype == torch.bool else mask.contiguous()
-        out = ops.masked_ratio_median(moge_metric_depth.contiguous(), pi3_metric_depth, pi3_metric_depth.stride(-1),
-                                      m8, n)
-        return out[0]
+        return cls._ratio_median(moge_metric_depth, pi3_metric_depth, mask)[0]
 
     @staticmethod
     def _interpolate_world_points_for_keypoints(result_dense: Dict, keypoints: torch.Tensor) -> Dict[str, torch.Tensor]:
@@ -154,6 +206,9 @@ class OfflineChunkCreator:
         masks = result_dense["masks"]
         m8 = masks.contiguous().view(torch.uint8) if masks.dtype == torch.bool else masks.contiguous()
         images = result_dense.get("images")
+        if not keypoints.is_cuda:     # through pinned memory: an asynchronous upload, the host does not wait for the GPU
+            kp_host = keypoints.to(torch.float32).contiguous()
+            keypoints = (kp_host.pin_memory() if torch.cuda.is_available() else kp_host).to(dev, non_blocking=True)
         return ops.gather_keypoints(result_dense["points"].contiguous(), result_dense["local_points"].contiguous(),
                                     result_dense["conf"].contiguous(), m8,
                                     images.contiguous() if images is not None else None,
@@ -170,166 +225,333 @@ class OfflineChunkCreator:
         return dict(intrinsics=r["intrinsics"], focal=r["focal"][None], shift=r["shift"][None], fx=fxy[:, 0][None],
                     fy=fxy[:, 1][None], cx=fxy[:, 2][None], cy=fxy[:, 3][None])
 
-    # ------------------------------------------------------------------ one chunk
-    def _process_single_chunk(self, chunk_images: torch.Tensor, chunk_paths: List[str]) -> Dict:
-        """Run pi3, optional MoGe scaling, intrinsics, keypoints and the gather for one chunk
-        (offline_chunk_creator.py:161-256).  chunk_images: (1, N, 3, H, W) fp32 in [0, 1], CPU or device."""
-        assert chunk_images.ndim == 5, "Expected (B=1, N, C, H, W) tensor for chunk images"
-        num_frames = int(chunk_images.shape[1])
-        t0 = time.time()
-        imgs_dev = chunk_images.to(self.device, non_blocking=True)
-        if self.config.hip_graph and hasattr(self.model, "forward_graphed"):
-            pi3_result = self.model.forward_graphed(imgs_dev)     # static outputs: consumed before the next chunk
-        else:
-            pi3_result = self.model(imgs_dev)
-        torch.cuda.synchronize(self.device)
-        dt_inf = max(1e-6, time.time() - t0)
-        fps = num_frames / dt_inf if num_frames > 0 else 0.0
-        print(f"   ⏱️ Inference: {dt_inf:.3f}s for {num_frames} frames  ->  {fps:.2f} FPS")
-        _metrics = {"infer_s": float(dt_inf), "num_frames": int(num_frames), "fps": float(fps)}
+    # ------------------------------------------------------------------ stage-in
+    def _stage_in(self, frames, paths: List, meta: Optional[Dict] = None, kind: str = "float") -> _Staged:
+        """Queue the upload (and the device resize / undistortion when frames are decoded uint8) on the copy stream.
+        kind: 'float' (1,N,3,H,W) fp32 in [0,1], CPU or device; 'u8' (N,H0,W0,3) uint8 -> device resize to
+        target_size; 'u8_undist' -> remap through the undistortion maps."""
+        meta = dict(meta or {})
+        if frames.is_cuda and kind == "float":
+            return _Staged(frames.to(self.device, torch.float32), None, paths, meta)
+        cur = torch.cuda.current_stream(self.device)
+        with torch.cuda.stream(self._copy_stream):
+            t_in = torch.cuda.Event(enable_timing=True)
+            t_in.record(self._copy_stream)
+            dev_in = frames.to(self.device, non_blocking=True)
+            if kind == "u8":
+                imgs = ingest_frames_device(dev_in, self.target_size)[None]
+            elif kind == "u8_undist":
+                imgs = self.undistortion_maps.undistort_frames_device(dev_in, self.target_size)[None]
+            else:
+                imgs = dev_in.to(torch.float32)
+            ready = torch.cuda.Event(enable_timing=True)
+            ready.record(self._copy_stream)
+            meta["_stage_in"] = (t_in, ready)
+        for t in (dev_in, imgs):
+            t.record_stream(cur)          # allocated on the copy stream, consumed on the compute stream
+            t.record_stream(self._moge_stream)
+        return _Staged(imgs, ready, paths, meta, keep=(frames,))
 
-        masks = self._compute_masks(pi3_result)[0]
+    # ------------------------------------------------------------------ launch
+    def _pinned(self, nbytes: int) -> torch.Tensor:
+        pool = self._pinned_pool.setdefault(nbytes, [])
+        return pool.pop() if pool else torch.empty(nbytes, dtype=torch.uint8, pin_memory=True)
 
+    def _launch(self, st: _Staged, chunk_images_for_kp: Optional[torch.Tensor] = None) -> _InFlight:
+        """Queue every kernel of one chunk plus the packed D2H; returns without waiting for the GPU."""
+        cfg, dev = self.config, self.device
+        trace = [] if os.environ.get("PI3_TRACE") else None
+
+        def mark(tag):
+            if trace is not None:
+                trace.append((tag, time.perf_counter()))
+        mark("begin")
+        cur = torch.cuda.current_stream(dev)
+        if st.ready is not None:
+            cur.wait_event(st.ready)
+        imgs = st.imgs
+        assert imgs.ndim == 5, "Expected (B=1, N, C, H, W) tensor for chunk images"
+        N = int(imgs.shape[1])
+        ev = {k: torch.cuda.Event(enable_timing=True) for k in ("f0", "f1", "post")}
+
+        # MoGe needs only the first frame: it runs beside the pi3 forward instead of after it (400 small
+        # single-image kernels that would otherwise run on an idle GPU)
+        moge_depth = None
         if self.moge_model is not None:
-            infer = (self.moge_model.infer_graphed if self.config.hip_graph and hasattr(self.moge_model, "infer_graphed")
-                     else self.moge_model.infer)
-            moge_depth = infer(imgs_dev[0, 0])["depth"]
-            pi3_depth = pi3_result["local_points"][0, 0][..., 2]
-            scale = self._get_scale_factor_for_pi3(moge_depth, pi3_depth, masks[0])
-            ops.apply_scale(scale.reshape(1), pi3_result["local_points"], pi3_result["points"],
-                            pi3_result["camera_poses"])
+            if st.ready is not None:
+                self._moge_stream.wait_event(st.ready)
+            else:
+                self._moge_stream.wait_stream(cur)
+            with torch.cuda.stream(self._moge_stream):
+                infer = (self.moge_model.infer_graphed if cfg.hip_graph and hasattr(self.moge_model, "infer_graphed")
+                         else self.moge_model.infer)
+                moge_depth = infer(imgs[0, 0])["depth"]
+            moge_depth.record_stream(cur)
+        mark("moge queued")
 
-        camera_params = None
-        if self.config.estimate_camera_params:
+        ev["f0"].record(cur)
+        if cfg.hip_graph and hasattr(self.model, "forward_graphed"):
+            pi3 = self.model.forward_graphed(imgs)     # static outputs: packed below, before the next replay
+        else:
+            pi3 = self.model(imgs)
+        ev["f1"].record(cur)
+        mark("forward queued")
+
+        masks = self._compute_masks(pi3)[0]
+        out: Dict[str, torch.Tensor] = {}
+        if moge_depth is not None:
+            cur.wait_stream(self._moge_stream)
+            med = self._ratio_median(moge_depth, pi3["local_points"][0, 0][..., 2], masks[0])
+            ops.apply_scale(med[:1], pi3["local_points"], pi3["points"], pi3["camera_poses"])
+            out["_scale"] = med                         # [median, masked pixel count]: checked on the host
+        if cfg.estimate_camera_params:
             try:
-                camera_params = self._estimate_camera_parameters(pi3_result)
+                for k, v in self._estimate_camera_parameters(pi3).items():
+                    out["cam." + k] = v
             except Exception as e:  # noqa: BLE001
                 print(f"⚠️  Camera parameter estimation failed: {e}")
-                camera_params = None
+        out["camera_poses"] = pi3["camera_poses"][0]
+        mark("scale+intrinsics queued")
 
-        result: Dict = {"camera_poses": pi3_result["camera_poses"][0].cpu(), "image_paths": chunk_paths,
-                        "_metrics": _metrics}
-        if camera_params is not None:
-            result["camera_params"] = {k: v.cpu() for k, v in camera_params.items()}
+        host: Dict = {}
+        dense = None
+        if self.keypoint_extractor is not None:
+            try:
+                kp = self.keypoint_extractor.extract(chunk_images_for_kp if chunk_images_for_kp is not None else imgs)
+                g = self._interpolate_world_points_for_keypoints(
+                    dict(points=pi3["points"][0], local_points=pi3["local_points"][0], conf=pi3["conf"][0],
+                         masks=masks, images=imgs[0]), kp["keypoints"])
+                for k in ("points", "local_points", "conf", "keypoints", "colors"):
+                    out[k] = g[k]
+                out["masks"] = g["masks"].view(torch.uint8)
+                host["descriptors"] = kp["descriptors"].to(torch.float16)
+                host["scores"] = kp["scores"].to(torch.float16)
+            except Exception as e:  # noqa: BLE001
+                print(f"⚠️  Keypoint extraction failed: {e}")
+                for k in ("points", "local_points", "conf", "keypoints", "colors", "masks"):
+                    out.pop(k, None)
+                host = {}
+        if "points" not in out:   # no keypoints: the dense maps are the result (offline_chunk_creator.py:204-209)
+            dense = dict(points=pi3["points"][0], local_points=pi3["local_points"][0], conf=pi3["conf"][0], masks=masks)
+            if cfg.hip_graph:     # static graph outputs: the next replay would overwrite them before finish() reads
+                dense = {k: v.clone() for k, v in dense.items()}
+        ev["post"].record(cur)
+        mark("keypoints+gather queued")
+
+        # one packed D2H: every small result tensor, 16-byte aligned, through one pinned buffer
+        layout, parts, off = [], [], 0
+        for k, t in out.items():
+            b = t.contiguous().view(torch.uint8).reshape(-1)
+            pad = (-b.numel()) % 16
+            layout.append((k, t.dtype, tuple(t.shape), off, b.numel()))
+            parts.append(b)
+            if pad:
+                parts.append(torch.zeros(pad, dtype=torch.uint8, device=dev))
+            off += b.numel() + pad
+        pinned = self._pinned(off)
+        pinned.copy_(torch.cat(parts), non_blocking=True)
+        done = torch.cuda.Event()
+        done.record(cur)
+        mark("pack queued")
+        if trace is not None:
+            print("   [trace] launch: " + ", ".join(f"{b[0]} +{(b[1] - a[1]) * 1e3:.1f} ms" for a, b in zip(trace, trace[1:])))
+        return _InFlight(pinned, layout, done, ev, host, dense, dict(st.meta, paths=st.paths, num_frames=N),
+                         t_launch=time.time())
+
+    # ------------------------------------------------------------------ finish
+    def _finish(self, fl: _InFlight) -> Dict:
+        """Wait for one chunk's results and build its chunk-file dictionary (host tensors)."""
+        fl.done.synchronize()
+        got: Dict[str, torch.Tensor] = {}
+        for k, dt, shape, off, nbytes in fl.layout:
+            got[k] = fl.pinned[off:off + nbytes].clone().view(dt).reshape(shape)
+        self._pinned_pool.setdefault(fl.pinned.numel(), []).append(fl.pinned)
+        N = fl.meta["num_frames"]
+        infer_s = max(1e-6, fl.timing["f0"].elapsed_time(fl.timing["f1"]) / 1e3)
+        post_s = fl.timing["f1"].elapsed_time(fl.timing["post"]) / 1e3
+        fps = N / infer_s if N > 0 else 0.0
+        print(f"   ⏱️ Inference: {infer_s:.3f}s for {N} frames  ->  {fps:.2f} FPS")
+        metrics = {"infer_s": float(infer_s), "num_frames": int(N), "fps": float(fps), "post_s": float(post_s)}
+        if "_stage_in" in fl.meta:     # H2D + device resize / undistortion on the copy stream
+            a, b = fl.meta.pop("_stage_in")
+            metrics["stage_in_s"] = a.elapsed_time(b) / 1e3
+        if "_scale" in got:
+            med, cnt = float(got["_scale"][0]), int(got["_scale"][1])
+            ok = cnt > 0 and med > 0.0 and med != float("inf") and med == med
+            metrics["metric_scale"] = med if ok else None
+            if not ok:   # the reference would raise on an empty mask (torch.median of nothing); say so, keep pi3's scale
+                print(f"⚠️  metric scale not applied: median {med} over {cnt} masked pixels of frame 0")
+        result: Dict = {"camera_poses": got["camera_poses"], "image_paths": fl.meta["paths"], "_metrics": metrics}
+        cam = {k[4:]: v for k, v in got.items() if k.startswith("cam.")}
+        if cam:
+            result["camera_params"] = cam
         if self.target_size is not None:
             result["original_width"] = self.target_size[1]
             result["original_height"] = self.target_size[0]
-
-        done = False
-        if self.keypoint_extractor is not None:
-            try:
-                kp_res = self.keypoint_extractor.extract(chunk_images)
-                dense = dict(points=pi3_result["points"][0], local_points=pi3_result["local_points"][0],
-                             conf=pi3_result["conf"][0], masks=masks, images=imgs_dev[0])
-                interp = self._interpolate_world_points_for_keypoints(dense, kp_res["keypoints"])
-                result["points"] = interp["points"].cpu()
-                result["local_points"] = interp["local_points"].cpu()
-                result["conf"] = interp["conf"].cpu()
-                result["masks"] = interp["masks"].cpu()
-                result["keypoints"] = interp["keypoints"].cpu()
-                result["descriptors"] = kp_res["descriptors"].to(torch.float16)
-                result["scores"] = kp_res["scores"].to(torch.float16)
-                result["colors"] = interp["colors"].cpu()
-                done = True
-            except Exception as e:  # noqa: BLE001
-                print(f"⚠️  Keypoint extraction failed: {e}")
-        if not done:  # dense maps are stored instead (offline_chunk_creator.py:204-209)
-            result["points"] = pi3_result["points"][0].cpu()
-            result["local_points"] = pi3_result["local_points"][0].cpu()
-            result["conf"] = pi3_result["conf"][0].cpu()
-            result["masks"] = masks.cpu()
-        if "camera_params" in result and result["camera_params"] is not None:
-            result["intrinsics"] = result["camera_params"].get("intrinsics", None)
+        if fl.dense is None:
+            for k in ("points", "local_points", "conf", "keypoints", "colors"):
+                result[k] = got[k]
+            result["masks"] = got["masks"].bool()
+            result["descriptors"] = fl.host["descriptors"]
+            result["scores"] = fl.host["scores"]
+        else:
+            for k, v in fl.dense.items():
+                result[k] = v.cpu()
+        if cam:
+            result["intrinsics"] = cam.get("intrinsics")
         return result
 
-    # ------------------------------------------------------------------ whole sequence
+    # ------------------------------------------------------------------ one chunk, start to end (reference surface)
+    def _process_single_chunk(self, chunk_images: torch.Tensor, chunk_paths: List[str]) -> Dict:
+        """pi3, optional MoGe scaling, intrinsics, keypoints and the gather for one chunk
+        (offline_chunk_creator.py:161-256).  chunk_images: (1, N, 3, H, W) fp32 in [0, 1], CPU or device."""
+        assert chunk_images.ndim == 5, "Expected (B=1, N, C, H, W) tensor for chunk images"
+        return self._finish(self._launch(self._stage_in(chunk_images, chunk_paths), chunk_images))
+
+    # ------------------------------------------------------------------ a stream of chunks, stages overlapped
+    def process_chunks(self, items: Iterable[Dict]) -> Iterator[Tuple[Dict, Dict]]:
+        """items: dicts with 'frames' (+ 'kind', see _stage_in), 'paths' and free-form 'meta'.  Yields (meta, result) in
+        order.  With overlap_stages the upload of chunk k+1 and the host work of chunk k-1 hide behind the kernels of
+        chunk k; results are identical either way."""
+        it = iter(items)
+
+        def stage_next() -> Optional[_Staged]:
+            item = next(it, None)
+            if item is None:
+                return None
+            meta = dict(item.get("meta") or {})
+            if self.keypoint_extractor is not None and hasattr(self.keypoint_extractor, "reseed") \
+                    and "chunk_index" in meta:
+                meta["_reseed"] = meta["chunk_index"]
+            return self._stage_in(item["frames"], item["paths"], meta, item.get("kind", "float"))
+
+        overlap = self.config.overlap_stages
+        host = self.host_seconds = {"wait_for_frames": 0.0, "launch": 0.0, "finish": 0.0}
+
+        def clocked(key, fn, *a):
+            t0 = time.perf_counter()
+            r = fn(*a)
+            host[key] += time.perf_counter() - t0
+            return r
+
+        staged = clocked("wait_for_frames", stage_next)
+        prev: Optional[_InFlight] = None
+        while staged is not None:
+            if "_reseed" in staged.meta:      # the random grid subset of chunk c must not depend on the sharding
+                self.keypoint_extractor.reseed(staged.meta.pop("_reseed"))
+            fl = clocked("launch", self._launch, staged)
+            staged = clocked("wait_for_frames", stage_next)   # its upload runs on the copy stream beside the kernels above
+            if not overlap:
+                yield fl.meta, clocked("finish", self._finish, fl)
+                continue
+            if prev is not None:
+                yield prev.meta, clocked("finish", self._finish, prev)
+            prev = fl
+        if prev is not None:
+            yield prev.meta, clocked("finish", self._finish, prev)
+
     def process_and_save(self, image_paths: List[str]) -> List[str]:
-        """offline_chunk_creator.py:258-371."""
+        """offline_chunk_creator.py:258-371: cut the sequence into chunks, run them, write chunk files + manifest +
+        metadata.  Chunk c is created by rank c % world under torch.distributed.run."""
         if not image_paths:
             raise ValueError("image_paths is empty")
+        cfg = self.config
         self.target_size = calculate_target_size(image_paths[0], pixel_limit=255000 // 2)
         print(f"Target size: {self.target_size}")
         undist = self.undistortion_maps
-        dataset = ChunkImageDataset(image_paths, self.config.chunk_length, self.config.overlap, self.target_size,
-                                    decode_only=self.config.device_resize or undist is not None)
-        nw = self.config.num_loader_workers
-        # chunk-parallel over the GPUs of the node (SURVEY.md §8e): chunk c is created by rank c % world; chunks do not
-        # depend on each other (each takes its metric scale from its own first frame)
-        my_chunks = list(range(self.rank, len(dataset), self.world))
-        shard = dataset if self.world == 1 else torch.utils.data.Subset(dataset, my_chunks)
-        loader = DataLoader(shard, batch_size=1, shuffle=False, num_workers=nw, pin_memory=self.config.pin_memory,
-                            persistent_workers=nw > 0 and len(my_chunks) > 0, prefetch_factor=1 if nw > 0 else None)
-        saved_files: List[str] = []
+        u8 = cfg.device_resize or undist is not None
+        dataset = ChunkImageDataset(image_paths, cfg.chunk_length, cfg.overlap, self.target_size, decode_only=u8)
+        mine = list(range(self.rank, len(dataset), self.world))
+        nw = cfg.num_loader_workers
+        if nw > 0:    # decode threads in this process, two chunks ahead, into pinned staging buffers
+            loader = ThreadedChunkLoader(dataset, mine, threads=max(nw, 4), depth=2, pin=cfg.pin_memory)
+        else:         # in-line loading (tests, tiny runs)
+            shard = dataset if self.world == 1 else torch.utils.data.Subset(dataset, mine)
+            loader = DataLoader(shard, batch_size=1, shuffle=False, num_workers=0, pin_memory=cfg.pin_memory)
+        print(f"🔄 Processing {len(mine)} of {len(dataset)} chunks (rank {self.rank}/{self.world})...")
+
+        t_first = [None]
+
+        def items():
+            for local_idx, batch in enumerate(loader):
+                if t_first[0] is None:
+                    t_first[0] = time.time()      # loader workers are up and the first chunk is decoded
+                c = mine[local_idx]
+                meta = {"chunk_index": c, "start_idx": int(batch["start_idx"].item()),
+                        "end_idx": int(batch["end_idx"].item())}
+                print(f"📦 Chunk {c + 1}/{len(dataset)}: frames {meta['start_idx'] + 1}-{meta['end_idx']}")
+                if u8:
+                    yield {"frames": batch["chunk_u8"][0], "kind": "u8_undist" if undist is not None else "u8",
+                           "paths": batch["chunk_paths"][0], "meta": meta}
+                else:
+                    yield {"frames": batch["chunk"], "kind": "float", "paths": batch["chunk_paths"][0], "meta": meta}
+
+        saved: List[str] = []
         manifest: List[Dict] = []
-        print(f"🔄 Processing {len(my_chunks)} of {len(dataset)} chunks (rank {self.rank}/{self.world})...")
-        infer_times, infer_frames, per_chunk_fps = [], [], []
-        for local_idx, batch in enumerate(loader):
-            chunk_idx = my_chunks[local_idx]
-            if self.keypoint_extractor is not None and hasattr(self.keypoint_extractor, "reseed"):
-                self.keypoint_extractor.reseed(chunk_idx)     # the random grid subset does not depend on the sharding
-            start_idx = int(batch["start_idx"].item())
-            end_idx = int(batch["end_idx"].item())
-            if undist is not None:     # remap + ToTensor on the GPU (datasets/image_datasets.py:192-199)
-                frames = batch["chunk_u8"][0].to(self.device, non_blocking=True)
-                chunk_images = undist.undistort_frames_device(frames, self.target_size)[None]
-            elif self.config.device_resize:
-                frames = batch["chunk_u8"][0].to(self.device, non_blocking=True)
-                chunk_images = ingest_frames_device(frames, self.target_size)[None]
-            else:
-                chunk_images = batch["chunk"]
-            chunk_paths = batch["chunk_paths"][0]
-            print(f"📦 Chunk {chunk_idx + 1}/{len(dataset)}: frames {start_idx + 1}-{end_idx}")
-            chunk_result = self._process_single_chunk(chunk_images, chunk_paths)
-            m = chunk_result.get("_metrics", {})
-            if m:
-                infer_times.append(float(m.get("infer_s", 0.0)))
-                infer_frames.append(int(m.get("num_frames", 0)))
-                per_chunk_fps.append(float(m.get("fps", 0.0)))
-            out_name = f"chunk_{chunk_idx:06d}.pt"
-            out_path = os.path.join(self.chunks_dir, out_name)
-            chunk_result["chunk_index"] = chunk_idx
-            chunk_result["start_idx"] = start_idx
-            chunk_result["end_idx"] = end_idx
+        stats: List[Tuple[float, int, float]] = []
+        writer = ThreadPoolExecutor(max_workers=1, thread_name_prefix="chunk-writer")
+        pending = []
+
+        def write(result: Dict, path: str) -> Optional[str]:
             try:
-                torch.save(chunk_result, out_path)
-                saved_files.append(out_path)
-                manifest.append({"chunk_index": chunk_idx, "file": out_name, "start_idx": start_idx,
-                                 "end_idx": end_idx, "num_frames": len(chunk_paths),
-                                 "image_paths": chunk_paths})
-                print(f"   💾 Saved: {out_path}")
+                torch.save(result, path)
+                return None
             except Exception as e:  # noqa: BLE001
-                print(f"❌ Failed to save chunk {chunk_idx}: {e}")
-        try:
-            total_time, total_frames = sum(infer_times), sum(infer_frames)
-            overall = (total_frames / total_time) if total_time > 0 else 0.0
-            steady = sorted(f for f, n in zip(per_chunk_fps, infer_frames) if n == self.config.chunk_length)
-            print(f"\n⏱️ Overall inference: {total_frames} frames in {total_time:.3f}s  ->  {overall:.2f} FPS (weighted)")
-            if steady:
-                print(f"   Steady-state FPS (full {self.config.chunk_length}-frame chunks, median): "
-                      f"{steady[len(steady) // 2]:.2f} FPS")
-        except Exception:  # noqa: BLE001
-            pass
+                return str(e)
+
+        t_all = time.time()
+        for meta, result in self.process_chunks(items()):
+            m = result["_metrics"]
+            stats.append((m["infer_s"], m["num_frames"], m["fps"]))
+            name = f"chunk_{meta['chunk_index']:06d}.pt"
+            result.update(chunk_index=meta["chunk_index"], start_idx=meta["start_idx"], end_idx=meta["end_idx"])
+            entry = {"chunk_index": meta["chunk_index"], "file": name, "start_idx": meta["start_idx"],
+                     "end_idx": meta["end_idx"], "num_frames": len(meta["paths"]), "image_paths": meta["paths"]}
+            pending.append((writer.submit(write, result, os.path.join(self.chunks_dir, name)), entry))
+        for fut, entry in pending:
+            err = fut.result()
+            path = os.path.join(self.chunks_dir, entry["file"])
+            if err is None:
+                saved.append(path)
+                manifest.append(entry)
+                print(f"   💾 Saved: {path}")
+            else:
+                print(f"❌ Failed to save chunk {entry['chunk_index']}: {err}")
+        writer.shutdown()
+        wall = max(1e-6, time.time() - t_all)
+
+        total_t, total_n = sum(s[0] for s in stats), sum(s[1] for s in stats)
+        if total_t > 0:
+            print(f"\n⏱️ Overall inference: {total_n} frames in {total_t:.3f}s  ->  {total_n / total_t:.2f} FPS (weighted); "
+                  f"end to end incl. loader and writer: {total_n / wall:.2f} FPS")
+            full = sorted(s[2] for s in stats if s[1] == cfg.chunk_length)
+            if full:
+                print(f"   Steady-state FPS (full {cfg.chunk_length}-frame chunks, median): {full[len(full) // 2]:.2f} FPS")
+        hs = getattr(self, "host_seconds", {})
+        print("   host time: " + ", ".join(f"{k} {v:.2f} s" for k, v in hs.items()) + f" of {wall:.2f} s wall")
+        self.last_run = {"frames": total_n, "wall_s": wall, "infer_s": total_t, "host_seconds": dict(hs),
+                         "wall_after_first_chunk_decoded_s": max(1e-6, time.time() - (t_first[0] or t_all))}
+
         if self.world > 1:   # rank 0 writes the manifest of all ranks' chunks
             from .dist import gather_objects
             parts = gather_objects(manifest)
             if self.rank != 0:
                 torch.distributed.barrier()
-                print(f"✅ Completed. Saved {len(saved_files)} chunks to {self.chunks_dir}")
-                return saved_files
-            manifest = sorted((m for part in parts for m in part), key=lambda m: m["chunk_index"])
-        try:
-            with open(os.path.join(self.config.output_dir, "chunks_manifest.json"), "w") as f:
-                json.dump(manifest, f, indent=2)
-        except Exception as e:  # noqa: BLE001
-            print(f"⚠️  Failed to write manifest: {e}")
-        try:
-            metadata = {"chunk_length": int(self.config.chunk_length), "overlap": int(self.config.overlap),
-                        "target_size": list(self.target_size) if self.target_size is not None else None}
-            with open(os.path.join(self.config.output_dir, "chunk_metadata.json"), "w") as f:
-                json.dump(metadata, f, indent=2)
-        except Exception as e:  # noqa: BLE001
-            print(f"⚠️  Failed to write chunk metadata: {e}")
+                print(f"✅ Completed. Saved {len(saved)} chunks to {self.chunks_dir}")
+                return saved
+            manifest = sorted((e for part in parts for e in part), key=lambda e: e["chunk_index"])
+        self._write_json("chunks_manifest.json", manifest)
+        self._write_json("chunk_metadata.json", {
+            "chunk_length": int(cfg.chunk_length), "overlap": int(cfg.overlap),
+            "target_size": list(self.target_size) if self.target_size is not None else None})
         if self.world > 1:
             torch.distributed.barrier()     # metadata is on disk before any rank starts stage 2
-        print(f"✅ Completed. Saved {len(saved_files)} chunks to {self.chunks_dir}")
-        return saved_files
+        print(f"✅ Completed. Saved {len(saved)} chunks to {self.chunks_dir}")
+        return saved
+
+    def _write_json(self, name: str, obj) -> None:
+        try:
+            with open(os.path.join(self.config.output_dir, name), "w") as f:
+                json.dump(obj, f, indent=2)
+        except Exception as e:  # noqa: BLE001
+            print(f"⚠️  Failed to write {name}: {e}")

@@ -220,3 +220,42 @@ def _prefix_cpu(T: torch.Tensor) -> torch.Tensor:
     for i in range(1, T.shape[0]):
         out.append(out[-1] @ T[i].reshape(4, 4))
     return torch.stack([o.reshape(16) for o in out])
+
+
+class WaveAligner:
+    """Progressive alignment of chunk-parallel ranks, one wave (= `world` consecutive chunks) at a time; shared by the
+    offline reconstructor and the online pipeline.  Every rank calls step() once per wave with its own chunk of the
+    wave (or None past the end of the sequence) and gets back the global transforms of ALL chunks of the wave."""
+
+    def __init__(self, rank: int, world: int, overlap: int, chunk_length: Optional[int], device, solve=None,
+                 compose=None):
+        self.rank, self.world, self.overlap, self.chunk_length = rank, world, overlap, chunk_length
+        self.on_gpu = dist.get_backend() == "nccl"
+        self.comm_dev = device if self.on_gpu else "cpu"
+        if solve is None:
+            from . import ops
+            solve = default_solver(overlap, device, chunk_length)
+            compose = lambda T: ops.sim3_compose_prefix(T.to(device))   # noqa: E731
+        self.solve, self.compose = solve, compose
+        self.G_last = torch.eye(4, dtype=torch.float64)
+        self.prev_tail: Optional[Dict] = None
+
+    def step(self, chunk: Optional[Dict], w0: int, n_chunks: int) -> Tuple[List[torch.Tensor], List[bool]]:
+        """chunk: this rank's chunk dict (chunk index w0 + rank) or None.  Collectives: sizes (2 ints per rank), boundary
+        blocks (~50 KB per rank), [accepted, T] records (136 B per rank)."""
+        sz = torch.tensor([int(chunk["keypoints"].shape[1]), int(chunk["points"].shape[0])] if chunk is not None
+                          else [0, 0], device=self.comm_dev)
+        szs = [torch.zeros_like(sz) for _ in range(self.world)]
+        dist.all_gather(szs, sz)
+        szs = [t.tolist() for t in szs]
+        K = max(k for k, _ in szs)
+        if chunk is not None:
+            local = pack_boundary(chunk, self.overlap, K, device=self.comm_dev)
+        else:   # ragged last wave: an empty block (n_frames = 0)
+            local = torch.zeros(boundary_numel(self.overlap, K), device=self.comm_dev)
+        blocks = [unpack_boundary(b, self.overlap, K, n_frames=szs[r][1])
+                  for r, b in enumerate(allgather_boundaries(local, self.comm_dev))]
+        Gs, oks = align_wave(self.rank, self.world, w0, n_chunks, blocks, self.prev_tail, self.G_last, self.solve,
+                             self.comm_dev, self.compose)
+        self.G_last, self.prev_tail = Gs[-1], blocks[len(Gs) - 1]
+        return Gs, oks

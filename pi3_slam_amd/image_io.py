@@ -111,6 +111,105 @@ def decode_frames_u8(paths: List[str], pin: bool = True) -> torch.Tensor:
     return out.pin_memory() if (pin and torch.cuda.is_available()) else out
 
 
+class ThreadedChunkLoader:
+    """In-process replacement for the reference's DataLoader workers (slam/offline_chunk_creator.py:279-287): a producer
+    thread walks the chunks, a thread pool decodes (and, for the host-resize path, resizes) the frames of a chunk in
+    parallel - PIL's decoder and resampler release the GIL - straight into a pinned staging buffer, `depth` chunks
+    ahead.  Why not worker processes: forking a process that holds a GPU context costs the device ~2 s of evicted
+    queues at start-up on this stack, every batch crosses a shared-memory pickle and a second copy into pinned memory,
+    and a chunk (100 frames) is ONE dataset item, so a worker decodes its frames one after the other.
+    Yields the same dictionaries as DataLoader(batch_size=1) over ChunkImageDataset: 'chunk_u8' (1,N,H0,W0,3) uint8 or
+    'chunk' (1,N,3,H,W) fp32, 'start_idx' / 'end_idx' (1,1) int64, 'chunk_paths' [[[p0],[p1],...]] (the nesting the
+    reference's collate + pin pass produces on a GPU box)."""
+
+    def __init__(self, dataset: "ChunkImageDataset", indices: List[int], threads: int = 8, depth: int = 2,
+                 pin: bool = True):
+        self.ds, self.indices, self.threads, self.depth = dataset, list(indices), max(1, threads), max(1, depth)
+        self.pin = pin and torch.cuda.is_available()
+
+    def __len__(self):
+        return len(self.indices)
+
+    def __iter__(self):
+        import queue
+        import threading
+        from concurrent.futures import ThreadPoolExecutor
+        from PIL import Image
+        ds = self.ds
+        q: "queue.Queue" = queue.Queue(maxsize=self.depth)
+        stop = threading.Event()
+        buffers: dict = {}            # (shape, dtype) -> free pinned staging tensors (returned when the consumer moves on)
+        lock = threading.Lock()
+
+        def staging(shape, dtype):
+            with lock:
+                free = buffers.setdefault((tuple(shape), dtype), [])
+                if free:
+                    return free.pop()
+            t = torch.empty(shape, dtype=dtype)
+            return t.pin_memory() if self.pin else t
+
+        def decode_one(dst, j, path):
+            if not os.path.exists(path):
+                raise ValueError(f"Image file not found: {path}")
+            img = Image.open(path).convert("RGB")
+            if ds.decode_only:
+                a = np.array(img, dtype=np.uint8)
+                if tuple(a.shape) != tuple(dst.shape[1:]):
+                    raise ValueError("frames of one chunk must share a size for the batched device resize")
+                dst[j].copy_(torch.from_numpy(a))
+            else:
+                a = np.array(img.resize((ds.target_size[1], ds.target_size[0]), Image.BILINEAR), dtype=np.uint8)
+                dst[j].copy_(torch.from_numpy(a).permute(2, 0, 1).to(torch.float32).div(255.0))
+
+        def produce():
+            try:
+                with ThreadPoolExecutor(self.threads, thread_name_prefix="frame-decode") as pool:
+                    for idx in self.indices:
+                        if stop.is_set():
+                            return
+                        s, e = ds.chunk_indices[idx]
+                        paths = ds.image_paths[s:e]
+                        if ds.decode_only:
+                            w0, h0 = Image.open(paths[0]).size
+                            buf = staging((e - s, h0, w0, 3), torch.uint8)
+                        else:
+                            buf = staging((e - s, 3, ds.target_size[0], ds.target_size[1]), torch.float32)
+                        list(pool.map(lambda jp: decode_one(buf, jp[0], jp[1]), enumerate(paths)))
+                        item = {"chunk_u8" if ds.decode_only else "chunk": buf[None],
+                                "start_idx": torch.tensor([[s]]), "end_idx": torch.tensor([[e]]),
+                                "chunk_paths": [[[p] for p in paths]], "_staging": buf}
+                        while not stop.is_set():
+                            try:
+                                q.put(item, timeout=0.1)
+                                break
+                            except queue.Full:
+                                continue
+                q.put(None)
+            except BaseException as exc:  # noqa: BLE001 - delivered to the consumer
+                q.put(exc)
+
+        th = threading.Thread(target=produce, name="chunk-loader", daemon=True)
+        th.start()
+        held = []                      # staging buffers the consumer may still be uploading from
+        try:
+            while True:
+                item = q.get()
+                if item is None:
+                    return
+                if isinstance(item, BaseException):
+                    raise item
+                buf = item.pop("_staging")
+                held.append(buf)
+                if len(held) > self.depth + 2:     # two chunks further on, the upload of this one has long finished
+                    old = held.pop(0)
+                    with lock:
+                        buffers.setdefault((tuple(old.shape), old.dtype), []).append(old)
+                yield item
+        finally:
+            stop.set()
+
+
 class ChunkImageDataset(Dataset):
     def __init__(self, image_paths: List[str], chunk_length: int, overlap: int, target_size: Tuple[int, int],
                  device: str = "cpu", undistortion_maps=None, decode_only: bool = False):

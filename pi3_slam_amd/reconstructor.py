@@ -155,39 +155,17 @@ class OfflineReconstructor:
         `solve` (tests): replaces the device solver, see dist.default_solver."""
         import torch.distributed as dist
 
-        from . import ops
         from .alignment import transform_chunk
-        from .dist import (align_wave, allgather_boundaries, boundary_numel, default_solver, gather_objects,
-                           pack_boundary, unpack_boundary)
+        from .dist import WaveAligner, gather_objects
         files = self._load_chunks()
         n_chunks = len(files)
-        on_gpu = dist.get_backend() == "nccl"
-        comm_dev = self.device if on_gpu else "cpu"
-        if solve is None:
-            solve = default_solver(self.overlap, self.device, self.chunk_length)
-            compose = lambda T: ops.sim3_compose_prefix(T.to(self.device))   # noqa: E731
-        else:
-            compose = None
+        aligner = WaveAligner(rank, world, self.overlap, self.chunk_length, self.device, solve)
         print(f"🔄 Reconstructing {n_chunks} chunks from {self.chunk_dir} on {world} ranks (rank {rank})")
-        G_last = torch.eye(4, dtype=torch.float64)
-        prev_tail = None
         mine: List[Dict] = []
         for w0 in range(0, n_chunks, world):
             c = w0 + rank
             data = torch.load(files[c], map_location="cpu", weights_only=False) if c < n_chunks else None
-            sz = torch.tensor([int(data["keypoints"].shape[1]), int(data["points"].shape[0])] if data is not None
-                              else [0, 0], device=comm_dev)
-            szs = [torch.zeros_like(sz) for _ in range(world)]
-            dist.all_gather(szs, sz)
-            szs = [t.tolist() for t in szs]
-            K = max(k for k, _ in szs)
-            if data is not None:
-                local = pack_boundary(data, self.overlap, K, device=comm_dev)
-            else:   # ragged last wave: an empty block (n_frames = 0)
-                local = torch.zeros(boundary_numel(self.overlap, K), device=comm_dev)
-            blocks = [unpack_boundary(b, self.overlap, K, n_frames=szs[r][1])
-                      for r, b in enumerate(allgather_boundaries(local, comm_dev))]
-            Gs, oks = align_wave(rank, world, w0, n_chunks, blocks, prev_tail, G_last, solve, comm_dev, compose)
+            Gs, oks = aligner.step(data, w0, n_chunks)
             for r, ok in enumerate(oks):
                 if not ok and rank == 0:
                     print(f"   ❌ Alignment failed for chunk {w0 + r}: it stays in its own frame")
@@ -200,8 +178,6 @@ class OfflineReconstructor:
                     self._save_chunk(data, c)
                 if self.save_observations:
                     self._save_observations(data, c)
-            n_wave = len(Gs)
-            G_last, prev_tail = Gs[-1], blocks[n_wave - 1]
         keep = ("points", "colors", "keypoints", "masks", "camera_poses", "image_paths", "chunk_order", "alignment_ok")
         parts = gather_objects([{k: d[k] for k in keep if k in d} for d in mine])
         if rank == 0:

@@ -119,18 +119,17 @@ def _wave_worker(rank, world, port, n_chunks, cl, ov, K, bad, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    from pi3_slam_amd.dist import align_wave, allgather_boundaries, boundary_numel, pack_boundary, unpack_boundary
+    from pi3_slam_amd.dist import WaveAligner
     chunks, _ = _synthetic_chunks(n_chunks, cl, ov, K, bad)
-    solve = _oracle_solver(ov, cl)
-    G_last, prev_tail, Gall, okall = torch.eye(4, dtype=torch.float64), None, [], []
+    # the product's wave driver (sizes all-gather, boundary all-gather, own solve, 136-byte all-gather, prefix product)
+    # with the CPU oracle standing in for the HIP solver
+    aligner = WaveAligner(rank, world, ov, cl, "cpu", solve=_oracle_solver(ov, cl))
+    Gall, okall = [], []
     for w0 in range(0, n_chunks, world):
         c = w0 + rank
-        local = pack_boundary(chunks[c], ov, K) if c < n_chunks else torch.zeros(boundary_numel(ov, K))
-        blocks = [unpack_boundary(b, ov, K) for b in allgather_boundaries(local, "cpu")]
-        Gs, oks = align_wave(rank, world, w0, n_chunks, blocks, prev_tail, G_last, solve)
+        Gs, oks = aligner.step(chunks[c] if c < n_chunks else None, w0, n_chunks)
         Gall += Gs
         okall += oks
-        G_last, prev_tail = Gs[-1], blocks[len(Gs) - 1]
     dist.barrier()
     q.put((rank, torch.stack(Gall).numpy(), okall))
     dist.destroy_process_group()

@@ -128,7 +128,7 @@ def test_chunk_creator_single_chunk_schema(dev, tmp_path):
     assert set(res["camera_params"]) == {"intrinsics", "focal", "shift", "fx", "fy", "cx", "cy"}
     assert res["camera_params"]["focal"].shape == (1, N)
     assert res["original_width"] == 70 and res["original_height"] == 56
-    assert set(res["_metrics"]) == {"infer_s", "num_frames", "fps"}
+    assert set(res["_metrics"]) >= {"infer_s", "num_frames", "fps"}      # the reference's three + per-stage extras
     assert float(res["descriptors"].abs().sum()) == 0 and float(res["colors"].max()) <= 255
 
 

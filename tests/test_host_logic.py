@@ -183,3 +183,22 @@ def test_cli_parsers_and_image_listing(tmp_path):
     assert [os.path.basename(p) for p in cli.list_images(str(tmp_path / "*.png"))] == ["a.png", "c.png"]
     with pytest.raises(SystemExit):
         cli.main(["create", "--images", str(tmp_path / "nothing_*.png"), "--output", str(tmp_path / "o")])
+
+
+def test_in_order_drain_releases_chunks_in_chunk_order():
+    """Reorder buffer of the chunk-parallel online path (reference: slam/online_reconstructor.py:852-920)."""
+    import random
+    from pi3_slam_amd.online import InOrderDrain
+    rng = random.Random(0)
+    order = list(range(23))
+    rng.shuffle(order)
+    d, got = InOrderDrain(), []
+    for i in order:
+        d.put(i, f"chunk{i}")
+        for idx, item in d.pop_ready():
+            assert item == f"chunk{idx}"
+            got.append(idx)
+        assert got == list(range(len(got)))            # never releases past a hole
+    assert got == list(range(23)) and len(d) == 0 and d.next_index == 23
+    with pytest.raises(ValueError):
+        d.put(3, "again")

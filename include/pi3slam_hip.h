@@ -193,7 +193,8 @@ int pi3_moge_depth(const float* pts, const float* shift, const float* log_scale,
 int pi3_sim3_match_keypoints(const void* kp_ref, const void* kp_qry, int ov, int K, int* idx, void* stream);
 
 /* Near-half filter (:78-86, use_filter != 0) + closed-form Umeyama similarity qry -> ref (:89-105).
- * pts_*: f16 [ov][K][3]; w_*: optional uint8 validity [ov][K]; last_ref_pose: f32 [16] cam->world of the last ref view.
+ * pts_*: [ov][K][3], f16 as chunk files store them, or f32 when bit 1 of use_filter is set (bundle-adjusted chunks);
+ * w_*: optional uint8 validity [ov][K]; last_ref_pose: f32 [16] cam->world of the last ref view.
  * out33 (f64): [0] s, [1..9] R, [10..12] t, [13..28] 4x4, [29] pairs used, [30] common pairs, [31] median, [32] rms. */
 int pi3_sim3_umeyama(const void* pts_ref, const void* pts_qry, const int* idx, const unsigned char* w_ref,
                      const unsigned char* w_qry, int ov, int K, const float* last_ref_pose, int use_filter,
@@ -228,6 +229,33 @@ int pi3_ingest_frames(const unsigned char* src, int N, int H0, int W0, int H1, i
 int pi3_undistort_maps(const double* params, int model, int H, int W, float* map_x, float* map_y, void* stream);
 int pi3_remap_bilinear_u8(const unsigned char* src, int N, int H0, int W0, const float* map_x, const float* map_y,
                           int H, int W, float* dst, void* stream);
+
+/* ---- bundle adjustment of a chunk ---------------------------------------------------------- */
+
+/* Replaces pt.sfm.BundleAdjustReconstruction as the reference configures it (utils/chunk_reconstruction.py:188-209:
+ * 10 iterations, Huber 2.0, DENSE_SCHUR; utils/reconstruction_alignment.py:137-159: 50 iterations, Huber 3.0, with the
+ * orientation / position priors of :110-132).  pytheia / Ceres are not available offline: restated algorithm, parity
+ * unpinned (see csrc/ba.hip).  Dense problem layout: track (s, k), observed by camera t iff valid[s][t][k];
+ * uv [N][N][K][2] f32 pixels (the diagonal t == s = the keypoint itself), uvT / validT = the same with the last two
+ * index axes swapped ([N][K][N]).  points f64 [N*K][3] and poses f64 [N][12] = [R world->camera (9) | centre (3)] are
+ * refined IN PLACE; intr f64 [N][4] = fx, fy, cx, cy (fixed).  prior_flag (or NULL) marks cameras with a pose prior
+ * (prior_R [N][9], prior_C [N][3]); sqrt_info_* = 1 / sqrt(covariance).  summary_dev: 11 doubles (cost, candidate
+ * cost, radius, decrease factor, model decrease, iterations, accepted steps, done, initial cost, cholesky failure,
+ * last step accepted).  N <= 128.  workspace: pi3_ba_workspace_doubles(N, K) doubles. */
+long pi3_ba_workspace_doubles(int N, int K);
+int pi3_bundle_adjust(double* points, double* poses, const double* intr, const float* uv, const unsigned char* valid,
+                      const float* uvT, const unsigned char* validT, int N, int K, double huber_width, int max_iters,
+                      const double* prior_R, const double* prior_C, const unsigned char* prior_flag,
+                      double sqrt_info_rot, double sqrt_info_pos, double* summary_dev, double* workspace,
+                      long workspace_doubles, void* stream);
+
+/* pt.sfm.SetOutlierTracksToUnestimated(tracks, max_reprojection_error_px, min_triangulation_angle_deg)
+ * (utils/chunk_reconstruction.py:218, utils/reconstruction_alignment.py:170): estimated[s*K + k] = 1 iff every
+ * observation of the track is in front of its camera and within max px, and two viewing rays subtend more than the
+ * minimum angle. */
+int pi3_ba_outlier_tracks(const double* points, const double* poses, const double* intr, const float* uv,
+                          const unsigned char* valid, int N, int K, double max_reprojection_px,
+                          double min_triangulation_angle_deg, unsigned char* estimated, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,204 @@
+"""ORACLE — test infrastructure only.  CPU (numpy, float64) restatement of the bundle adjustment the reference runs
+through pytheia / Ceres: per chunk (utils/chunk_reconstruction.py:188-219: 10 iterations, Huber 2.0, DENSE_SCHUR,
+SetOutlierTracksToUnestimated(tracks, 2, 0.25)) and after each alignment with pose priors on the overlap views
+(utils/reconstruction_alignment.py:107-171: orientation prior covariance 2 I, position prior covariance 25 I,
+50 iterations, Huber 3.0, outliers (3, 0.25)).
+
+PARITY UNPINNED: pytheia 0.2.9 (C++ TheiaSfM + Ceres Solver, requirements.txt:10) is not under /root/reference and
+cannot be installed offline, and the reference holds no vectors for this stage.  What is restated is the published
+method those libraries implement:
+  * reprojection residual of a pinhole camera with fixed intrinsics (Theia's default intrinsics_to_optimize = NONE),
+    camera = (world->camera rotation R, centre C), r = (fx x/z + cx - u, fy y/z + cy - v), (x, y, z) = R (X - C);
+  * Huber loss rho(s) = s (s <= a^2), 2 a sqrt(s) - a^2 otherwise, applied per observation as iteratively re-weighted
+    least squares (weight rho'(s));
+  * Levenberg-Marquardt as Ceres' trust-region strategy states it: (J^T W J + diag(J^T W J) / radius) d = -J^T W r with
+    the diagonal clamped to [1e-6, 1e32]; step quality rho = (cost - cost_new) / model_decrease; accepted when
+    rho > 1e-3 with radius /= max(1/3, 1 - (2 rho - 1)^3), otherwise radius /= decrease_factor (2, doubling);
+    function tolerance 1e-6; initial radius 1e4;
+  * the Schur complement on the points (DENSE_SCHUR), which is algebra, not an approximation: this file solves the full
+    normal equations densely, the device eliminates the points first - both must produce the same step.
+`solve_with_scipy` is an independent check of the OPTIMUM (scipy.optimize.least_squares with loss='huber').
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional, Tuple
+
+import numpy as np
+
+
+def huber(s: np.ndarray, a: float) -> Tuple[np.ndarray, np.ndarray]:
+    small = s <= a * a
+    r = np.sqrt(np.where(small, 1.0, s))
+    return np.where(small, s, 2 * a * r - a * a), np.where(small, 1.0, a / r)
+
+
+def skew(p: np.ndarray) -> np.ndarray:
+    z = np.zeros(p.shape[:-1])
+    return np.stack([np.stack([z, -p[..., 2], p[..., 1]], -1), np.stack([p[..., 2], z, -p[..., 0]], -1),
+                     np.stack([-p[..., 1], p[..., 0], z], -1)], -2)
+
+
+def exp_so3(w: np.ndarray) -> np.ndarray:
+    th = np.linalg.norm(w)
+    K = skew(w)
+    if th < 1e-8:
+        a, b = 1.0 - th * th / 6.0, 0.5 - th * th / 24.0
+    else:
+        a, b = np.sin(th) / th, (1 - np.cos(th)) / th ** 2
+    return np.eye(3) + a * K + b * K @ K
+
+
+def log_so3(R: np.ndarray) -> np.ndarray:
+    c = np.clip(0.5 * (np.trace(R) - 1.0), -1.0, 1.0)
+    th = np.arccos(c)
+    v = np.array([R[2, 1] - R[1, 2], R[0, 2] - R[2, 0], R[1, 0] - R[0, 1]])
+    return (0.5 if th < 1e-8 else th / (2 * np.sin(th))) * v
+
+
+def observations(uv: np.ndarray, valid: np.ndarray):
+    """Dense [N][N][K] layout -> lists: track index i = s*K + k, camera t, pixel."""
+    s, t, k = np.nonzero(valid)
+    K = valid.shape[2]
+    return s * K + k, t, uv[s, t, k].astype(np.float64)
+
+
+def residuals(R, C, intr, X, trk, cam, px):
+    """-> r (M,2), Jc (M,2,6), Jp (M,2,3), front (M,) bool."""
+    d = X[trk] - C[cam]
+    p = np.einsum("mij,mj->mi", R[cam], d)
+    front = p[:, 2] > 1e-9
+    z = np.where(front, p[:, 2], 1.0)
+    fx, fy, cx, cy = (intr[cam, i] for i in range(4))
+    r = np.stack([fx * p[:, 0] / z + cx - px[:, 0], fy * p[:, 1] / z + cy - px[:, 1]], -1)
+    Jpi = np.zeros((len(trk), 2, 3))
+    Jpi[:, 0, 0], Jpi[:, 0, 2] = fx / z, -fx * p[:, 0] / z ** 2
+    Jpi[:, 1, 1], Jpi[:, 1, 2] = fy / z, -fy * p[:, 1] / z ** 2
+    Jp = np.einsum("mij,mjk->mik", Jpi, R[cam])
+    Jw = -np.einsum("mij,mjk->mik", Jpi, skew(p))
+    Jc = np.concatenate([Jw, -Jp], axis=2)
+    return r, Jc, Jp, front
+
+
+def prior_terms(R, C, prior):
+    """-> (cost, H_diag (N,6), g (N,6)) of the pose priors (first-order Jacobian sr I / sp I)."""
+    N = len(R)
+    Hd, g, cost = np.zeros((N, 6)), np.zeros((N, 6)), 0.0
+    if prior is None:
+        return cost, Hd, g
+    sr2, sp2 = prior["sqrt_info_rot"] ** 2, prior["sqrt_info_pos"] ** 2
+    for t in np.nonzero(prior["flag"])[0]:
+        w3 = log_so3(R[t] @ prior["R"][t].T)
+        dc = C[t] - prior["C"][t]
+        Hd[t, :3], Hd[t, 3:] = sr2, sp2
+        g[t, :3], g[t, 3:] = sr2 * w3, sp2 * dc
+        cost += 0.5 * sr2 * w3 @ w3 + 0.5 * sp2 * dc @ dc
+    return cost, Hd, g
+
+
+def total_cost(R, C, intr, X, trk, cam, px, a, prior) -> float:
+    r, _, _, front = residuals(R, C, intr, X, trk, cam, px)
+    rho, _ = huber((r ** 2).sum(1), a)
+    return 0.5 * rho[front].sum() + prior_terms(R, C, prior)[0]
+
+
+def bundle_adjust(R, C, intr, X, uv, valid, huber_width: float, max_iters: int, prior: Optional[Dict] = None):
+    """R (N,3,3) world->camera, C (N,3), intr (N,4), X (N*K,3); uv (N,N,K,2), valid (N,N,K).
+    Returns refined (R, C, X) and a summary dict.  prior: {'R','C','flag','sqrt_info_rot','sqrt_info_pos'}."""
+    R, C, X = R.copy(), C.copy(), X.copy()
+    N, P = len(R), len(X)
+    trk, cam, px = observations(uv, valid)
+    cost = total_cost(R, C, intr, X, trk, cam, px, huber_width, prior)
+    summary = {"initial_cost": cost, "iterations": 0, "accepted_steps": 0}
+    radius, decrease = 1e4, 2.0
+    nc = 6 * N
+    for _ in range(max_iters):
+        r, Jc, Jp, front = residuals(R, C, intr, X, trk, cam, px)
+        _, w = huber((r ** 2).sum(1), huber_width)
+        w = w * front
+        H = np.zeros((nc + 3 * P, nc + 3 * P))
+        g = np.zeros(nc + 3 * P)
+        ci = (6 * cam[:, None] + np.arange(6)[None]).astype(int)
+        pi = (nc + 3 * trk[:, None] + np.arange(3)[None]).astype(int)
+        J = np.zeros((len(trk), 2, 9))
+        J[:, :, :6], J[:, :, 6:] = Jc, Jp
+        idx = np.concatenate([ci, pi], 1)
+        blocks = np.einsum("m,mia,mib->mab", w, J, J)
+        np.add.at(H, (idx[:, :, None], idx[:, None, :]), blocks)
+        np.add.at(g, idx, np.einsum("m,mia,mi->ma", w, J, r))
+        _, Hd, gprior = prior_terms(R, C, prior)
+        H[np.arange(nc), np.arange(nc)] += Hd.reshape(-1)
+        g[:nc] += gprior.reshape(-1)
+        D = np.clip(np.diag(H), 1e-6, 1e32) / radius
+        ok = True
+        try:
+            L = np.linalg.cholesky(H + np.diag(D))
+            d = -np.linalg.solve(L.T, np.linalg.solve(L, g))
+        except np.linalg.LinAlgError:
+            ok, d = False, np.zeros_like(g)
+        model = -0.5 * g @ d + 0.5 * d @ (D * d)
+        Rn = np.stack([exp_so3(d[6 * t:6 * t + 3]) @ R[t] for t in range(N)])
+        Cn = C + d[:nc].reshape(N, 6)[:, 3:]
+        Xn = X + d[nc:].reshape(P, 3)
+        cnew = total_cost(Rn, Cn, intr, Xn, trk, cam, px, huber_width, prior)
+        summary["iterations"] += 1
+        rho = (cost - cnew) / model if (ok and model > 0) else -1.0
+        if rho > 1e-3 and np.isfinite(cnew):
+            radius = min(radius / max(1.0 / 3.0, 1.0 - (2 * rho - 1) ** 3), 1e16)
+            decrease = 2.0
+            rel = abs(cost - cnew) / max(cost, 1e-300)
+            R, C, X, cost = Rn, Cn, Xn, cnew
+            summary["accepted_steps"] += 1
+            if rel < 1e-6:
+                break
+        else:
+            radius /= decrease
+            decrease *= 2.0
+            if radius < 1e-32:
+                break
+    summary["final_cost"] = cost
+    summary["radius"] = radius
+    return R, C, X, summary
+
+
+def outlier_tracks(R, C, intr, X, uv, valid, max_px: float, min_angle_deg: float) -> np.ndarray:
+    """SetOutlierTracksToUnestimated semantics (TheiaSfM): a track stays estimated iff every observation is in front of
+    its camera and within max_px, and some pair of viewing rays subtends more than min_angle_deg."""
+    N, _, K = valid.shape
+    est = np.zeros(N * K, dtype=bool)
+    cosmin = np.cos(np.deg2rad(min_angle_deg))
+    for s in range(N):
+        for k in range(K):
+            i = s * K + k
+            cams = np.nonzero(valid[s, :, k])[0]
+            if len(cams) == 0:
+                continue
+            trk = np.full(len(cams), i)
+            r, _, _, front = residuals(R, C, intr, X, trk, cams, uv[s, cams, k].astype(np.float64))
+            if not front.all() or ((r ** 2).sum(1) > max_px ** 2).any():
+                continue
+            rays = X[i] - C[cams]
+            rays = rays / np.linalg.norm(rays, axis=1, keepdims=True)
+            cs = rays @ rays.T
+            est[i] = bool((cs[np.triu_indices(len(cams), 1)] < cosmin).any())
+    return est
+
+
+def solve_with_scipy(R, C, intr, X, uv, valid, huber_width: float, prior: Optional[Dict] = None, max_nfev: int = 200):
+    """Independent optimiser for the same objective (scipy trust-region reflective, loss='huber' on the 2-vector
+    residual norm implemented through per-observation re-weighting): returns the final cost only."""
+    from scipy.optimize import minimize
+    N, P = len(R), len(X)
+    trk, cam, px = observations(uv, valid)
+
+    def unpack(z):
+        Rn = np.stack([exp_so3(z[6 * t:6 * t + 3]) @ R[t] for t in range(N)])
+        Cn = C + z[:6 * N].reshape(N, 6)[:, 3:]
+        return Rn, Cn, X + z[6 * N:].reshape(P, 3)
+
+    def fun(z):
+        Rn, Cn, Xn = unpack(z)
+        return total_cost(Rn, Cn, intr, Xn, trk, cam, px, huber_width, prior)
+
+    res = minimize(fun, np.zeros(6 * N + 3 * P), method="L-BFGS-B", options={"maxiter": 3000, "maxfun": 200000,
+                                                                           "ftol": 1e-15, "gtol": 1e-10})
+    return float(res.fun)

@@ -52,8 +52,9 @@ def estimate_sim3(chunk_ref: Dict, chunk_qry: Dict, view_graph_matches: List[Tup
     last_pose = _chunk_frame(chunk_ref)["camera_poses"][n_ref - 1].to(device, torch.float32).contiguous()
     w_ref = ref["masks"].reshape(len(pairs), -1).to(torch.uint8).contiguous() if use_masks else None
     w_qry = qry["masks"].reshape(len(pairs), -1).to(torch.uint8).contiguous() if use_masks else None
-    return ops.sim3_umeyama(ref["points"].to(torch.float16), qry["points"].to(torch.float16), idx, last_pose,
-                            w_ref, w_qry, use_filter)
+    # chunk-file points are fp16 and go in as they are; bundle-adjusted chunks carry refined fp32 points
+    dt = torch.float16 if ref["points"].dtype == torch.float16 and qry["points"].dtype == torch.float16 else torch.float32
+    return ops.sim3_umeyama(ref["points"].to(dt), qry["points"].to(dt), idx, last_pose, w_ref, w_qry, use_filter)
 
 
 def sim3_accepted(out33_cpu: torch.Tensor) -> bool:
@@ -101,7 +102,7 @@ def transform_chunk(chunk: Dict, M4: torch.Tensor, device="cuda:0", absolute: bo
 
 def align_and_refine_reconstructions(chunk_ref: Dict, chunk_qry: Dict, view_graph_matches: List[Tuple[int, int]],
                                      use_inverse_depth: bool = False, device="cuda:0",
-                                     use_masks: bool = False) -> Tuple[bool, Dict]:
+                                     use_masks: bool = False, bundle_adjust: Optional[Dict] = None) -> Tuple[bool, Dict]:
     """Same contract as the reference (returns (False, {"error": ...}) instead of raising): chunk_qry is transformed
     in place into chunk_ref's frame.
 
@@ -125,6 +126,20 @@ def align_and_refine_reconstructions(chunk_ref: Dict, chunk_qry: Dict, view_grap
                 "sim3_summary": {"success": True, "alignment_error": float(o[32].item()), "scale": float(o[0].item()),
                                  "matrix": o[13:29].reshape(4, 4).clone(), "global_matrix": G.cpu().clone()},
                 "priors_set": 0, "bundle_adjustment": None}
+        if bundle_adjust is not None:
+            # steps 4-5 (reconstruction_alignment.py:107-171): pose priors on the overlap views from the reference
+            # chunk, 50 LM iterations with Huber 3.0, outlier tracks; the refined values become the chunk's new frame
+            from .bundle_adjust import AFTER_ALIGNMENT, bundle_adjust_chunk, overlap_priors
+            priors = overlap_priors(chunk_ref, view_graph_matches)
+            ba = bundle_adjust_chunk(chunk_qry, bundle_adjust["width"], bundle_adjust["height"],
+                                     bundle_adjust.get("max_observations_per_track", 5), device, AFTER_ALIGNMENT, priors)
+            info["priors_set"] = len(priors)
+            info["bundle_adjustment"] = ba
+            if ba.get("success"):
+                print(f"   Bundle adjustment completed: Success=True, Final cost={ba['final_cost']:.6f}; "
+                      f"removed {ba['removed_tracks']} tracks")
+                chunk_qry["_chunk_frame"] = {"points": chunk_qry["points"], "camera_poses": chunk_qry["camera_poses"]}
+                chunk_qry["_sim3_global"] = torch.eye(4, dtype=torch.float64)
         return True, info
     except Exception as e:  # noqa: BLE001 - the reference swallows and reports (reconstruction_alignment.py:194-198)
         print(f"❌ Complete reconstruction alignment failed: {e}")

@@ -1,0 +1,117 @@
+"""Bundle adjustment of chunk reconstructions: the host side of csrc/ba.hip.
+
+Mirror of what the reference does through pytheia around its BundleAdjustReconstruction calls:
+  * ChunkPTRecon.create_recon_from_chunk (utils/chunk_reconstruction.py:36-222): views with the chunk's poses and
+    intrinsics priors (default fx = fy = max(W, H), principal point at the centre when a chunk has no intrinsics,
+    :96-107), one track per (frame, keypoint) with its own keypoint observation (:128-160) plus the projections into all
+    earlier frames and the next max_observations_per_track // 2 frames that land inside the image (:162-185), then
+    10 LM iterations with Huber width 2.0 (:188-209) and SetOutlierTracksToUnestimated(tracks, 2, 0.25) (:218);
+  * align_and_refine_reconstructions steps 4-5 (utils/reconstruction_alignment.py:107-171): orientation / position
+    priors (covariance 2 I / 25 I) on the query chunk's overlap views taken from the reference chunk's views, 50 LM
+    iterations with Huber width 3.0, outlier tracks (3, 0.25).
+The arithmetic of those pytheia calls is third-party C++ that is not available offline: parity UNPINNED, see
+csrc/ba.hip and oracle/ba_ref.py.  Everything below is bookkeeping; the solver runs in the HIP library."""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Tuple
+
+import torch
+
+from . import ops
+
+PER_CHUNK = dict(max_iters=10, huber_width=2.0, max_reprojection_px=2.0, min_triangulation_angle_deg=0.25)
+AFTER_ALIGNMENT = dict(max_iters=50, huber_width=3.0, max_reprojection_px=3.0, min_triangulation_angle_deg=0.25)
+PRIOR_SQRT_INFO_ROT = (1.0 / 2.0) ** 0.5        # orientation prior covariance 2 I (reconstruction_alignment.py:123)
+PRIOR_SQRT_INFO_POS = (1.0 / 25.0) ** 0.5       # position prior covariance 25 I (:127)
+
+
+def chunk_intrinsics(chunk: Dict, W: int, H: int, device) -> torch.Tensor:
+    """(N, 4) f64 fx, fy, cx, cy: the chunk's estimated intrinsics, else the reference's default (:96-107)."""
+    N = int(chunk["camera_poses"].shape[0])
+    K3 = chunk.get("intrinsics")
+    if K3 is None:
+        f = float(max(W, H))
+        return torch.tensor([[f, f, W / 2.0, H / 2.0]], dtype=torch.float64, device=device).repeat(N, 1)
+    K3 = K3.to(device, torch.float64)
+    return torch.stack([K3[:, 0, 0], K3[:, 1, 1], K3[:, 0, 2], K3[:, 1, 2]], dim=1).contiguous()
+
+
+def poses_to_rc(cam_to_world: torch.Tensor) -> torch.Tensor:
+    """cam->world (N,4,4) -> (N,12) f64 [R world->camera | centre] (SetOrientationFromRotationMatrix(pose[:3,:3].T),
+    SetPosition(pose[:3,3]), chunk_reconstruction.py:118-119)."""
+    P = cam_to_world.to(torch.float64)
+    return torch.cat([P[:, :3, :3].transpose(1, 2).reshape(-1, 9), P[:, :3, 3]], dim=1).contiguous()
+
+
+def rc_to_poses(rc: torch.Tensor) -> torch.Tensor:
+    N = rc.shape[0]
+    P = torch.zeros(N, 4, 4, dtype=torch.float64, device=rc.device)
+    P[:, :3, :3] = rc[:, :9].reshape(N, 3, 3).transpose(1, 2)
+    P[:, :3, 3] = rc[:, 9:]
+    P[:, 3, 3] = 1.0
+    return P
+
+
+def build_observations(chunk: Dict, W: int, H: int, max_observations_per_track: int, device):
+    """Dense observation arrays of a chunk: uv f32 [N,N,K,2] / valid u8 [N,N,K] from pi3_project_observations, with
+    the diagonal (a track in its own frame) holding the keypoint pixel."""
+    pts16 = chunk["points"].to(device, torch.float16).contiguous()
+    poses = chunk["camera_poses"].to(device, torch.float32).contiguous()
+    N, K = pts16.shape[:2]
+    intr = chunk_intrinsics(chunk, W, H, device)
+    K3 = torch.zeros(N, 3, 3, device=device, dtype=torch.float32)
+    K3[:, 0, 0], K3[:, 1, 1], K3[:, 0, 2], K3[:, 1, 2], K3[:, 2, 2] = intr[:, 0], intr[:, 1], intr[:, 2], intr[:, 3], 1.0
+    uv, valid = ops.project_observations(pts16, poses, K3, int(W), int(H), max_observations_per_track // 2)
+    idx = torch.arange(N, device=device)
+    uv[idx, idx] = chunk["keypoints"].to(device, torch.float32)
+    valid = valid.to(torch.uint8)
+    valid[idx, idx] = 1
+    return uv.contiguous(), valid.contiguous(), intr
+
+
+def bundle_adjust_chunk(chunk: Dict, W: int, H: int, max_observations_per_track: int = 5, device="cuda:0",
+                        settings: Dict = PER_CHUNK, priors: Optional[Dict[int, torch.Tensor]] = None) -> Dict:
+    """Refine chunk['points'] (-> fp32) and chunk['camera_poses'] in place; chunk['track_estimated'] (N, K) bool marks
+    the tracks SetOutlierTracksToUnestimated keeps.  priors: {view index: cam->world 4x4 of the reference view}.
+    Returns {'success', 'initial_cost', 'final_cost', 'iterations', 'accepted_steps', 'removed_tracks'}."""
+    if "keypoints" not in chunk or chunk.get("keypoints") is None:
+        return {"success": False, "reason": "no keypoints"}
+    N, K = chunk["points"].shape[:2]
+    if N > 128:
+        return {"success": False, "reason": "more than 128 views in a chunk"}
+    # the reference adds the observations once, when the reconstruction is built from the chunk file values
+    # (chunk_reconstruction.py:128-185), and every later adjustment reuses them (pixels do not change under Sim(3))
+    if "_observations" not in chunk:
+        chunk["_observations"] = build_observations(chunk, W, H, max_observations_per_track, device)
+    uv, valid, intr = chunk["_observations"]
+    pts = chunk["points"].to(device, torch.float64).reshape(N * K, 3).contiguous()
+    rc = poses_to_rc(chunk["camera_poses"].to(device))
+    pr = pc = pf = None
+    if priors:
+        pr = torch.zeros(N, 9, dtype=torch.float64, device=device)
+        pc = torch.zeros(N, 3, dtype=torch.float64, device=device)
+        pf = torch.zeros(N, dtype=torch.uint8, device=device)
+        for v, P in priors.items():
+            if 0 <= v < N:
+                r = poses_to_rc(P.to(device).reshape(1, 4, 4))[0]
+                pr[v], pc[v], pf[v] = r[:9], r[9:], 1
+    summary = ops.bundle_adjust(pts, rc, intr, uv, valid, settings["huber_width"], settings["max_iters"], pr, pc, pf,
+                                PRIOR_SQRT_INFO_ROT, PRIOR_SQRT_INFO_POS)
+    est = ops.ba_outlier_tracks(pts, rc, intr, uv, valid, settings["max_reprojection_px"],
+                                settings["min_triangulation_angle_deg"])
+    s = summary.cpu()
+    ok = bool(torch.isfinite(s[0])) and bool(torch.isfinite(pts).all()) and bool(torch.isfinite(rc).all())
+    if ok:
+        dst = chunk["points"].device
+        chunk["points"] = pts.reshape(N, K, 3).to(torch.float32).to(dst)
+        chunk["camera_poses"] = rc_to_poses(rc).to(torch.float32).to(chunk["camera_poses"].device)
+        chunk["track_estimated"] = est.to(dst)
+    return {"success": ok, "initial_cost": float(s[8]), "final_cost": float(s[0]), "iterations": int(s[5]),
+            "accepted_steps": int(s[6]), "removed_tracks": int((~est).sum().item())}
+
+
+def overlap_priors(chunk_ref: Dict, view_graph_matches: List[Tuple[int, int]]) -> Dict[int, torch.Tensor]:
+    """Pose priors for the query chunk's overlap views = the reference chunk's poses of the same images
+    (reconstruction_alignment.py:110-132)."""
+    n_ref = int(chunk_ref["camera_poses"].shape[0])
+    return {q: chunk_ref["camera_poses"][r] for r, q in view_graph_matches if r < n_ref}

@@ -1,0 +1,691 @@
+// Bundle adjustment of one chunk on the device: the refinement the reference runs through
+// pytheia / Ceres after building a chunk reconstruction (utils/chunk_reconstruction.py:188-219: 10 iterations, Huber
+// 2.0, DENSE_SCHUR, then SetOutlierTracksToUnestimated(…, 2, 0.25)) and after each chunk alignment with pose priors on
+// the overlap views (utils/reconstruction_alignment.py:107-171: orientation prior cov 2 I, position prior cov 25 I,
+// 50 iterations, Huber 3.0, outliers (3, 0.25)).  pytheia 0.2.9 / Ceres are not vendored and not installable offline:
+// the algorithm is RESTATED from the published method (Levenberg-Marquardt trust region with the Schur complement on
+// the points, Huber loss as iteratively re-weighted least squares) - parity with Ceres' iterates is UNPINNED
+// (oracle/ba_ref.py restates the same algorithm in numpy and cross-checks the optimum with scipy).
+//
+// Problem layout (dense, no index lists): a track is (source frame s, keypoint k); camera t observes it iff
+// valid[s][t][k].  Observations are what pi3_project_observations emits, with the diagonal t == s holding the keypoint
+// pixel itself.  N <= 128 cameras, K keypoints per frame, fp64 throughout.
+//   camera t: R_t (world -> camera, row-major 9) and centre C_t (3): pose[t] = [R | C] (12 doubles); intrinsics
+//             (fx, fy, cx, cy) fixed (Theia's default intrinsics_to_optimize = NONE)
+//   residual: r = (fx x/z + cx - u, fy y/z + cy - v),  (x, y, z) = R (X - C)
+//   update:   R <- exp([dw]x) R,  C <- C + dC,  X <- X + dX
+// One LM iteration = fixed sequence of kernels; accept / reject and the trust-region radius live in a device-side state
+// block (no host synchronisation inside the loop).  Every reduction has a fixed order: results do not depend on
+// scheduling.
+#include "common.h"
+
+#define BA_MAXN 128
+#define BA_SLICES 4
+
+struct BaState {
+  double cost, cost_new, radius, decrease, model_change, iters, accepted_steps, done, initial_cost, chol_fail, accept;
+};
+
+struct BaProblem {
+  const float* uv;            // [N][N][K][2]  (source, target, keypoint)
+  const uint8_t* valid;       // [N][N][K]
+  const float* uvT;           // [N][K][N][2]  (source, keypoint, target)
+  const uint8_t* validT;      // [N][K][N]
+  const double* intr;         // [N][4]
+  const double* prior_R;      // [N][9] or null
+  const double* prior_C;      // [N][3]
+  const uint8_t* prior_flag;  // [N]
+  double sqrt_info_rot, sqrt_info_pos, huber;
+  int N, K;
+};
+
+__device__ __forceinline__ double huber_rho(double s, double a, double& w) {
+  if (s <= a * a) { w = 1.0; return s; }
+  const double r = sqrt(s);
+  w = a / r;
+  return 2.0 * a * r - a * a;
+}
+
+// residual + Jacobians of one observation; returns false when the point is not in front of the camera
+__device__ __forceinline__ bool ba_project(const double* pose, const double* in4, const double* X, double u, double v,
+                                           double r[2], double Jc[2][6], double Jp[2][3]) {
+  const double* R = pose;
+  const double d0 = X[0] - pose[9], d1 = X[1] - pose[10], d2 = X[2] - pose[11];
+  const double x = R[0] * d0 + R[1] * d1 + R[2] * d2;
+  const double y = R[3] * d0 + R[4] * d1 + R[5] * d2;
+  const double z = R[6] * d0 + R[7] * d1 + R[8] * d2;
+  if (!(z > 1e-9)) return false;
+  const double iz = 1.0 / z, fx = in4[0], fy = in4[1];
+  r[0] = fx * x * iz + in4[2] - u;
+  r[1] = fy * y * iz + in4[3] - v;
+  const double a0 = fx * iz, a2 = -fx * x * iz * iz, b1 = fy * iz, b2 = -fy * y * iz * iz;   // d(u,v)/d(x,y,z)
+  // point: Jpi R
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    Jp[0][c] = a0 * R[c] + a2 * R[6 + c];
+    Jp[1][c] = b1 * R[3 + c] + b2 * R[6 + c];
+  }
+  // rotation (local): dp = dw x p  ->  Jpi (-[p]x)
+  Jc[0][0] = a2 * y;            Jc[0][1] = a0 * z - a2 * x;   Jc[0][2] = -a0 * y;
+  Jc[1][0] = -b1 * z + b2 * y;  Jc[1][1] = -b2 * x;           Jc[1][2] = b1 * x;
+  // centre: -Jpi R
+#pragma unroll
+  for (int c = 0; c < 3; ++c) { Jc[0][3 + c] = -Jp[0][c]; Jc[1][3 + c] = -Jp[1][c]; }
+  return true;
+}
+
+// deterministic block reduction of `n` values per thread (fixed tree through LDS); result valid in thread 0
+template <int NT>
+__device__ __forceinline__ double ba_block_sum(double v, double* red, int tid) {
+  v = wave_sum_f64(v);
+  __syncthreads();
+  if ((tid & 63) == 0) red[tid >> 6] = v;
+  __syncthreads();
+  double s = 0.0;
+  if (tid == 0)
+    for (int w = 0; w < NT / 64; ++w) s += red[w];
+  return s;
+}
+
+// ---- pass 1: per track: C_i = sum w Jp^T Jp, g_i = sum w Jp^T r, cost_i = sum rho   (thread per track)
+__global__ __launch_bounds__(256) void ba_linearize_points(BaProblem pb, const double* __restrict__ pts,
+                                                           const double* __restrict__ poses, double* __restrict__ Cblk,
+                                                           double* __restrict__ gp, double* __restrict__ cost_part,
+                                                           const BaState* st) {
+  __shared__ double red[4];
+  const int N = pb.N, K = pb.K, tid = threadIdx.x;
+  const long i = (long)blockIdx.x * 256 + tid;
+  double cost = 0.0;
+  if (st->done == 0.0 && i < (long)N * K) {
+    const int s = (int)(i / K), k = (int)(i - (long)s * K);
+    const double X[3] = {pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]};
+    double C[6] = {0, 0, 0, 0, 0, 0}, g[3] = {0, 0, 0};
+    for (int t = 0; t < N; ++t) {
+      const long o = ((long)s * N + t) * K + k;
+      if (!pb.valid[o]) continue;
+      double r[2], Jc[2][6], Jp[2][3];
+      if (!ba_project(poses + 12 * t, pb.intr + 4 * t, X, (double)pb.uv[2 * o], (double)pb.uv[2 * o + 1], r, Jc, Jp))
+        continue;
+      double w;
+      cost += huber_rho(r[0] * r[0] + r[1] * r[1], pb.huber, w);
+      C[0] += w * (Jp[0][0] * Jp[0][0] + Jp[1][0] * Jp[1][0]);
+      C[1] += w * (Jp[0][0] * Jp[0][1] + Jp[1][0] * Jp[1][1]);
+      C[2] += w * (Jp[0][0] * Jp[0][2] + Jp[1][0] * Jp[1][2]);
+      C[3] += w * (Jp[0][1] * Jp[0][1] + Jp[1][1] * Jp[1][1]);
+      C[4] += w * (Jp[0][1] * Jp[0][2] + Jp[1][1] * Jp[1][2]);
+      C[5] += w * (Jp[0][2] * Jp[0][2] + Jp[1][2] * Jp[1][2]);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) g[c] += w * (Jp[0][c] * r[0] + Jp[1][c] * r[1]);
+    }
+#pragma unroll
+    for (int c = 0; c < 6; ++c) Cblk[6 * i + c] = C[c];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) gp[3 * i + c] = g[c];
+  }
+  const double tot = ba_block_sum<256>(cost, red, tid);
+  if (tid == 0) cost_part[blockIdx.x] = 0.5 * tot;
+}
+
+// cost only (candidate parameters)
+__global__ __launch_bounds__(256) void ba_cost_points(BaProblem pb, const double* __restrict__ pts,
+                                                      const double* __restrict__ poses, double* __restrict__ cost_part,
+                                                      const BaState* st) {
+  __shared__ double red[4];
+  const int N = pb.N, K = pb.K, tid = threadIdx.x;
+  const long i = (long)blockIdx.x * 256 + tid;
+  double cost = 0.0;
+  if (st->done == 0.0 && i < (long)N * K) {
+    const int s = (int)(i / K), k = (int)(i - (long)s * K);
+    const double X[3] = {pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]};
+    for (int t = 0; t < N; ++t) {
+      const long o = ((long)s * N + t) * K + k;
+      if (!pb.valid[o]) continue;
+      double r[2], Jc[2][6], Jp[2][3];
+      if (!ba_project(poses + 12 * t, pb.intr + 4 * t, X, (double)pb.uv[2 * o], (double)pb.uv[2 * o + 1], r, Jc, Jp))
+        continue;
+      double w;
+      cost += huber_rho(r[0] * r[0] + r[1] * r[1], pb.huber, w);
+    }
+  }
+  const double tot = ba_block_sum<256>(cost, red, tid);
+  if (tid == 0) cost_part[blockIdx.x] = 0.5 * tot;
+}
+
+// log map of a rotation matrix (row-major), angle-axis vector
+__device__ __forceinline__ void ba_log_so3(const double* R, double w[3]) {
+  const double tr = R[0] + R[4] + R[8];
+  double c = 0.5 * (tr - 1.0);
+  c = c > 1.0 ? 1.0 : (c < -1.0 ? -1.0 : c);
+  const double th = acos(c);
+  const double vx = R[7] - R[5], vy = R[2] - R[6], vz = R[3] - R[1];
+  double f;
+  if (th < 1e-8) f = 0.5;
+  else f = th / (2.0 * sin(th));       // (angles near pi do not occur between a pose and its prior here)
+  w[0] = f * vx; w[1] = f * vy; w[2] = f * vz;
+}
+
+// ---- pass 2: per camera t: B_t = sum w Jc^T Jc (21 values), g_t = sum w Jc^T r, + pose priors.  One WG per camera.
+__global__ __launch_bounds__(256) void ba_camera_blocks(BaProblem pb, const double* __restrict__ pts,
+                                                        const double* __restrict__ poses, double* __restrict__ Bblk,
+                                                        double* __restrict__ gc, double* __restrict__ prior_cost,
+                                                        const BaState* st) {
+  __shared__ double red[4];
+  __shared__ double acc[27];
+  const int N = pb.N, K = pb.K, t = blockIdx.x, tid = threadIdx.x;
+  if (st->done != 0.0) return;
+  double a[27];
+#pragma unroll
+  for (int c = 0; c < 27; ++c) a[c] = 0.0;
+  for (long i = tid; i < (long)N * K; i += 256) {
+    const int s = (int)(i / K), k = (int)(i - (long)s * K);
+    const long o = ((long)s * N + t) * K + k;
+    if (!pb.valid[o]) continue;
+    const double X[3] = {pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]};
+    double r[2], Jc[2][6], Jp[2][3];
+    if (!ba_project(poses + 12 * t, pb.intr + 4 * t, X, (double)pb.uv[2 * o], (double)pb.uv[2 * o + 1], r, Jc, Jp)) continue;
+    double w;
+    huber_rho(r[0] * r[0] + r[1] * r[1], pb.huber, w);
+    int q = 0;
+#pragma unroll
+    for (int p = 0; p < 6; ++p)
+#pragma unroll
+      for (int c = p; c < 6; ++c) a[q++] += w * (Jc[0][p] * Jc[0][c] + Jc[1][p] * Jc[1][c]);
+#pragma unroll
+    for (int p = 0; p < 6; ++p) a[21 + p] += w * (Jc[0][p] * r[0] + Jc[1][p] * r[1]);
+  }
+  for (int c = 0; c < 27; ++c) {
+    const double v = ba_block_sum<256>(a[c], red, tid);
+    if (tid == 0) acc[c] = v;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    double pc = 0.0;
+    if (pb.prior_flag && pb.prior_flag[t]) {
+      // orientation prior: r = sr * log(R R0^T), dr/dw ~ I;  position prior: r = sp * (C - C0)
+      const double* R = poses + 12 * t;
+      const double* R0 = pb.prior_R + 9 * t;
+      double E[9];
+      for (int p = 0; p < 3; ++p)
+        for (int c = 0; c < 3; ++c) E[3 * p + c] = R[3 * p] * R0[3 * c] + R[3 * p + 1] * R0[3 * c + 1] + R[3 * p + 2] * R0[3 * c + 2];
+      double w3[3];
+      ba_log_so3(E, w3);
+      const double sr2 = pb.sqrt_info_rot * pb.sqrt_info_rot, sp2 = pb.sqrt_info_pos * pb.sqrt_info_pos;
+      const int dq[6] = {0, 6, 11, 15, 18, 20};   // packed index of the diagonal entries (p, p)
+      for (int p = 0; p < 3; ++p) {
+        acc[dq[p]] += sr2;
+        acc[21 + p] += sr2 * w3[p];
+        pc += 0.5 * sr2 * w3[p] * w3[p];
+        const double dcp = poses[12 * t + 9 + p] - pb.prior_C[3 * t + p];
+        acc[dq[3 + p]] += sp2;
+        acc[24 + p] += sp2 * dcp;
+        pc += 0.5 * sp2 * dcp * dcp;
+      }
+    }
+    for (int c = 0; c < 21; ++c) Bblk[21 * t + c] = acc[c];
+    for (int c = 0; c < 6; ++c) gc[6 * t + c] = acc[21 + c];
+    prior_cost[t] = pc;
+  }
+}
+
+// prior cost only (candidate parameters)
+__global__ void ba_prior_cost(BaProblem pb, const double* __restrict__ poses, double* __restrict__ prior_cost,
+                              const BaState* st) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (st->done != 0.0 || t >= pb.N) return;
+  double pc = 0.0;
+  if (pb.prior_flag && pb.prior_flag[t]) {
+    const double* R = poses + 12 * t;
+    const double* R0 = pb.prior_R + 9 * t;
+    double E[9], w3[3];
+    for (int p = 0; p < 3; ++p)
+      for (int c = 0; c < 3; ++c) E[3 * p + c] = R[3 * p] * R0[3 * c] + R[3 * p + 1] * R0[3 * c + 1] + R[3 * p + 2] * R0[3 * c + 2];
+    ba_log_so3(E, w3);
+    const double sr2 = pb.sqrt_info_rot * pb.sqrt_info_rot, sp2 = pb.sqrt_info_pos * pb.sqrt_info_pos;
+    for (int p = 0; p < 3; ++p) {
+      const double dcp = poses[12 * t + 9 + p] - pb.prior_C[3 * t + p];
+      pc += 0.5 * sr2 * w3[p] * w3[p] + 0.5 * sp2 * dcp * dcp;
+    }
+  }
+  prior_cost[t] = pc;
+}
+
+// damped inverse of a track's 3x3 block: (C + D)^-1 with D = clamp(diag(C)) / radius; returns false if singular
+__device__ __forceinline__ bool ba_point_inverse(const double* C6, double radius, double Ci[6], double D[3]) {
+  double c00 = C6[0], c01 = C6[1], c02 = C6[2], c11 = C6[3], c12 = C6[4], c22 = C6[5];
+  D[0] = fmin(fmax(c00, 1e-6), 1e32) / radius;
+  D[1] = fmin(fmax(c11, 1e-6), 1e32) / radius;
+  D[2] = fmin(fmax(c22, 1e-6), 1e32) / radius;
+  c00 += D[0]; c11 += D[1]; c22 += D[2];
+  const double m0 = c11 * c22 - c12 * c12, m1 = c02 * c12 - c01 * c22, m2 = c01 * c12 - c02 * c11;
+  const double det = c00 * m0 + c01 * m1 + c02 * m2;
+  if (!(fabs(det) > 1e-300)) return false;
+  const double id = 1.0 / det;
+  Ci[0] = m0 * id; Ci[1] = m1 * id; Ci[2] = m2 * id;
+  Ci[3] = (c00 * c22 - c02 * c02) * id; Ci[4] = (c01 * c02 - c00 * c12) * id; Ci[5] = (c00 * c11 - c01 * c01) * id;
+  return true;
+}
+
+// ---- pass 3: Schur complement rows.  WG (camera j, slice): lanes = cameras k'.  S_part[slice][6j+a][6k'+b] and the
+// slice's share of rhs_j = -(g_j - sum_i E_ij Cinv_i g_i).  Layout T ([s][k][t]) makes a track's cameras contiguous.
+__global__ __launch_bounds__(BA_MAXN) void ba_schur_rows(BaProblem pb, const double* __restrict__ pts,
+                                                         const double* __restrict__ poses,
+                                                         const double* __restrict__ Cblk, const double* __restrict__ gp,
+                                                         double* __restrict__ S_part, double* __restrict__ rhs_part,
+                                                         const BaState* st) {
+  const int N = pb.N, K = pb.K, j = blockIdx.x, slice = blockIdx.y, kp = threadIdx.x;
+  if (st->done != 0.0) return;
+  const int n6 = 6 * N;
+  const double radius = st->radius;
+  double S[6][6], rj[6];
+#pragma unroll
+  for (int a = 0; a < 6; ++a) {
+    rj[a] = 0.0;
+#pragma unroll
+    for (int b = 0; b < 6; ++b) S[a][b] = 0.0;
+  }
+  const bool lane_cam = kp < N;
+  const int s0 = (N * slice) / BA_SLICES, s1 = (N * (slice + 1)) / BA_SLICES;
+  for (int s = s0; s < s1; ++s) {
+    for (int k = 0; k < K; ++k) {
+      const long i = (long)s * K + k;
+      const long oj = i * N + j;
+      if (!pb.validT[oj]) continue;                               // uniform over the workgroup
+      const double X[3] = {pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]};
+      double Ci[6], D[3];
+      if (!ba_point_inverse(Cblk + 6 * i, radius, Ci, D)) continue;
+      // E_ij = Jc^T w Jp for camera j (every lane computes it: no LDS traffic, no barrier)
+      double r[2], Jc[2][6], Jp[2][3], w;
+      if (!ba_project(poses + 12 * j, pb.intr + 4 * j, X, (double)pb.uvT[2 * oj], (double)pb.uvT[2 * oj + 1], r, Jc, Jp))
+        continue;
+      huber_rho(r[0] * r[0] + r[1] * r[1], pb.huber, w);
+      double Y[6][3];   // E_ij Cinv
+#pragma unroll
+      for (int a = 0; a < 6; ++a) {
+        const double e0 = w * (Jc[0][a] * Jp[0][0] + Jc[1][a] * Jp[1][0]);
+        const double e1 = w * (Jc[0][a] * Jp[0][1] + Jc[1][a] * Jp[1][1]);
+        const double e2 = w * (Jc[0][a] * Jp[0][2] + Jc[1][a] * Jp[1][2]);
+        Y[a][0] = e0 * Ci[0] + e1 * Ci[1] + e2 * Ci[2];
+        Y[a][1] = e0 * Ci[1] + e1 * Ci[3] + e2 * Ci[4];
+        Y[a][2] = e0 * Ci[2] + e1 * Ci[4] + e2 * Ci[5];
+      }
+      const double g0 = gp[3 * i], g1 = gp[3 * i + 1], g2 = gp[3 * i + 2];
+#pragma unroll
+      for (int a = 0; a < 6; ++a) rj[a] += Y[a][0] * g0 + Y[a][1] * g1 + Y[a][2] * g2;
+      // this lane's camera k'
+      if (!lane_cam) continue;
+      const long ok = i * N + kp;
+      if (!pb.validT[ok]) continue;
+      double r2[2], Jc2[2][6], Jp2[2][3], w2;
+      if (!ba_project(poses + 12 * kp, pb.intr + 4 * kp, X, (double)pb.uvT[2 * ok], (double)pb.uvT[2 * ok + 1], r2, Jc2, Jp2))
+        continue;
+      huber_rho(r2[0] * r2[0] + r2[1] * r2[1], pb.huber, w2);
+#pragma unroll
+      for (int b = 0; b < 6; ++b) {
+        const double e0 = w2 * (Jc2[0][b] * Jp2[0][0] + Jc2[1][b] * Jp2[1][0]);
+        const double e1 = w2 * (Jc2[0][b] * Jp2[0][1] + Jc2[1][b] * Jp2[1][1]);
+        const double e2 = w2 * (Jc2[0][b] * Jp2[0][2] + Jc2[1][b] * Jp2[1][2]);
+#pragma unroll
+        for (int a = 0; a < 6; ++a) S[a][b] -= Y[a][0] * e0 + Y[a][1] * e1 + Y[a][2] * e2;
+      }
+    }
+  }
+  if (lane_cam) {
+    double* out = S_part + (long)slice * n6 * n6;
+#pragma unroll
+    for (int a = 0; a < 6; ++a)
+#pragma unroll
+      for (int b = 0; b < 6; ++b) out[(long)(6 * j + a) * n6 + 6 * kp + b] = S[a][b];
+  }
+  if (kp == 0)
+    for (int a = 0; a < 6; ++a) rhs_part[((long)slice * N + j) * 6 + a] = rj[a];
+}
+
+// ---- pass 4: assemble S = sum of slices + B + D, rhs = -(g_c - sum slices); one WG; then Cholesky + solves (in place)
+__global__ __launch_bounds__(1024) void ba_solve_cameras(int N, const double* __restrict__ S_part,
+                                                         const double* __restrict__ rhs_part,
+                                                         const double* __restrict__ Bblk, const double* __restrict__ gc,
+                                                         double* __restrict__ S, double* __restrict__ dcam,
+                                                         double* __restrict__ Dcam, BaState* st) {
+  __shared__ double colbuf[6 * BA_MAXN];
+  __shared__ double piv;
+  __shared__ int fail;
+  const int tid = threadIdx.x, n = 6 * N;
+  if (st->done != 0.0) return;
+  const double radius = st->radius;
+  for (long e = tid; e < (long)n * n; e += 1024) {
+    double v = 0.0;
+    for (int sl = 0; sl < BA_SLICES; ++sl) v += S_part[(long)sl * n * n + e];
+    S[e] = v;
+  }
+  __syncthreads();
+  for (int e = tid; e < N * 36; e += 1024) {      // + B_t (symmetric, packed upper) + LM diagonal on the block diagonal
+    const int t = e / 36, a = (e % 36) / 6, b = e % 6;
+    const int p = a < b ? a : b, q = a < b ? b : a;
+    const int idx = p * 6 - p * (p - 1) / 2 + (q - p);
+    double v = Bblk[21 * t + idx];
+    if (a == b) {
+      const double d = fmin(fmax(v, 1e-6), 1e32) / radius;
+      Dcam[6 * t + a] = d;
+      v += d;
+    }
+    S[(long)(6 * t + a) * n + 6 * t + b] += v;
+  }
+  for (int e = tid; e < n; e += 1024) {
+    double v = 0.0;
+    for (int sl = 0; sl < BA_SLICES; ++sl) v += rhs_part[(long)sl * n + e];
+    dcam[e] = -(gc[e] - v);
+  }
+  if (tid == 0) fail = 0;
+  __syncthreads();
+  // right-looking Cholesky, lower triangle, column by column (n <= 768; the matrix lives in L2)
+  for (int c = 0; c < n; ++c) {
+    if (tid == 0) {
+      const double d = S[(long)c * n + c];
+      if (!(d > 0.0)) fail = 1;
+      piv = sqrt(d > 0.0 ? d : 1.0);
+    }
+    __syncthreads();
+    if (fail) break;
+    const double ip = 1.0 / piv;
+    for (int r = c + tid; r < n; r += 1024) {
+      const double v = S[(long)r * n + c] * ip;
+      S[(long)r * n + c] = v;
+      colbuf[r] = v;
+    }
+    __syncthreads();
+    // trailing update S[r][q] -= L[r][c] L[q][c] for c < q <= r
+    const int m = n - c - 1;
+    for (long e = tid; e < (long)m * m; e += 1024) {
+      const int r = c + 1 + (int)(e / m), q = c + 1 + (int)(e % m);
+      if (q <= r) S[(long)r * n + q] -= colbuf[r] * colbuf[q];
+    }
+    __syncthreads();
+  }
+  if (fail) {
+    if (tid == 0) st->chol_fail = 1.0;
+    for (int e = tid; e < n; e += 1024) dcam[e] = 0.0;
+    return;
+  }
+  if (tid == 0) st->chol_fail = 0.0;
+  // forward / backward substitution by one wave; the solution vector lives in LDS (DS operations of one wave execute
+  // in program order, so lane 0's write of x[r] is seen by every lane's reads in the next step)
+  __syncthreads();
+  for (int e = tid; e < n; e += 1024) colbuf[e] = dcam[e];
+  __syncthreads();
+  if (tid < 64) {
+    for (int r = 0; r < n; ++r) {
+      double acc = 0.0;
+      for (int q = tid; q < r; q += 64) acc += S[(long)r * n + q] * colbuf[q];
+      acc = wave_sum_f64(acc);
+      if (tid == 0) colbuf[r] = (colbuf[r] - acc) / S[(long)r * n + r];
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    }
+    for (int r = n - 1; r >= 0; --r) {
+      double acc = 0.0;
+      for (int q = r + 1 + tid; q < n; q += 64) acc += S[(long)q * n + r] * colbuf[q];
+      acc = wave_sum_f64(acc);
+      if (tid == 0) colbuf[r] = (colbuf[r] - acc) / S[(long)r * n + r];
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    }
+  }
+  __syncthreads();
+  for (int e = tid; e < n; e += 1024) dcam[e] = colbuf[e];
+}
+
+// ---- pass 5: back-substitution for the points and candidate parameters; model decrease partials
+__global__ __launch_bounds__(256) void ba_backsub_points(BaProblem pb, const double* __restrict__ pts,
+                                                         const double* __restrict__ poses,
+                                                         const double* __restrict__ Cblk, const double* __restrict__ gp,
+                                                         const double* __restrict__ dcam, double* __restrict__ pts_new,
+                                                         double* __restrict__ model_part, const BaState* st) {
+  __shared__ double red[4];
+  const int N = pb.N, K = pb.K, tid = threadIdx.x;
+  const long i = (long)blockIdx.x * 256 + tid;
+  double model = 0.0;
+  if (st->done == 0.0 && i < (long)N * K) {
+    const int s = (int)(i / K), k = (int)(i - (long)s * K);
+    const double X[3] = {pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]};
+    double Ci[6], D[3];
+    double dx[3] = {0, 0, 0};
+    if (st->chol_fail == 0.0 && ba_point_inverse(Cblk + 6 * i, st->radius, Ci, D)) {
+      double v[3] = {gp[3 * i], gp[3 * i + 1], gp[3 * i + 2]};   // g_i + sum_t E_it^T dc_t
+      for (int t = 0; t < N; ++t) {
+        const long o = ((long)s * N + t) * K + k;
+        if (!pb.valid[o]) continue;
+        double r[2], Jc[2][6], Jp[2][3], w;
+        if (!ba_project(poses + 12 * t, pb.intr + 4 * t, X, (double)pb.uv[2 * o], (double)pb.uv[2 * o + 1], r, Jc, Jp))
+          continue;
+        huber_rho(r[0] * r[0] + r[1] * r[1], pb.huber, w);
+        double jd0 = 0.0, jd1 = 0.0;      // Jc dc
+#pragma unroll
+        for (int a = 0; a < 6; ++a) { jd0 += Jc[0][a] * dcam[6 * t + a]; jd1 += Jc[1][a] * dcam[6 * t + a]; }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) v[c] += w * (Jp[0][c] * jd0 + Jp[1][c] * jd1);
+      }
+      dx[0] = -(Ci[0] * v[0] + Ci[1] * v[1] + Ci[2] * v[2]);
+      dx[1] = -(Ci[1] * v[0] + Ci[3] * v[1] + Ci[4] * v[2]);
+      dx[2] = -(Ci[2] * v[0] + Ci[4] * v[1] + Ci[5] * v[2]);
+      // model decrease = -1/2 g^T d + 1/2 d^T D d
+#pragma unroll
+      for (int c = 0; c < 3; ++c) model += -0.5 * gp[3 * i + c] * dx[c] + 0.5 * D[c] * dx[c] * dx[c];
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) pts_new[3 * i + c] = X[c] + dx[c];
+  }
+  const double tot = ba_block_sum<256>(model, red, tid);
+  if (tid == 0) model_part[blockIdx.x] = tot;
+}
+
+__global__ void ba_update_cameras(int N, const double* __restrict__ poses, const double* __restrict__ dcam,
+                                  const double* __restrict__ gc, const double* __restrict__ Dcam,
+                                  double* __restrict__ poses_new, double* __restrict__ model_cam, const BaState* st) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (st->done != 0.0 || t >= N) return;
+  const double* d = dcam + 6 * t;
+  const double th = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+  double a, b;      // exp([w]x) = I + a [w]x + b [w]x^2
+  if (th < 1e-8) { a = 1.0 - th * th / 6.0; b = 0.5 - th * th / 24.0; }
+  else { a = sin(th) / th; b = (1.0 - cos(th)) / (th * th); }
+  const double wx = d[0], wy = d[1], wz = d[2];
+  const double E[9] = {1.0 - b * (wy * wy + wz * wz), -a * wz + b * wx * wy, a * wy + b * wx * wz,
+                       a * wz + b * wx * wy, 1.0 - b * (wx * wx + wz * wz), -a * wx + b * wy * wz,
+                       -a * wy + b * wx * wz, a * wx + b * wy * wz, 1.0 - b * (wx * wx + wy * wy)};
+  const double* R = poses + 12 * t;
+  for (int p = 0; p < 3; ++p)
+    for (int c = 0; c < 3; ++c)
+      poses_new[12 * t + 3 * p + c] = E[3 * p] * R[c] + E[3 * p + 1] * R[3 + c] + E[3 * p + 2] * R[6 + c];
+  for (int c = 0; c < 3; ++c) poses_new[12 * t + 9 + c] = poses[12 * t + 9 + c] + d[3 + c];
+  double m = 0.0;
+  for (int a6 = 0; a6 < 6; ++a6) m += -0.5 * gc[6 * t + a6] * d[a6] + 0.5 * Dcam[6 * t + a6] * d[a6] * d[a6];
+  model_cam[t] = m;
+}
+
+// ---- pass 6: reductions in a fixed order + Ceres-style trust-region update + commit (single workgroup)
+__global__ __launch_bounds__(256) void ba_decide(int nblk, int N, long n_pts3, const double* __restrict__ cost_part,
+                                                 const double* __restrict__ prior_cost, const double* __restrict__ model_part,
+                                                 const double* __restrict__ model_cam, int first, double* __restrict__ pts,
+                                                 const double* __restrict__ pts_new, double* __restrict__ poses,
+                                                 const double* __restrict__ poses_new, int max_iters, BaState* st) {
+  __shared__ double sh[2];
+  __shared__ int commit;
+  const int tid = threadIdx.x;
+  if (st->done != 0.0) return;
+  if (tid == 0) {
+    double c = 0.0;
+    for (int b = 0; b < nblk; ++b) c += cost_part[b];
+    for (int t = 0; t < N; ++t) c += prior_cost[t];
+    commit = 0;
+    if (first) {            // cost at the starting point
+      st->cost = c; st->initial_cost = c; st->radius = 1e4; st->decrease = 2.0; st->iters = 0.0;
+      st->accepted_steps = 0.0; st->chol_fail = 0.0;
+    } else {
+      double model = 0.0;
+      for (int b = 0; b < nblk; ++b) model += model_part[b];
+      for (int t = 0; t < N; ++t) model += model_cam[t];
+      st->cost_new = c; st->model_change = model;
+      st->iters += 1.0;
+      const double rho = (model > 0.0 && st->chol_fail == 0.0) ? (st->cost - c) / model : -1.0;
+      if (rho > 1e-3 && isfinite(c)) {
+        const double t3 = 2.0 * rho - 1.0;
+        st->radius = fmin(st->radius / fmax(1.0 / 3.0, 1.0 - t3 * t3 * t3), 1e16);
+        st->decrease = 2.0;
+        const double rel = fabs(st->cost - c) / fmax(st->cost, 1e-300);
+        st->cost = c;
+        st->accepted_steps += 1.0;
+        commit = 1;
+        if (rel < 1e-6) st->done = 1.0;           // function tolerance
+      } else {
+        st->radius = st->radius / st->decrease;
+        st->decrease *= 2.0;
+        if (st->radius < 1e-32) st->done = 1.0;
+      }
+      if (st->iters >= (double)max_iters) st->done = 1.0;
+    }
+    st->accept = (double)commit;
+  }
+  __syncthreads();
+  if (commit) {
+    for (long e = tid; e < n_pts3; e += 256) pts[e] = pts_new[e];
+    for (int e = tid; e < 12 * N; e += 256) poses[e] = poses_new[e];
+  }
+  (void)sh;
+}
+
+// ---- outlier tracks: SetOutlierTracksToUnestimated(tracks, max_reprojection_error_px, min_triangulation_angle_deg)
+// restated from the TheiaSfM semantics: a track is unestimated if any observation is behind its camera or off by more
+// than max px, or if no pair of viewing rays subtends more than the minimum angle.
+__global__ __launch_bounds__(256) void ba_outlier_tracks(BaProblem pb, const double* __restrict__ pts,
+                                                         const double* __restrict__ poses, double max_px,
+                                                         double cos_min_angle, uint8_t* __restrict__ estimated) {
+  const int N = pb.N, K = pb.K;
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long)N * K) return;
+  const int s = (int)(i / K), k = (int)(i - (long)s * K);
+  const double X[3] = {pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]};
+  bool ok = true;
+  int nobs = 0;
+  for (int t = 0; t < N && ok; ++t) {
+    const long o = ((long)s * N + t) * K + k;
+    if (!pb.valid[o]) continue;
+    double r[2], Jc[2][6], Jp[2][3];
+    if (!ba_project(poses + 12 * t, pb.intr + 4 * t, X, (double)pb.uv[2 * o], (double)pb.uv[2 * o + 1], r, Jc, Jp)) ok = false;
+    else if (r[0] * r[0] + r[1] * r[1] > max_px * max_px) ok = false;
+    ++nobs;
+  }
+  if (ok) {   // sufficient triangulation angle: some pair of rays with cos(angle) < cos(min angle)
+    bool wide = false;
+    for (int t = 0; t < N && !wide; ++t) {
+      if (!pb.valid[((long)s * N + t) * K + k]) continue;
+      double a0 = X[0] - poses[12 * t + 9], a1 = X[1] - poses[12 * t + 10], a2 = X[2] - poses[12 * t + 11];
+      const double ia = 1.0 / sqrt(a0 * a0 + a1 * a1 + a2 * a2);
+      a0 *= ia; a1 *= ia; a2 *= ia;
+      for (int u = t + 1; u < N; ++u) {
+        if (!pb.valid[((long)s * N + u) * K + k]) continue;
+        double b0 = X[0] - poses[12 * u + 9], b1 = X[1] - poses[12 * u + 10], b2 = X[2] - poses[12 * u + 11];
+        const double ib = 1.0 / sqrt(b0 * b0 + b1 * b1 + b2 * b2);
+        if ((a0 * b0 + a1 * b1 + a2 * b2) * ib < cos_min_angle) { wide = true; break; }
+      }
+    }
+    ok = wide;
+  }
+  estimated[i] = ok ? 1 : 0;
+}
+
+// ------------------------------------------------------------------------------------------------------------- C ABI
+static inline int ba_nblk(int N, int K) { return (int)(((long)N * K + 255) / 256); }
+
+extern "C" long pi3_ba_workspace_doubles(int N, int K) {
+  const long n6 = 6L * N, nk = (long)N * K;
+  return 16 /*state*/ + 6 * nk + 3 * nk + 3 * nk /*pts_new*/ + 12L * N /*poses_new*/ + 21L * N + 6L * N /*gc*/ +
+         6L * N /*dcam*/ + 6L * N /*Dcam*/ + BA_SLICES * n6 * n6 + BA_SLICES * n6 + n6 * n6 + 3L * ba_nblk(N, K) +
+         3L * N + 64;
+}
+
+extern "C" int pi3_bundle_adjust(double* points, double* poses, const double* intr, const float* uv,
+                                 const unsigned char* valid, const float* uvT, const unsigned char* validT, int N, int K,
+                                 double huber_width, int max_iters, const double* prior_R, const double* prior_C,
+                                 const unsigned char* prior_flag, double sqrt_info_rot, double sqrt_info_pos,
+                                 double* summary_dev, double* workspace, long workspace_doubles, void* stream) {
+  if (!points || !poses || !intr || !uv || !valid || !uvT || !validT || !summary_dev || !workspace || N <= 0 ||
+      N > BA_MAXN || K <= 0 || max_iters < 0 || !(huber_width > 0.0) ||
+      ((prior_flag != nullptr) && (!prior_R || !prior_C))) {
+    pi3_set_error("pi3_bundle_adjust: bad arguments N=%d (<= %d) K=%d", N, BA_MAXN, K);
+    return PI3_ERR_ARG;
+  }
+  if (workspace_doubles < pi3_ba_workspace_doubles(N, K)) {
+    pi3_set_error("pi3_bundle_adjust: workspace of %ld doubles, need %ld", workspace_doubles, pi3_ba_workspace_doubles(N, K));
+    return PI3_ERR_WORKSPACE;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  const long n6 = 6L * N, nk = (long)N * K;
+  const int nblk = ba_nblk(N, K);
+  double* w = workspace;
+  BaState* state = (BaState*)w; w += 16;
+  double* Cblk = w; w += 6 * nk;
+  double* gp = w; w += 3 * nk;
+  double* pts_new = w; w += 3 * nk;
+  double* poses_new = w; w += 12L * N;
+  double* Bblk = w; w += 21L * N;
+  double* gc = w; w += 6L * N;
+  double* dcam = w; w += 6L * N;
+  double* Dcam = w; w += 6L * N;
+  double* S_part = w; w += BA_SLICES * n6 * n6;
+  double* rhs_part = w; w += BA_SLICES * n6;
+  double* S = w; w += n6 * n6;
+  double* cost_part = w; w += nblk;
+  double* model_part = w; w += nblk;
+  double* cost_part2 = w; w += nblk;
+  double* prior_cost = w; w += N;
+  double* model_cam = w; w += N;
+  double* prior_cost2 = w; w += N;
+  if (hipMemsetAsync(state, 0, 16 * sizeof(double), st) != hipSuccess) {
+    pi3_set_error("pi3_bundle_adjust: hipMemsetAsync failed");
+    return PI3_ERR_LAUNCH;
+  }
+  BaProblem pb;
+  pb.uv = uv; pb.valid = valid; pb.uvT = uvT; pb.validT = validT; pb.intr = intr;
+  pb.prior_R = prior_R; pb.prior_C = prior_C; pb.prior_flag = prior_flag;
+  pb.sqrt_info_rot = sqrt_info_rot; pb.sqrt_info_pos = sqrt_info_pos; pb.huber = huber_width; pb.N = N; pb.K = K;
+  // cost at the start
+  hipLaunchKernelGGL(ba_cost_points, dim3(nblk), dim3(256), 0, st, pb, points, poses, cost_part, state);
+  hipLaunchKernelGGL(ba_prior_cost, dim3((N + 63) / 64), dim3(64), 0, st, pb, poses, prior_cost, state);
+  hipLaunchKernelGGL(ba_decide, dim3(1), dim3(256), 0, st, nblk, N, 3 * nk, cost_part, prior_cost, model_part, model_cam, 1,
+                     points, pts_new, poses, poses_new, max_iters, state);
+  for (int it = 0; it < max_iters; ++it) {
+    hipLaunchKernelGGL(ba_linearize_points, dim3(nblk), dim3(256), 0, st, pb, points, poses, Cblk, gp, cost_part, state);
+    hipLaunchKernelGGL(ba_camera_blocks, dim3(N), dim3(256), 0, st, pb, points, poses, Bblk, gc, prior_cost, state);
+    hipLaunchKernelGGL(ba_schur_rows, dim3(N, BA_SLICES), dim3(BA_MAXN), 0, st, pb, points, poses, Cblk, gp, S_part,
+                       rhs_part, state);
+    hipLaunchKernelGGL(ba_solve_cameras, dim3(1), dim3(1024), 0, st, N, S_part, rhs_part, Bblk, gc, S, dcam, Dcam, state);
+    hipLaunchKernelGGL(ba_backsub_points, dim3(nblk), dim3(256), 0, st, pb, points, poses, Cblk, gp, dcam, pts_new,
+                       model_part, state);
+    hipLaunchKernelGGL(ba_update_cameras, dim3((N + 63) / 64), dim3(64), 0, st, N, poses, dcam, gc, Dcam, poses_new,
+                       model_cam, state);
+    hipLaunchKernelGGL(ba_cost_points, dim3(nblk), dim3(256), 0, st, pb, pts_new, poses_new, cost_part2, state);
+    hipLaunchKernelGGL(ba_prior_cost, dim3((N + 63) / 64), dim3(64), 0, st, pb, poses_new, prior_cost2, state);
+    hipLaunchKernelGGL(ba_decide, dim3(1), dim3(256), 0, st, nblk, N, 3 * nk, cost_part2, prior_cost2, model_part, model_cam,
+                       0, points, pts_new, poses, poses_new, max_iters, state);
+  }
+  // summary: initial cost, final cost, iterations, accepted steps, final radius
+  if (hipMemcpyAsync(summary_dev, state, sizeof(BaState), hipMemcpyDeviceToDevice, st) != hipSuccess) {
+    pi3_set_error("pi3_bundle_adjust: summary copy failed");
+    return PI3_ERR_LAUNCH;
+  }
+  return pi3_check_launch("bundle_adjust");
+}
+
+extern "C" int pi3_ba_outlier_tracks(const double* points, const double* poses, const double* intr, const float* uv,
+                                     const unsigned char* valid, int N, int K, double max_reprojection_px,
+                                     double min_triangulation_angle_deg, unsigned char* estimated, void* stream) {
+  if (!points || !poses || !intr || !uv || !valid || !estimated || N <= 0 || K <= 0) {
+    pi3_set_error("pi3_ba_outlier_tracks: bad arguments");
+    return PI3_ERR_ARG;
+  }
+  BaProblem pb;
+  pb.uv = uv; pb.valid = valid; pb.uvT = nullptr; pb.validT = nullptr; pb.intr = intr;
+  pb.prior_R = nullptr; pb.prior_C = nullptr; pb.prior_flag = nullptr;
+  pb.sqrt_info_rot = 0; pb.sqrt_info_pos = 0; pb.huber = 1.0; pb.N = N; pb.K = K;
+  hipLaunchKernelGGL(ba_outlier_tracks, dim3(ba_nblk(N, K)), dim3(256), 0, (hipStream_t)stream, pb, points, poses,
+                     max_reprojection_px, cos(min_triangulation_angle_deg * 3.14159265358979323846 / 180.0), estimated);
+  return pi3_check_launch("ba_outlier_tracks");
+}

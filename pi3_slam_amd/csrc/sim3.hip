@@ -57,8 +57,9 @@ __device__ __forceinline__ double block_sum(double v, double* red, int tid) {
 }
 
 struct PairSrc {
-  const __half* pts_ref;  // [ov][K][3]
-  const __half* pts_qry;  // [ov][K][3]
+  const void* pts_ref;    // [ov][K][3] f16 (chunk files) or f32 (bundle-adjusted chunks)
+  const void* pts_qry;    // [ov][K][3]
+  int f32;
   const int* idx;         // [ov][K] ref keypoint index per qry keypoint or -1
   const uint8_t* w_ref;   // optional validity [ov][K] (e.g. masks) or null
   const uint8_t* w_qry;
@@ -74,8 +75,13 @@ __device__ __forceinline__ bool pair_get(const PairSrc& s, int i, double x[3], d
   if (s.w_ref && !s.w_ref[r]) return false;
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
-    x[c] = (double)__half2float(s.pts_qry[3 * i + c]);
-    y[c] = (double)__half2float(s.pts_ref[3 * r + c]);
+    if (s.f32) {
+      x[c] = (double)((const float*)s.pts_qry)[3 * i + c];
+      y[c] = (double)((const float*)s.pts_ref)[3 * r + c];
+    } else {
+      x[c] = (double)__half2float(((const __half*)s.pts_qry)[3 * i + c]);
+      y[c] = (double)__half2float(((const __half*)s.pts_ref)[3 * r + c]);
+    }
   }
   return true;
 }
@@ -234,7 +240,9 @@ extern "C" int pi3_sim3_umeyama(const void* pts_ref, const void* pts_qry, const 
     return PI3_ERR_ARG;
   }
   PairSrc s;
-  s.pts_ref = (const __half*)pts_ref; s.pts_qry = (const __half*)pts_qry; s.idx = idx;
+  s.pts_ref = pts_ref; s.pts_qry = pts_qry; s.idx = idx;
+  s.f32 = (use_filter & 2) ? 1 : 0;
+  use_filter &= 1;
   s.w_ref = w_ref; s.w_qry = w_qry; s.ov = ov; s.K = K;
   hipLaunchKernelGGL(sim3_umeyama_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, s, last_ref_pose, use_filter,
                      out33);

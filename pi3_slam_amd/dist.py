@@ -69,14 +69,14 @@ def shard_chunks(n_chunks: int, rank: int, world: int) -> List[int]:
 
 def pack_boundary(chunk: Dict[str, torch.Tensor], overlap: int, K: int, device="cpu") -> torch.Tensor:
     """Flat fp32 boundary block of one chunk: head (first ov views) and tail (last ov views) of keypoints (as fp16 bit
-    patterns widened to fp32-exact integers), world points, validity, and the last camera pose.
+    patterns widened to fp32-exact integers), world points (fp32 values), validity, and the last camera pose.
     Layout: [n_frames, head_kp(ov*K*2), head_pts(ov*K*3), head_mask(ov*K), tail_kp, tail_pts, tail_mask, pose(16)]."""
     n = int(chunk["points"].shape[0])
     ov = min(overlap, n)
 
     def blk(sl):
         kp = chunk["keypoints"][sl].to(torch.float16).contiguous().view(torch.int16).to(torch.float32)
-        pt = chunk["points"][sl].to(torch.float16).contiguous().view(torch.int16).to(torch.float32)
+        pt = chunk["points"][sl].to(torch.float32).contiguous()   # fp16 file values are exact in fp32; refined ones stay fp32
         mk = chunk["masks"][sl].reshape(-1).to(torch.float32)
         out = torch.zeros(overlap * K * 6, device=device)
         kp, pt, mk = kp.to(device), pt.to(device), mk.to(device)
@@ -102,7 +102,7 @@ def unpack_boundary(flat: torch.Tensor, overlap: int, K: int, n_frames: Optional
 
     def blk(t):
         kp = t[: overlap * K * 2].to(torch.int16).view(torch.float16).reshape(overlap, K, 2)
-        pt = t[overlap * K * 2: overlap * K * 5].to(torch.int16).view(torch.float16).reshape(overlap, K, 3)
+        pt = t[overlap * K * 2: overlap * K * 5].reshape(overlap, K, 3)
         mk = t[overlap * K * 5:].reshape(overlap, K, 1) > 0.5
         return dict(keypoints=kp, points=pt, masks=mk)
 

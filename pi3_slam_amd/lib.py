@@ -15,7 +15,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpi3slam_hip.so")
 
-_vp, _i, _l, _f, _u64 = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_ulonglong
+_vp, _i, _l, _f, _u64, _d = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_ulonglong, C.c_double
 
 # name -> argtypes; every function returns int (0 = ok) except the two noted below.  Mirrors include/pi3slam_hip.h.
 SIGNATURES = {
@@ -53,6 +53,8 @@ SIGNATURES = {
     "pi3_ingest_frames": [_vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp],
     "pi3_undistort_maps": [_vp, _i, _i, _i, _vp, _vp, _vp],
     "pi3_remap_bilinear_u8": [_vp, _i, _i, _i, _vp, _vp, _i, _i, _vp, _vp],
+    "pi3_bundle_adjust": [_vp] * 7 + [_i, _i, _d, _i, _vp, _vp, _vp, _d, _d, _vp, _vp, _l, _vp],
+    "pi3_ba_outlier_tracks": [_vp] * 5 + [_i, _i, _d, _d, _vp, _vp],
 }
 
 _lib: Optional[C.CDLL] = None
@@ -77,6 +79,8 @@ def load(require_gpu: bool = True) -> C.CDLL:
         lib.pi3_device_count.restype = _i
         lib.pi3_groupnorm_ws_doubles.restype = _l
         lib.pi3_groupnorm_ws_doubles.argtypes = [_i, _i, _i]
+        lib.pi3_ba_workspace_doubles.restype = _l
+        lib.pi3_ba_workspace_doubles.argtypes = [_i, _i]
         for name, argt in SIGNATURES.items():
             if os.environ.get("PI3_DEV_PARTIAL") and not hasattr(lib, name):
                 continue  # development builds of a subset of the kernels only

@@ -61,7 +61,8 @@ class Pi3SLAMOnline:
                  save_chunk_reconstructions: bool = False, max_observations_per_track: int = 5,
                  do_metric_depth: bool = False, save_debug_projections: bool = False, model_path: Optional[str] = None,
                  use_inverse_depth: bool = False, moge_model=None, moge_model_path: Optional[str] = None,
-                 hip_graph: bool = True, output_dir: Optional[str] = None, num_loader_workers: int = 0):
+                 hip_graph: bool = True, output_dir: Optional[str] = None, num_loader_workers: int = 0,
+                 bundle_adjust: bool = True):
         self.chunk_length, self.overlap = int(chunk_length), int(overlap)
         self.pixel_limit = 255000 // 2
         self.output_dir = output_dir or os.path.join("/tmp", f"pi3_online_{os.getpid()}")
@@ -77,6 +78,9 @@ class Pi3SLAMOnline:
         self.device = self._creator.device
         self.model = self._creator.model
         self.max_observations_per_track = max_observations_per_track
+        # the two pytheia refinement stages of the reference (ChunkPTRecon BA, prior-constrained BA after alignment) on
+        # the device (bundle_adjust.py); the chunk-parallel branch runs the per-chunk stage only
+        self.bundle_adjust = bool(bundle_adjust)
         self.chunk_reconstructions: List[Dict] = []     # aligned chunk dicts (the reference keeps pytheia objects)
         self.alignment_infos: List[Optional[Dict]] = []
         self.timestamps: List[int] = []
@@ -105,8 +109,26 @@ class Pi3SLAMOnline:
         self._record_timing("create_chunk", time.time() - t0)
         return self._consume(chunk)
 
+    def _ba_args(self, chunk: Dict) -> Optional[Dict]:
+        if not self.bundle_adjust or chunk.get("keypoints") is None:
+            return None
+        return {"width": int(chunk.get("original_width", 406)), "height": int(chunk.get("original_height", 308)),
+                "max_observations_per_track": self.max_observations_per_track}
+
+    def _refine_new_chunk(self, chunk: Dict) -> None:
+        args = self._ba_args(chunk)
+        if args is None:
+            return
+        from .bundle_adjust import PER_CHUNK, bundle_adjust_chunk
+        t0 = time.time()
+        with torch.cuda.stream(self._align_stream):
+            bundle_adjust_chunk(chunk, args["width"], args["height"], args["max_observations_per_track"],
+                                str(self.device), PER_CHUNK)
+        self._record_timing("bundle_adjust_chunk", time.time() - t0)
+
     def _consume(self, chunk: Dict) -> Dict:
-        """Sequential consumer: align to the previous chunk, account the new frames."""
+        """Sequential consumer: refine the chunk, align it to the previous one, account the new frames."""
+        self._refine_new_chunk(chunk)
         t0 = time.time()
         info = self._align_chunk_online(chunk)
         self._record_timing("align_chunk", time.time() - t0)
@@ -124,7 +146,7 @@ class Pi3SLAMOnline:
             return np.eye(4)
         with torch.cuda.stream(self._align_stream):     # beside, not behind, the next chunk's forward
             ok, info = align_and_refine_reconstructions(self.chunk_reconstructions[-2], chunk, self._matches,
-                                                        device=str(self.device))
+                                                        device=str(self.device), bundle_adjust=self._ba_args(chunk))
         self.alignment_infos.append(info if ok else None)
         if not ok:
             print(f"   ❌ Alignment failed for chunk {len(self.chunk_reconstructions) - 1}")
@@ -183,6 +205,8 @@ class Pi3SLAMOnline:
             if c < n:
                 meta, chunk = next(stream)
                 assert meta["chunk_index"] == c
+            if chunk is not None:
+                self._refine_new_chunk(chunk)
             with torch.cuda.stream(self._align_stream):
                 Gs, oks = aligner.step(chunk, w0, n)
                 if chunk is not None:

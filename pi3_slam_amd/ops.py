@@ -275,14 +275,15 @@ def sim3_umeyama(pts_ref: torch.Tensor, pts_qry: torch.Tensor, idx: torch.Tensor
                  use_filter: bool = True) -> torch.Tensor:
     """-> f64 device tensor [33]: s, R(9), t(3), M(16), n_used, n_common, median, rms."""
     lib = _L.load()
-    assert pts_ref.dtype == torch.float16 and pts_qry.dtype == torch.float16 and idx.dtype == torch.int32
+    assert pts_ref.dtype == pts_qry.dtype and pts_ref.dtype in (torch.float16, torch.float32) and idx.dtype == torch.int32
     pts_ref, pts_qry, idx = pts_ref.contiguous(), pts_qry.contiguous(), idx.contiguous()
+    flags = int(bool(use_filter)) | (2 if pts_ref.dtype == torch.float32 else 0)
     assert last_ref_pose.dtype == torch.float32
     last_ref_pose = last_ref_pose.contiguous()
     ov, K = idx.shape
     out = torch.empty(33, device=idx.device, dtype=torch.float64)
     rc = lib.pi3_sim3_umeyama(pts_ref.data_ptr(), pts_qry.data_ptr(), idx.data_ptr(), _L.ptr(w_ref), _L.ptr(w_qry),
-                              ov, K, last_ref_pose.data_ptr(), int(use_filter), out.data_ptr(), _L.stream_ptr())
+                              ov, K, last_ref_pose.data_ptr(), flags, out.data_ptr(), _L.stream_ptr())
     _L.check(rc, "pi3_sim3_umeyama")
     return out
 
@@ -461,6 +462,46 @@ def remap_bilinear_u8(frames_u8: torch.Tensor, map_x: torch.Tensor, map_y: torch
                                    map_y.contiguous().data_ptr(), H, W, dst.data_ptr(), _L.stream_ptr())
     _L.check(rc, "pi3_remap_bilinear_u8")
     return dst
+
+
+# ----------------------------------------------------------------------------------------------- bundle adjustment
+def bundle_adjust(points: torch.Tensor, poses: torch.Tensor, intr: torch.Tensor, uv: torch.Tensor, valid: torch.Tensor,
+                  huber_width: float, max_iters: int, prior_R: Optional[torch.Tensor] = None,
+                  prior_C: Optional[torch.Tensor] = None, prior_flag: Optional[torch.Tensor] = None,
+                  sqrt_info_rot: float = 0.0, sqrt_info_pos: float = 0.0) -> torch.Tensor:
+    """points f64 [N*K,3] and poses f64 [N,12] (R world->camera | centre) refined in place; intr f64 [N,4];
+    uv f32 [N,N,K,2], valid u8 [N,N,K].  -> summary f64 [11] (device)."""
+    lib = _L.load()
+    N, _, K = valid.shape
+    for t in (points, poses, intr):
+        assert t.dtype == torch.float64 and t.is_contiguous()
+    assert uv.dtype == torch.float32 and uv.is_contiguous() and valid.dtype == torch.uint8 and valid.is_contiguous()
+    assert tuple(points.shape) == (N * K, 3) and tuple(poses.shape) == (N, 12) and tuple(intr.shape) == (N, 4)
+    uvT = uv.permute(0, 2, 1, 3).contiguous()          # [source][keypoint][target]: a track's cameras are contiguous
+    validT = valid.permute(0, 2, 1).contiguous()
+    n_ws = int(lib.pi3_ba_workspace_doubles(N, K))
+    ws = torch.empty(n_ws, device=points.device, dtype=torch.float64)
+    summary = torch.empty(11, device=points.device, dtype=torch.float64)
+    if prior_flag is not None:
+        assert prior_flag.dtype == torch.uint8 and prior_R.dtype == torch.float64 and prior_C.dtype == torch.float64
+        prior_R, prior_C, prior_flag = prior_R.contiguous(), prior_C.contiguous(), prior_flag.contiguous()
+    rc = lib.pi3_bundle_adjust(points.data_ptr(), poses.data_ptr(), intr.data_ptr(), uv.data_ptr(), valid.data_ptr(),
+                               uvT.data_ptr(), validT.data_ptr(), N, K, float(huber_width), int(max_iters),
+                               _L.ptr(prior_R), _L.ptr(prior_C), _L.ptr(prior_flag), float(sqrt_info_rot),
+                               float(sqrt_info_pos), summary.data_ptr(), ws.data_ptr(), n_ws, _L.stream_ptr())
+    _L.check(rc, "pi3_bundle_adjust")
+    return summary
+
+
+def ba_outlier_tracks(points: torch.Tensor, poses: torch.Tensor, intr: torch.Tensor, uv: torch.Tensor,
+                      valid: torch.Tensor, max_px: float, min_angle_deg: float) -> torch.Tensor:
+    lib = _L.load()
+    N, _, K = valid.shape
+    est = torch.empty(N * K, device=points.device, dtype=torch.uint8)
+    rc = lib.pi3_ba_outlier_tracks(points.data_ptr(), poses.data_ptr(), intr.data_ptr(), uv.data_ptr(), valid.data_ptr(),
+                                   N, K, float(max_px), float(min_angle_deg), est.data_ptr(), _L.stream_ptr())
+    _L.check(rc, "pi3_ba_outlier_tracks")
+    return est.view(N, K).bool()
 
 
 # ---------------------------------------------------------------------------------------------------- device guard

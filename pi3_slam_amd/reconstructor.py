@@ -49,7 +49,8 @@ def write_ply(points: np.ndarray, colors: np.ndarray, path: str) -> None:
 class OfflineReconstructor:
     def __init__(self, chunk_dir: str, output_dir: str, chunk_length: Optional[int] = None,
                  overlap: Optional[int] = None, max_observations_per_track: int = 5, save_per_chunk: bool = False,
-                 use_inverse_depth: bool = False, device: str = "cuda", save_observations: bool = False):
+                 use_inverse_depth: bool = False, device: str = "cuda", save_observations: bool = False,
+                 bundle_adjust: bool = True):
         self.chunk_dir, self.output_dir = chunk_dir, output_dir
         loaded_cl = loaded_ov = None
         try:  # offline_reconstructor.py:32-46
@@ -70,6 +71,11 @@ class OfflineReconstructor:
         self.device = resolve_device(device)     # 'cuda' -> this rank's card (the one the process group is bound to)
         if torch.cuda.is_available():
             torch.cuda.set_device(self.device)   # every kernel wrapper launches on the current device's stream
+        # bundle_adjust: the reference's two refinement stages (per chunk: utils/chunk_reconstruction.py:188-219; after each
+        # alignment with pose priors: utils/reconstruction_alignment.py:107-171) on the device (csrc/ba.hip, parity
+        # unpinned); False = closed-form Sim(3) chain only
+        self.bundle_adjust = bool(bundle_adjust)
+        self.ba_infos: List[Dict] = []
         # save_observations: also write, per chunk, the track observations the reference builds for its bundle adjuster
         # (ChunkPTRecon.create_recon_from_chunk, utils/chunk_reconstruction.py:162-185) as observations_%06d.pt
         self.save_observations = save_observations
@@ -90,11 +96,33 @@ class OfflineReconstructor:
             return None
         matches = create_view_graph_matches(self.chunk_length, self.overlap)
         ok, info = align_and_refine_reconstructions(self.reconstructions[-2], self.reconstructions[-1], matches,
-                                                    device=self.device)
+                                                    device=self.device, bundle_adjust=self._ba_args(self.reconstructions[-1]))
         if not ok:
             print(f"   ❌ Alignment failed for chunk {len(self.reconstructions) - 1}")
             return None
         return info
+
+    def _ba_args(self, data: Dict) -> Optional[Dict]:
+        if not self.bundle_adjust or data.get("keypoints") is None:
+            return None
+        return {"width": int(data.get("original_width", 406)), "height": int(data.get("original_height", 308)),
+                "max_observations_per_track": self.max_observations_per_track}
+
+    def _bundle_adjust_new_chunk(self, data: Dict, idx: int) -> None:
+        """The refinement inside ChunkPTRecon.create_recon_from_chunk (chunk_reconstruction.py:188-219)."""
+        args = self._ba_args(data)
+        if args is None:
+            return
+        try:
+            from .bundle_adjust import PER_CHUNK, bundle_adjust_chunk
+            info = bundle_adjust_chunk(data, args["width"], args["height"], args["max_observations_per_track"],
+                                       self.device, PER_CHUNK)
+            self.ba_infos.append(info)
+            if info.get("success"):
+                print(f"   Removed {info['removed_tracks']} tracks after initial bundle adjustment "
+                      f"(cost {info['initial_cost']:.4f} -> {info['final_cost']:.4f}, {info['iterations']} iterations)")
+        except Exception as e:  # noqa: BLE001 - degrade, do not crash
+            print(f"   ⚠️  Bundle adjustment of chunk {idx} failed: {e}")
 
     def run(self) -> None:
         from .dist import ensure_process_group
@@ -108,6 +136,7 @@ class OfflineReconstructor:
             print(f"\n📦 Loading {os.path.basename(path)} ({idx + 1}/{len(chunk_files)})")
             data: Dict = torch.load(path, map_location="cpu", weights_only=False)
             t0 = time.time()
+            self._bundle_adjust_new_chunk(data, idx)
             self.reconstructions.append(data)
             if idx > 0:
                 print("   🔗 Aligning with previous reconstruction...")
@@ -165,6 +194,8 @@ class OfflineReconstructor:
         for w0 in range(0, n_chunks, world):
             c = w0 + rank
             data = torch.load(files[c], map_location="cpu", weights_only=False) if c < n_chunks else None
+            if data is not None:    # the per-chunk refinement is independent per chunk; the prior-constrained one after
+                self._bundle_adjust_new_chunk(data, c)   # each alignment needs the refined predecessor: sequential only
             Gs, oks = aligner.step(data, w0, n_chunks)
             for r, ok in enumerate(oks):
                 if not ok and rank == 0:

@@ -22,12 +22,14 @@ def main():
     creator = OfflineChunkCreator(cfg, model=None if False else Pi3Engine(small, f"cuda:{torch.cuda.current_device()}"),
                                   moge_model=None)
     creator.process_and_save(paths)
-    OfflineReconstructor(out_dir, recon_dir).run()          # device 'cuda' -> this rank's card (dist.resolve_device)
+    # bundle_adjust=False: the equality claim is about the closed-form chain (the prior-constrained refinement after an
+    # alignment needs the refined predecessor and exists in the sequential flow only); BA has its own tests
+    OfflineReconstructor(out_dir, recon_dir, bundle_adjust=False).run()   # device 'cuda' -> this rank's card
     # BASELINE config 5: the online sliding-window path, chunk-parallel when launched under torch.distributed.run
     from pi3_slam_amd.online import Pi3SLAMOnline
     slam = Pi3SLAMOnline(model=creator.model, chunk_length=8, overlap=3, device=str(creator.device), keypoint_type="grid",
                          max_num_keypoints=100, estimate_camera_params=True, hip_graph=True,
-                         output_dir=os.path.join(recon_dir, "online"))
+                         output_dir=os.path.join(recon_dir, "online"), bundle_adjust=False)
     res = slam.process_chunks(paths)
     if slam.rank == 0:
         os.makedirs(os.path.join(recon_dir, "online"), exist_ok=True)

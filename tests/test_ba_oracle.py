@@ -1,0 +1,65 @@
+"""CPU: known-answer tests of the bundle-adjustment oracle (oracle/ba_ref.py).  Parity with pytheia / Ceres is UNPINNED
+(not available offline); these tests pin the restated algorithm to facts that hold for ANY correct implementation:
+exact data -> zero cost, the LM optimum equals an independent optimiser's optimum, priors and the Huber loss act as
+defined, outlier-track semantics on hand-made cases."""
+import numpy as np
+import pytest
+
+from ba_problem import make_problem
+from oracle import ba_ref
+
+
+def test_exact_observations_are_a_fixed_point_and_perturbations_are_repaired():
+    pb = make_problem(perturb=0.0)
+    R, C, X, s = ba_ref.bundle_adjust(pb["R"], pb["C"], pb["intr"], pb["X"], pb["uv"], pb["valid"], 2.0, 5)
+    assert s["initial_cost"] < 1e-6 and s["final_cost"] <= s["initial_cost"] + 1e-12     # float32 pixels only
+    pb = make_problem(perturb=1.0, seed=3)
+    R, C, X, s = ba_ref.bundle_adjust(pb["R"], pb["C"], pb["intr"], pb["X"], pb["uv"], pb["valid"], 2.0, 60)
+    assert s["initial_cost"] > 10.0 and s["final_cost"] < 1e-6 * s["initial_cost"], s
+    for Rt in R:
+        assert np.abs(Rt @ Rt.T - np.eye(3)).max() < 1e-12 and abs(np.linalg.det(Rt) - 1) < 1e-12
+
+
+@pytest.mark.parametrize("outliers", [0.0, 0.05])
+def test_lm_optimum_equals_independent_optimiser(outliers):
+    pb = make_problem(N=3, K=5, seed=5, noise_px=0.7, outlier_frac=outliers, perturb=0.5)
+    a = 2.0
+    R, C, X, s = ba_ref.bundle_adjust(pb["R"], pb["C"], pb["intr"], pb["X"], pb["uv"], pb["valid"], a, 200)
+    ref = ba_ref.solve_with_scipy(R, C, pb["intr"], X, pb["uv"], pb["valid"], a)       # polish from the LM optimum
+    assert ref <= s["final_cost"] * (1 + 1e-9) and ref >= s["final_cost"] * (1 - 2e-3), (ref, s)
+    cold = ba_ref.solve_with_scipy(pb["R"], pb["C"], pb["intr"], pb["X"], pb["uv"], pb["valid"], a)   # from the start point
+    assert s["final_cost"] <= cold * (1 + 1e-3), (s["final_cost"], cold)
+    if outliers:
+        assert s["final_cost"] > 5.0          # the robust loss keeps (bounded) cost on the outliers instead of bending to them
+
+
+def test_pose_priors_pull_the_cameras():
+    pb = make_problem(N=4, K=6, seed=2, perturb=0.0)
+    prior = dict(R=pb["R_gt"].copy(), C=pb["C_gt"] + np.array([0.3, 0.0, 0.0]), flag=np.array([1, 1, 0, 0], np.uint8),
+                 sqrt_info_rot=50.0, sqrt_info_pos=50.0)          # strong priors that disagree with the data by 0.3 m
+    R, C, X, s = ba_ref.bundle_adjust(pb["R"], pb["C"], pb["intr"], pb["X"], pb["uv"], pb["valid"], 3.0, 50, prior)
+    assert s["final_cost"] < s["initial_cost"]
+    moved = C - pb["C_gt"]
+    assert (moved[:2, 0] > 0.05).all()                       # the two constrained cameras moved towards their priors
+    weak = dict(prior, sqrt_info_rot=1e-3, sqrt_info_pos=1e-3)
+    _, C2, _, s2 = ba_ref.bundle_adjust(pb["R"], pb["C"], pb["intr"], pb["X"], pb["uv"], pb["valid"], 3.0, 50, weak)
+    # weak priors: the data term wins; only the gauge (global similarity, free in the data term) drifts towards them
+    assert s2["final_cost"] < 1e-5 and np.abs(C2 - pb["C_gt"]).max() < 0.05
+
+
+def test_outlier_track_semantics():
+    pb = make_problem(N=4, K=5, seed=1)
+    est = ba_ref.outlier_tracks(pb["R_gt"], pb["C_gt"], pb["intr"], pb["X_gt"], pb["uv"], pb["valid"], 2.0, 0.25)
+    nobs = pb["valid"].sum(1).reshape(-1)
+    assert est[nobs >= 2].all() and not est[nobs < 2].any()        # clean data: only single-view tracks go
+    uv = pb["uv"].copy()
+    uv[2, 0, 1] += 5.0                                             # one observation 5 px off -> its track goes
+    est2 = ba_ref.outlier_tracks(pb["R_gt"], pb["C_gt"], pb["intr"], pb["X_gt"], uv, pb["valid"], 2.0, 0.25)
+    assert not est2[2 * 5 + 1] and (est2 == est).sum() == len(est) - 1
+    est3 = ba_ref.outlier_tracks(pb["R_gt"], pb["C_gt"], pb["intr"], pb["X_gt"], uv, pb["valid"], 10.0, 0.25)
+    assert np.array_equal(est3, est)                               # within a 10 px threshold again
+    est4 = ba_ref.outlier_tracks(pb["R_gt"], pb["C_gt"], pb["intr"], pb["X_gt"], pb["uv"], pb["valid"], 2.0, 60.0)
+    assert not est4.any()                                          # no pair of rays 60 degrees apart
+    X = pb["X_gt"].copy()
+    X[0] = pb["C_gt"][0] - pb["R_gt"][0].T @ np.array([0, 0, 2.0])  # behind camera 0
+    assert not ba_ref.outlier_tracks(pb["R_gt"], pb["C_gt"], pb["intr"], X, pb["uv"], pb["valid"], 1e9, 0.25)[0]

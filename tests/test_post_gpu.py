@@ -348,7 +348,9 @@ def test_offline_reconstructor_roundtrip(dev, tmp_path):
                     "original_width": 406, "original_height": 308, "chunk_index": c},
                    tmp_path / "chunks" / f"chunk_{c:06d}.pt")
     json.dump({"chunk_length": cl, "overlap": ov, "target_size": [308, 406]}, open(tmp_path / "chunk_metadata.json", "w"))
-    rec = OfflineReconstructor(str(tmp_path), str(tmp_path / "out"))
+    # random keypoints / points / poses with no camera model behind them: the closed-form chain is what this test is
+    # about (bundle adjustment of physically inconsistent data is meaningless; it has its own tests in test_ba_gpu.py)
+    rec = OfflineReconstructor(str(tmp_path), str(tmp_path / "out"), bundle_adjust=False)
     assert rec.chunk_length == cl and rec.overlap == ov
     rec.run()
     lines = open(tmp_path / "out" / "trajectory_tum.txt").read().strip().split("\n")

@@ -458,6 +458,8 @@ int pi3_attention_knorm_launch(const void* k, long tok_stride, long batch_stride
   return pi3_check_launch("a64_knorm");
 }
 
+int pi3_attention64p_launch(const Attn64Params& p, long nwg, hipStream_t stream);   // attn64p.hip: software-pipelined form
+
 // Called by pi3_attention (attn.hip) for long sequences; same argument meaning.
 // k2max_ws: caller-provided [B*H] floats (or null -> online-max loop); k2max_ready: already filled by the producer.
 int pi3_attention64_launch(const void* q, const void* k, const void* v, long tok_stride, long batch_stride, void* o,
@@ -504,6 +506,12 @@ int pi3_attention64_launch(const void* q, const void* k, const void* v, long tok
     }
     p.k2max = k2max_ws;
   }
+  static int pipe = -1;   // PI3_ATTN_PIPE: 1 = software-pipelined kernel (attn64p.hip), 0 = the three-phase loop (A/B knob)
+  if (pipe < 0) {
+    const char* e = getenv("PI3_ATTN_PIPE");
+    pipe = e ? atoi(e) : 0;
+  }
+  if (pipe && nw == 8) return pi3_attention64p_launch(p, nwg, stream);
   static int msum = -1;   // PI3_ATTN_MSUM: 1 = row sums on the matrix pipe in the bounded-score loop (A/B knob)
   if (msum < 0) {
     const char* e = getenv("PI3_ATTN_MSUM");

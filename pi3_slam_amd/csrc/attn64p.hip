@@ -1,0 +1,374 @@
+// Attention forward for long sequences, software-pipelined form of attn64.hip (same tiles, fragments, LDS images,
+// bounded-score test and results; see that header for the data flow).
+//
+// attn64.hip runs, per 64-key tile and wave, QK^T (16 MFMAs) -> softmax (64 v_exp + 32 v_cvt_pk) -> PV (16 MFMAs) as
+// three dependent phases, and the two waves of a SIMD march through them together (one barrier per tile): the matrix
+// pipe idles during the softmax and the vector unit during the MFMA phases (60-68 % MFMA busy).  Here every wave works
+// on THREE half-tiles (32 keys) at once, one per stage:
+//      matrix pipe:   S^T(j+1) = K(j+1).Q^T   (8 MFMAs)      and      O^T += V^T(j-1).P^T(j-1)   (8 MFMAs)
+//      vector unit:   P(j) = exp2(S^T(j)) -> bf16           (32 v_exp + 16 v_cvt_pk, + 8 row-sum MFMAs 4x4x4)
+// The three are independent inside a step, so the instruction stream alternates one MFMA with two v_exp and one
+// v_cvt_pk (2 x 8 + 4 issue cycles under the MFMA's 24 free ones; pinned with sched_group_barrier).
+// STATUS: correct (same tests as attn64.hip, both paths), measured 14.06 ms against 13.90 ms of the three-phase kernel at
+// S = 64 300 on the same device (round 2): the interleave comes out as written, but hipcc places each fragment read
+// right in front of the MFMA that consumes it, so every wave still stalls a dozen times per step on the LDS round trip
+// and two waves per SIMD do not cover that; prefetching the next step's 12 fragments needs 32 more registers than the
+// 256 this occupancy allows.  Kept behind PI3_ATTN_PIPE=1 as the starting point for a hand-scheduled stream; the
+// three-phase kernel stays the default.  Register cost is unchanged: two score
+// half-tiles (even / odd) and two packed probability half-tiles are live, exactly the 64 + 32 registers the unpipelined
+// loop holds; every K and V^T fragment still feeds both query blocks.
+// K/V rings are 3 deep (the QK^T stage runs half a tile ahead of the PV stage): body(t) reads K(t), K(t+1), V(t-1),
+// V(t) while the LDS-DMA of K(t+2) and V(t+1) is in flight; one barrier per tile as before.
+// Waves that fail the bounded-score test run the online-max loop of attn64.hip inside the same ring / barrier protocol
+// (tile t needs K(t) and V(t), both resident during body(t)), so every input gives the exact softmax.
+#include "common.h"
+#include <stdlib.h>
+
+struct Attn64Params {
+  const bf16_t* q; const bf16_t* k; const bf16_t* v;
+  long tok_stride, batch_stride;
+  bf16_t* o; long o_tok_stride, o_batch_stride;
+  int S, H, B, nqb;
+  const float* k2max;
+  unsigned long long* dbg;
+};
+#define P64_BOUND2 8100.0f
+#define P64_KT 64
+#define P64_THR 6.0f
+#define P64_SLOT 8192
+
+typedef short p64_s16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ bf16x8 p64_cat4(bf16x4 a, bf16x4 b) { return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7); }
+
+__device__ __forceinline__ void p64_glds16(const void* gsrc, const void* lds_dst) {
+  const unsigned m0v = __builtin_amdgcn_readfirstlane(
+      (unsigned)(__UINTPTR_TYPE__)((__attribute__((address_space(3))) void*)(lds_dst)));
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(m0v) : "memory", "m0");
+}
+
+// exp2 + bf16 pack of one 32-row block's half-tile (16 scores per lane) + row sums on the matrix pipe
+__device__ __forceinline__ void p64_exp_half(const f32x16& sc, bf16x8 (&pf)[2], f32x4& lacc) {
+  const p64_s16x4 ones = {0x3f80, 0x3f80, 0x3f80, 0x3f80};
+#pragma unroll
+  for (int s2 = 0; s2 < 2; ++s2) {
+    u32x4 pw;
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+      const float p0 = __builtin_amdgcn_exp2f(sc[8 * s2 + 2 * jj]);
+      const float p1 = __builtin_amdgcn_exp2f(sc[8 * s2 + 2 * jj + 1]);
+      pw[jj] = pack_bf16x2(p0, p1);
+    }
+    u32x2 lo2, hi2;
+    lo2[0] = pw[0]; lo2[1] = pw[1]; hi2[0] = pw[2]; hi2[1] = pw[3];
+    lacc = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(ones, __builtin_bit_cast(p64_s16x4, lo2), lacc, 0, 0, 0);
+    lacc = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(ones, __builtin_bit_cast(p64_s16x4, hi2), lacc, 0, 0, 0);
+    pf[s2] = __builtin_bit_cast(bf16x8, pw);
+  }
+}
+
+// online-softmax step of one 32-row block on a whole tile (slow path; as attn64.hip)
+template <bool FIRST>
+__device__ __forceinline__ void p64_softmax_online(f32x16 (&sc)[2], float& m, f32x16 (&o)[2], float& l, bf16x8 (&pf)[2][2]) {
+  float tmax = sc[0][0];
+#pragma unroll
+  for (int i = 1; i < 16; ++i) tmax = fmaxf(tmax, sc[0][i]);
+#pragma unroll
+  for (int i = 0; i < 16; ++i) tmax = fmaxf(tmax, sc[1][i]);
+  tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+  if (FIRST) {
+    m = tmax;
+  } else if (!__all(tmax <= m + P64_THR)) {
+    const float mn = fmaxf(m, tmax);
+    float alpha = __builtin_amdgcn_exp2f(m - mn);
+    asm volatile("s_nop 1" : "+v"(alpha));
+    l *= alpha;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) asm volatile("v_mul_f32 %0, %1, %0" : "+v"(o[dt][i]) : "v"(alpha));
+    m = mn;
+  }
+  float psum = 0.f;
+#pragma unroll
+  for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      u32x4 pw;
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        const float p0 = __builtin_amdgcn_exp2f(sc[kt][8 * s2 + 2 * jj] - m);
+        const float p1 = __builtin_amdgcn_exp2f(sc[kt][8 * s2 + 2 * jj + 1] - m);
+        psum += p0 + p1;
+        pw[jj] = pack_bf16x2(p0, p1);
+      }
+      pf[kt][s2] = __builtin_bit_cast(bf16x8, pw);
+    }
+  l += psum;
+}
+
+__global__ __launch_bounds__(512, 2) void attn_fwd64p_kernel(Attn64Params p) {
+  __shared__ __attribute__((aligned(16))) char lds[6 * P64_SLOT];   // K ring [3][64][128 B], then V ring [3][64][128 B]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int nwg = p.nqb * p.H * p.B;
+  const int id = xcd_remap(blockIdx.x, nwg);
+  const int qb = id % p.nqb;
+  const int head = (id / p.nqb) % p.H;
+  const int b = id / (p.nqb * p.H);
+  const int S = p.S;
+
+  const int q0 = qb * 512 + wave * 64;
+  bf16x8 qfA[4], qfB[4];
+  {
+    const int ra = min(q0 + r, S - 1), rb = min(q0 + 32 + r, S - 1);
+    const bf16_t* pa = p.q + (long)b * p.batch_stride + (long)ra * p.tok_stride + head * 64;
+    const bf16_t* pb = p.q + (long)b * p.batch_stride + (long)rb * p.tok_stride + head * 64;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      qfA[s] = *(const bf16x8*)(pa + 16 * s + 8 * h);
+      qfB[s] = *(const bf16x8*)(pb + 16 * s + 8 * h);
+    }
+  }
+  f32x16 oA[2], oB[2];
+  oA[0] = oA[1] = oB[0] = oB[1] = (f32x16)(0.f);
+  float lA = 0.f, lB = 0.f;
+  f32x4 laccA = (f32x4)(0.f), laccB = (f32x4)(0.f);
+
+  const int nt = (S + P64_KT - 1) / P64_KT;
+  const bf16_t* kbase = p.k + (long)b * p.batch_stride + head * 64;
+  const bf16_t* vbase = p.v + (long)b * p.batch_stride + head * 64;
+  // LDS-DMA: wave w writes the 1 KiB segment (rows 8w .. 8w+7) of a K (V) tile; slot (row, pos) receives source chunk
+  // pos ^ f(row) (swizzle on the source address)
+  const int drow = wave * 8 + (lane >> 3), dpos = lane & 7;
+  const int kchunk = (dpos ^ ((drow >> 1) & 7)) << 4, vchunk = (dpos ^ (((drow >> 1) & 1) << 2)) << 4;
+  auto dma_k = [&](int T, int slot) {
+    int grow = T * P64_KT + drow;
+    grow = grow < S ? grow : S - 1;
+    p64_glds16((const char*)(kbase + (long)grow * p.tok_stride) + kchunk, lds + slot * P64_SLOT + wave * 1024);
+  };
+  auto dma_v = [&](int T, int slot) {
+    int grow = T * P64_KT + drow;
+    grow = grow < S ? grow : S - 1;
+    p64_glds16((const char*)(vbase + (long)grow * p.tok_stride) + vchunk, lds + (3 + slot) * P64_SLOT + wave * 1024);
+  };
+
+  const int kswz = (r >> 1) & 7;
+  const int krow_off = r * 128;
+  const int gi = lane & 15, gg = (lane >> 4) & 1;
+  const int vrow_l = 4 * h + (gi >> 2);
+  const int vcol_l = 16 * gg + 4 * (gi & 3);
+  const int vch_l = vcol_l >> 3;
+  const int vin_l = (vcol_l & 7) * 2;
+  const int vswz = ((vrow_l >> 1) & 1) << 2;
+  const int koff0 = ((0 + h) ^ kswz) << 4, koff1 = ((2 + h) ^ kswz) << 4, koff2 = ((4 + h) ^ kswz) << 4,
+            koff3 = ((6 + h) ^ kswz) << 4;
+  const int voff0 = vrow_l * 128 + (((0 + vch_l) ^ vswz) << 4) + vin_l;      // dt = 0
+  const int voff1 = vrow_l * 128 + (((4 + vch_l) ^ vswz) << 4) + vin_l;      // dt = 1
+
+  // bounded-score test (attn64.hip header): wave-uniform
+  bool fast = false;
+  if (p.k2max) {
+    const float k2 = p.k2max[b * p.H + head];
+    float qa = 0.f, qb2 = 0.f;
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float fa = (float)qfA[s][e], fb = (float)qfB[s][e];
+        qa += fa * fa;
+        qb2 += fb * fb;
+      }
+    qa += __shfl_xor(qa, 32, 64);
+    qb2 += __shfl_xor(qb2, 32, 64);
+    fast = __all(fmaxf(qa, qb2) * k2 <= P64_BOUND2);
+  }
+
+  // prologue: K(0), V(0), K(1) resident
+  dma_k(0, 0);
+  dma_v(0, 0);
+  if (nt > 1) dma_k(1, 1);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+// S^T of one half-tile (32 keys) for both query blocks: 4 K fragments, 8 MFMAs
+#define P64_QK(KSLOT, HALF, SA, SB)                                                                      \
+  {                                                                                                      \
+    const char* kl = lds + (KSLOT) * P64_SLOT + (HALF) * 32 * 128 + krow_off;                            \
+    const bf16x8 a0 = *(const bf16x8*)(kl + koff0);                                                      \
+    const bf16x8 a1 = *(const bf16x8*)(kl + koff1);                                                      \
+    const bf16x8 a2 = *(const bf16x8*)(kl + koff2);                                                      \
+    const bf16x8 a3 = *(const bf16x8*)(kl + koff3);                                                      \
+    SA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, qfA[0], (f32x16)(0.f), 0, 0, 0);                    \
+    SB = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, qfB[0], (f32x16)(0.f), 0, 0, 0);                    \
+    SA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, qfA[1], SA, 0, 0, 0);                               \
+    SB = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, qfB[1], SB, 0, 0, 0);                               \
+    SA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, qfA[2], SA, 0, 0, 0);                               \
+    SB = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, qfB[2], SB, 0, 0, 0);                               \
+    SA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, qfA[3], SA, 0, 0, 0);                               \
+    SB = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, qfB[3], SB, 0, 0, 0);                               \
+  }
+// O^T += V^T . P^T for one half-tile (32 keys = two 16-key k-steps) and both query blocks: 8 transposed reads, 8 MFMAs
+#define P64_PV(VSLOT, HALF, PA, PB)                                                                      \
+  {                                                                                                      \
+    const char* vl = lds + (3 + (VSLOT)) * P64_SLOT + (HALF) * 32 * 128;                                 \
+    _Pragma("unroll") for (int s2 = 0; s2 < 2; ++s2) {                                                   \
+      const char* a0p = vl + s2 * 16 * 128 + voff0;                                                      \
+      const char* a1p = vl + s2 * 16 * 128 + voff1;                                                      \
+      const bf16x4 lo0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)LDS_PTR(a0p));           \
+      const bf16x4 hi0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)LDS_PTR(a0p + 8 * 128)); \
+      const bf16x4 lo1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)LDS_PTR(a1p));           \
+      const bf16x4 hi1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)LDS_PTR(a1p + 8 * 128)); \
+      const bf16x8 v0 = p64_cat4(lo0, hi0), v1 = p64_cat4(lo1, hi1);                                     \
+      oA[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v0, PA[s2], oA[0], 0, 0, 0);                       \
+      oB[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v0, PB[s2], oB[0], 0, 0, 0);                       \
+      oA[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v1, PA[s2], oA[1], 0, 0, 0);                       \
+      oB[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v1, PB[s2], oB[1], 0, 0, 0);                       \
+    }                                                                                                    \
+  }
+#define P64_MASK(T, HALF, SC)                                                                            \
+  {                                                                                                      \
+    const int kb = (T) * P64_KT + 32 * (HALF) + 4 * h;                                                   \
+    _Pragma("unroll") for (int i = 0; i < 16; ++i) {                                                     \
+      const int key = kb + (i & 3) + 8 * (i >> 2);                                                       \
+      if (key >= S) SC[i] = -INFINITY;                                                                   \
+    }                                                                                                    \
+  }
+// interleave hint for one pipelined step: 16 x {1 MFMA, 2 transcendental, 1 VALU (cvt_pk)}; the 12 fragment reads and
+// the 8 row-sum MFMAs are left to the scheduler around that spine
+#ifdef P64_NOHINT
+#define P64_INTERLEAVE(NDS)
+#else
+// interleave hint for one pipelined step: 16 x {1 MFMA, 2 transcendental, 1 VALU (cvt_pk)}; the fragment reads and the
+// row-sum MFMAs are left to the scheduler around that spine.  (A spine that also pins the 12 fragment reads ahead of
+// their MFMAs and lags the cvt_pk by one group made hipcc's solver give up and cluster the MFMAs: measured slower.)
+#define P64_INTERLEAVE(NDS)                                                                              \
+  _Pragma("unroll") for (int g_ = 0; g_ < 16; ++g_) {                                                    \
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                   \
+    __builtin_amdgcn_sched_group_barrier(0x400, 2, 0);                                                   \
+    __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);                                                   \
+  }
+#endif
+
+  const bool tail = (S & (P64_KT - 1)) != 0;
+
+// one tile of the pipelined loop.  FIRST / LAST and the six ring slots are LITERALS: each instantiation is straight-line
+// code (the interleave hints act inside one basic block) and every LDS address is lane base + immediate (runtime slot
+// numbers cost a dozen address registers and push the loop into scratch)
+#define P64_BODY(T, FIRST, LAST, KS0, KS1, KS2, VSM, VS0, VS1)                                           \
+  {                                                                                                      \
+    if ((T) + 2 < nt) dma_k((T) + 2, KS2);                                                               \
+    if ((T) + 1 < nt) dma_v((T) + 1, VS1);                                                               \
+    /* step 0: exp of half (t,0) | S^T of half (t,1) | PV of half (t-1,1) */                              \
+    if ((LAST) && tail) { P64_MASK(T, 0, eA) P64_MASK(T, 0, eB) }                                        \
+    __builtin_amdgcn_sched_barrier(0);                                                                   \
+    P64_QK(KS0, 1, dA, dB)                                                                               \
+    if (!(FIRST)) P64_PV(VSM, 1, pdA, pdB)                                                               \
+    p64_exp_half(eA, peA, laccA);                                                                        \
+    p64_exp_half(eB, peB, laccB);                                                                        \
+    P64_INTERLEAVE((FIRST) ? 4 : 12)                                                                     \
+    __builtin_amdgcn_sched_barrier(0);                                                                   \
+    /* step 1: exp of half (t,1) | S^T of half (t+1,0) | PV of half (t,0) */                              \
+    if ((LAST) && tail) { P64_MASK(T, 1, dA) P64_MASK(T, 1, dB) }                                        \
+    __builtin_amdgcn_sched_barrier(0);                                                                   \
+    if (!(LAST)) P64_QK(KS1, 0, eA, eB)                                                                  \
+    P64_PV(VS0, 0, peA, peB)                                                                             \
+    p64_exp_half(dA, pdA, laccA);                                                                        \
+    p64_exp_half(dB, pdB, laccB);                                                                        \
+    P64_INTERLEAVE((LAST) ? 8 : 12)                                                                      \
+    __builtin_amdgcn_sched_barrier(0);                                                                   \
+    if (!(LAST)) {                                                                                       \
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                   \
+      __syncthreads();                                                                                   \
+    }                                                                                                    \
+  }
+// tile t uses slots: K(t) t%3, K(t+1) (t+1)%3, K(t+2) (t+2)%3; V(t-1) (t+2)%3, V(t) t%3, V(t+1) (t+1)%3
+#define P64_BODY_PH0(T, FIRST, LAST) P64_BODY(T, FIRST, LAST, 0, 1, 2, 2, 0, 1)
+#define P64_BODY_PH1(T, FIRST, LAST) P64_BODY(T, FIRST, LAST, 1, 2, 0, 0, 1, 2)
+#define P64_BODY_PH2(T, FIRST, LAST) P64_BODY(T, FIRST, LAST, 2, 0, 1, 1, 2, 0)
+
+  if (fast) {
+    f32x16 eA, eB, dA, dB;            // scores of the even / odd half-tile in flight (blocks A, B)
+    bf16x8 peA[2], peB[2], pdA[2], pdB[2];
+    P64_QK(0, 0, eA, eB)              // S^T of half (0, 0)
+    if (nt == 1) {
+      P64_BODY_PH0(0, true, true)
+    } else {
+      P64_BODY_PH0(0, true, false)
+      int t = 1;
+      for (; t + 3 <= nt - 1; t += 3) {
+        P64_BODY_PH1(t, false, false)
+        P64_BODY_PH2(t + 1, false, false)
+        P64_BODY_PH0(t + 2, false, false)
+      }
+      if (t < nt - 1) { P64_BODY_PH1(t, false, false) ++t; }
+      if (t < nt - 1) { P64_BODY_PH2(t, false, false) ++t; }
+      const int ph = (nt - 1) % 3;
+      if (ph == 0) P64_BODY_PH0(nt - 1, false, true)
+      else if (ph == 1) P64_BODY_PH1(nt - 1, false, true)
+      else P64_BODY_PH2(nt - 1, false, true)
+    }
+    {                                 // PV of the last half-tile: V(nt-1) sits in slot (nt-1) % 3
+      const int ph = (nt - 1) % 3;
+      if (ph == 0) P64_PV(0, 1, pdA, pdB)
+      else if (ph == 1) P64_PV(1, 1, pdA, pdB)
+      else P64_PV(2, 1, pdA, pdB)
+    }
+  } else {
+    float mA = 0.f, mB = 0.f;
+    int ks0 = 0, ks1 = 1, ks2 = 2;      // ring slots of K(t), K(t+1), K(t+2)
+    int vsm = 2, vs0 = 0, vs1 = 1;      // ring slots of V(t-1), V(t), V(t+1)
+    for (int t = 0; t < nt; ++t) {
+      const bool last = (t == nt - 1);
+      if (t + 2 < nt) dma_k(t + 2, ks2);
+      if (t + 1 < nt) dma_v(t + 1, vs1);
+      f32x16 scA[2], scB[2];
+      bf16x8 pfA[2][2], pfB[2][2];
+      P64_QK(ks0, 0, scA[0], scB[0])
+      P64_QK(ks0, 1, scA[1], scB[1])
+      if (last && tail) { P64_MASK(t, 0, scA[0]) P64_MASK(t, 0, scB[0]) P64_MASK(t, 1, scA[1]) P64_MASK(t, 1, scB[1]) }
+      if (t == 0) {
+        p64_softmax_online<true>(scA, mA, oA, lA, pfA);
+        p64_softmax_online<true>(scB, mB, oB, lB, pfB);
+      } else {
+        p64_softmax_online<false>(scA, mA, oA, lA, pfA);
+        p64_softmax_online<false>(scB, mB, oB, lB, pfB);
+      }
+      P64_PV(vs0, 0, pfA[0], pfB[0])
+      P64_PV(vs0, 1, pfA[1], pfB[1])
+      if (!last) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+      }
+      const int k_ = ks0; ks0 = ks1; ks1 = ks2; ks2 = k_;
+      const int v_ = vsm; vsm = vs0; vs0 = vs1; vs1 = v_;
+    }
+  }
+
+  // finalize both blocks
+#pragma unroll
+  for (int blk = 0; blk < 2; ++blk) {
+    const float lsum = blk ? lB + laccB[0] : lA + laccA[0];
+    const float inv = 1.0f / (lsum + __shfl_xor(lsum, 32, 64));
+    const int row = q0 + 32 * blk + r;
+    if (row < S) {
+      bf16_t* optr = p.o + (long)b * p.o_batch_stride + (long)row * p.o_tok_stride + head * 64;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f32x16& ov = blk ? oB[dt] : oA[dt];
+          u32x2 w;
+          w[0] = pack_bf16x2(ov[4 * g + 0] * inv, ov[4 * g + 1] * inv);
+          w[1] = pack_bf16x2(ov[4 * g + 2] * inv, ov[4 * g + 3] * inv);
+          *(u32x2*)(optr + 32 * dt + 8 * g + 4 * h) = w;
+        }
+    }
+  }
+}
+
+// Called by pi3_attention64_launch (attn64.hip) when the pipelined form is selected.
+int pi3_attention64p_launch(const Attn64Params& p, long nwg, hipStream_t stream) {
+  hipLaunchKernelGGL(attn_fwd64p_kernel, dim3((unsigned)nwg), dim3(512), 0, stream, p);
+  return pi3_check_launch("attn_fwd64p");
+}

@@ -13,7 +13,11 @@
 // S = 64 300 on the same device (round 2): the interleave comes out as written, but hipcc places each fragment read
 // right in front of the MFMA that consumes it, so every wave still stalls a dozen times per step on the LDS round trip
 // and two waves per SIMD do not cover that; prefetching the next step's 12 fragments needs 32 more registers than the
-// 256 this occupancy allows.  Kept behind PI3_ATTN_PIPE=1 as the starting point for a hand-scheduled stream; the
+// 256 this occupancy allows.  Prefetching only the 4 K fragments a step ahead (16 registers, still no scratch in the
+// loop) was built and measured too: 14.65 ms against 14.33 ms of the three-phase kernel on that device, i.e. slower
+// again, so the LDS round trips are not what bounds the loop either; with the clock at 1.9-2.05 GHz of 2.4 under this
+// load the kernel behaves power-limited (a denser stream is paid back in clock, MI355X_MICROARCH.md DVFS give-back).
+// Kept behind PI3_ATTN_PIPE=1 as the starting point for a hand-scheduled stream; the
 // three-phase kernel stays the default.  Register cost is unchanged: two score
 // half-tiles (even / odd) and two packed probability half-tiles are live, exactly the 64 + 32 registers the unpipelined
 // loop holds; every K and V^T fragment still feeds both query blocks.

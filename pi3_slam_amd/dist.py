@@ -26,8 +26,8 @@ def ensure_process_group() -> Tuple[int, int]:
     if dist.is_available() and dist.is_initialized():
         return dist.get_rank(), dist.get_world_size()
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world <= 1:
-        return 0, 1
+    if world <= 1 and os.environ.get("PI3_DIST_FORCE") != "1":
+        return 0, 1          # PI3_DIST_FORCE=1: build the group anyway (a 1-rank RCCL group exercises the nccl branch)
     backend = os.environ.get("PI3_DIST_BACKEND", "nccl" if torch.cuda.is_available() else "gloo")
     if backend == "nccl":
         dev = torch.device("cuda", local_device_index())

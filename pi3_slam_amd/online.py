@@ -175,7 +175,8 @@ class Pi3SLAMOnline:
         stages of consecutive chunks overlap on streams instead of processes."""
         self._creator.target_size = calculate_target_size(image_paths[0], pixel_limit=self.pixel_limit)
         ds = ChunkImageDataset(image_paths, self.chunk_length, self.overlap, self._creator.target_size, decode_only=True)
-        if self.world > 1:
+        import torch.distributed as _dist
+        if self.world > 1 or (_dist.is_available() and _dist.is_initialized()):
             return self._process_chunks_distributed(ds)
         results, t_start, frames_before = [], time.time(), len(self.timestamps)
         for meta, chunk in self._creator.process_chunks(self._items(ds, list(range(len(ds))))):

@@ -127,7 +127,8 @@ class OfflineReconstructor:
     def run(self) -> None:
         from .dist import ensure_process_group
         rank, world = ensure_process_group()
-        if world > 1:
+        import torch.distributed as _dist
+        if world > 1 or (_dist.is_available() and _dist.is_initialized()):
             self._run_distributed(rank, world)
             return
         chunk_files = self._load_chunks()

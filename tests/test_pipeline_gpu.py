@@ -259,6 +259,35 @@ def test_two_rank_pipeline_matches_single_process(tmp_path, built_lib):
     assert np.abs(o1[:, 1:4] - t1[:, 1:4]).max() / scale < 1e-4      # and the online flow equals the offline one
 
 
+def test_rccl_branch_with_a_one_rank_group(tmp_path, built_lib):
+    """The nccl (= RCCL) branch of the chunk-parallel code on the hardware that is available: ONE rank on this box's GPU
+    (two ranks cannot share a card under RCCL).  Device-resident boundary blocks, all-gathers of device tensors,
+    process-group device binding (init_process_group(device_id=...)), 'cuda' -> cuda:LOCAL_RANK resolution: the wave
+    alignment must reproduce the sequential run."""
+    import subprocess
+    import sys
+    frames = tmp_path / "frames"
+    frames.mkdir()
+    _write_frames(str(frames))
+    worker = os.path.join(os.path.dirname(__file__), "dist_pipeline_worker.py")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "PI3_DIST_BACKEND", "PI3_DIST_FORCE"):
+        env.pop(k, None)
+    r1 = subprocess.run([sys.executable, worker, str(frames), str(tmp_path / "o1"), str(tmp_path / "r1")], env=env,
+                        capture_output=True, text=True, timeout=300)
+    assert r1.returncode == 0, r1.stdout[-2000:] + r1.stderr[-2000:]
+    env2 = dict(env, PI3_DIST_BACKEND="nccl", PI3_DIST_FORCE="1")
+    r2 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                         "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), worker, str(frames),
+                         str(tmp_path / "o2"), str(tmp_path / "r2")], env=env2, capture_output=True, text=True, timeout=300)
+    assert r2.returncode == 0, r2.stdout[-3000:] + r2.stderr[-3000:]
+    assert "on 1 ranks" in r2.stdout                              # the distributed code path ran
+    t1 = np.loadtxt(tmp_path / "r1" / "trajectory_tum.txt")
+    t2 = np.loadtxt(tmp_path / "r2" / "trajectory_tum.txt")
+    assert t1.shape == t2.shape == (32, 8)
+    assert np.abs(t1[:, 1:] - t2[:, 1:]).max() < 1e-4
+
+
 def test_cli_entry_points_full_model(tmp_path, built_lib):
     """python -m pi3_slam_amd.cli create / reconstruct with the reference's flags, full-size pi3
     (recipe weights) + recipe MoGe, undistortion off, 10 frames."""

@@ -161,9 +161,15 @@ long pi3_groupnorm_ws_doubles(int B, int HW, int C);
 int pi3_groupnorm_stats(const float* x, long ldx, int B, int HW, int C, int G, double* stats, double* ws,
                         long ws_doubles, void* stream);
 
-/* GroupNorm affine + activation (0 none, 2 ReLU) -> bf16 NHWC staging image [B][HW][ldo], channels [C, Cpad) zeroed. */
+/* Norm + activation in front of a ResidualConvBlock convolution (moge/model/modules.py:47-58) -> bf16 NHWC staging
+ * image [B][HW][ldo], channels [C, Cpad) zeroed.  G groups (GroupNorm(C/32), 'layer_norm' = 1 group, InstanceNorm2d =
+ * C groups with gamma = beta = NULL); G = 0: no normalisation ('none').  act: 0 none, 2 ReLU, 3 LeakyReLU(0.2),
+ * 4 SiLU, 5 ELU. */
 int pi3_groupnorm_apply(const float* x, long ldx, int B, int HW, int C, int Cpad, int G, const double* stats,
                         const float* gamma, const float* beta, float eps, int act, void* out, long ldo, void* stream);
+
+/* x[r][0..C) += y[r][0..C) on fp32 maps: ConvStack with an identity input block (modules.py:245-249). */
+int pi3_add_rows(float* x, long ldx, const float* y, long ldy, long rows, int C, void* stream);
 
 /* ConvTranspose2d(k=2, s=2) scatter: g f32 [B*H*W][(dy*2+dx)*Cs + co] -> bf16 NHWC [B][2H][2W][ldo]. */
 int pi3_convt_scatter(const float* g, long ldg, int B, int H, int W, int Cout, int Cs, int Cpad, void* out, long ldo,

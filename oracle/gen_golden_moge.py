@@ -31,6 +31,44 @@ CASES = {  # name: (H, W, resolution_level)
     "moge_pinhole_chunk": (308, 406, 9),
 }
 
+
+
+def _variant(**stack_overrides):
+    import copy
+    cfg = copy.deepcopy(SYNTHETIC_CONFIG)
+    for head in ("neck", "points_head", "mask_head"):
+        for k, v in stack_overrides.items():
+            if not k.startswith("_"):
+                cfg[head][k] = copy.deepcopy(v)
+    for k, v in stack_overrides.get("_per_head", {}).items():
+        head, key = k.split(".")
+        cfg[head][key] = copy.deepcopy(v)
+    return cfg
+
+
+# the rest of the ConvStack config space of moge/model/modules.py:139-254 (the released checkpoint's model_config is
+# unknown offline: whatever it says must load), one fixture per family, vectors from the real MoGeModel class
+VARIANT_CONFIGS = {
+    # pixel-shuffle resamplers, SiLU, hidden width x2, no input norm, instance norm inside the block
+    "moge_var_pixelshuffle": _variant(resamplers=["pixel_shuffle"] * 4, activation="silu", dim_times_res_block_hidden=2,
+                                      res_block_in_norm="none", res_block_hidden_norm="instance_norm"),
+    # interpolating resamplers, LeakyReLU, group / layer norms swapped, two res blocks per level, identity input blocks
+    # in the points head where the widths agree and an identity output block on the neck's finest level
+    "moge_var_interp": _variant(resamplers=["bilinear", "nearest", "bilinear", "nearest"], activation="leaky_relu",
+                                res_block_in_norm="group_norm", res_block_hidden_norm="layer_norm", num_res_blocks=2,
+                                _per_head={"neck.dim_out": [256, 128, 64, 32, None],
+                                           "points_head.dim_in": [256, 128, 64, None, None]}),
+    # ELU, instance norm in front, no norm inside, transposed convolutions
+    "moge_var_elu": _variant(activation="elu", res_block_in_norm="instance_norm", res_block_hidden_norm="none"),
+}
+for _n in VARIANT_CONFIGS:
+    CASES[_n] = (84, 112, 0)
+
+
+def case_config(name: str):
+    return VARIANT_CONFIGS.get(name, SYNTHETIC_CONFIG)
+
+
 PINHOLE = dict(A=6.0, f0=0.9, b=0.5, c=-0.4, d=0.3, noise=0.25)
 
 
@@ -74,7 +112,7 @@ def pinhole_overrides(sd):
 
 
 def case_state_dict(name: str):
-    sd = recipe_state_dict_cpu(SYNTHETIC_CONFIG)
+    sd = recipe_state_dict_cpu(case_config(name))
     return pinhole_overrides(sd) if "pinhole" in name else sd
 
 
@@ -118,22 +156,23 @@ def main() -> None:
     from moge.model.v2 import MoGeModel
     from oracle import moge_ref
 
-    model = MoGeModel(**SYNTHETIC_CONFIG).eval()
     out_dir = os.path.join(REPO, "tests", "golden")
     only = sys.argv[1:]
     for name, (H, W, level) in CASES.items():
         if only and name not in only:
             continue
+        CFG = case_config(name)
+        model = MoGeModel(**CFG).eval()
         sd = case_state_dict(name)
         missing, unexpected = model.load_state_dict(sd, strict=False)
         assert not missing and not unexpected, (missing, unexpected)
         img = moge_image(name, H, W)
         ref = model.infer(img, resolution_level=level, use_fp16=False)
-        lo, hi = SYNTHETIC_CONFIG["num_tokens_range"]
+        lo, hi = CFG["num_tokens_range"]
         ntok = int(lo + (level / 9) * (hi - lo))
         with torch.no_grad():
             fwd = model.forward(img[None], num_tokens=ntok)
-        orc = moge_ref.moge_infer(sd, SYNTHETIC_CONFIG, img, level)
+        orc = moge_ref.moge_infer(sd, CFG, img, level)
         m = ref["mask"]
         print(f"{name}: mask frac {m.float().mean().item():.3f}  depth median {ref['depth'][m].median().item():.4f}  "
               f"metric_scale {fwd['metric_scale'].item():.4f}")

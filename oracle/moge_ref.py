@@ -99,6 +99,22 @@ def _norm(sd, key, x, kind):
         return F.group_norm(x, C // 32, sd[key + ".weight"], sd[key + ".bias"], 1e-5)
     if kind == "layer_norm":
         return F.group_norm(x, 1, sd[key + ".weight"], sd[key + ".bias"], 1e-5)
+    if kind == "instance_norm":      # nn.InstanceNorm2d(C): no affine parameters, eps 1e-5
+        return F.instance_norm(x, eps=1e-5)
+    if kind == "none":
+        return x
+    raise NotImplementedError(kind)
+
+
+def _act(x, kind):
+    if kind == "relu":
+        return F.relu(x)
+    if kind == "leaky_relu":
+        return F.leaky_relu(x, 0.2)
+    if kind == "silu":
+        return F.silu(x)
+    if kind == "elu":
+        return F.elu(x)
     raise NotImplementedError(kind)
 
 
@@ -106,12 +122,24 @@ def conv3(sd, key, x):
     return F.conv2d(F.pad(x, (1, 1, 1, 1), mode="replicate"), sd[key + ".weight"], sd[key + ".bias"])
 
 
+def resample(sd, p, kind, x):
+    """Resampler (modules.py:139-182), scale factor 2, the four up-sampling kinds."""
+    if kind == "conv_transpose":
+        return conv3(sd, p + ".1", F.conv_transpose2d(x, sd[p + ".0.weight"], sd[p + ".0.bias"], stride=2))
+    if kind == "pixel_shuffle":
+        return conv3(sd, p + ".2", F.pixel_shuffle(conv3(sd, p + ".0", x), 2))
+    if kind in ("nearest", "bilinear"):
+        up = F.interpolate(x, scale_factor=2, mode=kind, align_corners=False if kind == "bilinear" else None)
+        return conv3(sd, p + ".1", up)
+    raise NotImplementedError(kind)
+
+
 def conv_stack(sd, name, cfg, in_features: List[Optional[torch.Tensor]]):
     """ConvStack.forward (modules.py:242-254) with ResidualConvBlock (:18-68) and Resampler (:139-182)."""
     dims = cfg["dim_res_blocks"]
     nres = cfg.get("num_res_blocks", 1)
     in_norm, hid_norm = cfg.get("res_block_in_norm", "layer_norm"), cfg.get("res_block_hidden_norm", "group_norm")
-    assert cfg.get("activation", "relu") == "relu" and cfg.get("dim_times_res_block_hidden", 1) == 1
+    act = cfg.get("activation", "relu")
     dim_in = cfg["dim_in"] if isinstance(cfg["dim_in"], (list, tuple)) else [cfg["dim_in"]] * len(dims)
     dim_out = cfg["dim_out"] if isinstance(cfg["dim_out"], (list, tuple)) else [cfg["dim_out"]] * len(dims)
     res = cfg["resamplers"] if isinstance(cfg["resamplers"], (list, tuple)) else [cfg["resamplers"]] * (len(dims) - 1)
@@ -124,18 +152,15 @@ def conv_stack(sd, name, cfg, in_features: List[Optional[torch.Tensor]]):
         x = feat if i == 0 else (x + feat if feat is not None else x)
         for j in range(nres[i] if isinstance(nres, list) else nres):
             p = f"{name}.res_blocks.{i}.{j}.layers"
-            h = conv3(sd, p + ".2", F.relu(_norm(sd, p + ".0", x, in_norm)))
-            h = conv3(sd, p + ".5", F.relu(_norm(sd, p + ".3", h, hid_norm)))
+            h = conv3(sd, p + ".2", _act(_norm(sd, p + ".0", x, in_norm), act))
+            h = conv3(sd, p + ".5", _act(_norm(sd, p + ".3", h, hid_norm), act))
             x = x + h
         o = x
         if dim_out[i] is not None:
             o = F.conv2d(x, sd[f"{name}.output_blocks.{i}.weight"], sd[f"{name}.output_blocks.{i}.bias"])
         outs.append(o)
         if i < len(dims) - 1:
-            assert res[i] == "conv_transpose", "only the conv_transpose resampler is restated"
-            p = f"{name}.resamplers.{i}"
-            x = F.conv_transpose2d(x, sd[p + ".0.weight"], sd[p + ".0.bias"], stride=2)
-            x = conv3(sd, p + ".1", x)
+            x = resample(sd, f"{name}.resamplers.{i}", res[i], x)
     return outs
 
 

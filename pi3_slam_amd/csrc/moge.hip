@@ -143,13 +143,25 @@ extern "C" int pi3_groupnorm_stats(const float* x, long ldx, int B, int HW, int 
 }
 
 // y = act((x - mean_g) * rstd_g * gamma_c + beta_c) -> bf16 NHWC staging image [B][HW][ldo], channels [C, Cpad) = 0.
-// act: 0 none, 2 ReLU (same codes as pi3_gemm).  eps = 1e-5 (nn.GroupNorm default).
+// act (modules.py:36-45): 0 none, 2 ReLU (same codes as pi3_gemm), 3 LeakyReLU(0.2), 4 SiLU, 5 ELU(1).
+// eps = 1e-5 (nn.GroupNorm / nn.InstanceNorm2d default).  gamma / beta may be null (InstanceNorm2d has no affine
+// parameters: G = C); G == 0 means no normalisation at all (in_norm 'none': y = act(x), stats unused).
+__device__ __forceinline__ float moge_act(float v, int act) {
+  switch (act) {
+    case 2: return fmaxf(v, 0.f);
+    case 3: return v >= 0.f ? v : 0.2f * v;
+    case 4: return v / (1.0f + __expf(-v));
+    case 5: return v > 0.f ? v : expm1f(v);
+    default: return v;
+  }
+}
+
 __global__ __launch_bounds__(256) void groupnorm_apply_kernel(const float* __restrict__ x, long ldx, int HW, int C,
                                                               int Cpad, int G, const double* __restrict__ stats,
                                                               const float* __restrict__ gamma,
                                                               const float* __restrict__ beta, float eps, int act,
                                                               bf16_t* __restrict__ out, long ldo, long total) {
-  const int cpg = C / G;
+  const int cpg = G > 0 ? C / G : C;
   const int cv = Cpad >> 1;  // two channels per thread
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
     const int c = (int)(i % cv) * 2;
@@ -160,14 +172,17 @@ __global__ __launch_bounds__(256) void groupnorm_apply_kernel(const float* __res
     for (int e = 0; e < 2; ++e) {
       const int cc = c + e;
       if (cc < C) {
-        const int g = cc / cpg;
-        const double n = (double)cpg * (double)HW;
-        const double mean = stats[((long)b * G + g) * 2] / n;
-        const double var = stats[((long)b * G + g) * 2 + 1] / n - mean * mean;
-        const float rstd = (float)(1.0 / sqrt((var > 0.0 ? var : 0.0) + (double)eps));
-        float v = (x[bp * ldx + cc] - (float)mean) * rstd * gamma[cc] + beta[cc];
-        if (act == 2) v = fmaxf(v, 0.f);
-        y[e] = v;
+        float v = x[bp * ldx + cc];
+        if (G > 0) {
+          const int g = cc / cpg;
+          const double n = (double)cpg * (double)HW;
+          const double mean = stats[((long)b * G + g) * 2] / n;
+          const double var = stats[((long)b * G + g) * 2 + 1] / n - mean * mean;
+          const float rstd = (float)(1.0 / sqrt((var > 0.0 ? var : 0.0) + (double)eps));
+          v = (v - (float)mean) * rstd;
+          if (gamma) v = v * gamma[cc] + beta[cc];
+        }
+        y[e] = moge_act(v, act);
       } else {
         y[e] = 0.f;
       }
@@ -176,11 +191,34 @@ __global__ __launch_bounds__(256) void groupnorm_apply_kernel(const float* __res
   }
 }
 
+// x[r][c] += y[r][c] on fp32 maps (ConvStack with an identity input block: x = x + feature, modules.py:245-249)
+__global__ __launch_bounds__(256) void add_rows_kernel(float* __restrict__ x, long ldx, const float* __restrict__ y,
+                                                       long ldy, long rows, int C) {
+  const long total = rows * C;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long r = i / C;
+    const int c = (int)(i - r * C);
+    x[r * ldx + c] += y[r * ldy + c];
+  }
+}
+
+extern "C" int pi3_add_rows(float* x, long ldx, const float* y, long ldy, long rows, int C, void* stream) {
+  if (!x || !y || rows <= 0 || C <= 0) {
+    pi3_set_error("pi3_add_rows: bad arguments");
+    return PI3_ERR_ARG;
+  }
+  long blocks = (rows * C + 255) / 256;
+  if (blocks > 256 * 32) blocks = 256 * 32;
+  hipLaunchKernelGGL(add_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy, rows, C);
+  return pi3_check_launch("add_rows");
+}
+
 extern "C" int pi3_groupnorm_apply(const float* x, long ldx, int B, int HW, int C, int Cpad, int G,
                                    const double* stats, const float* gamma, const float* beta, float eps, int act,
                                    void* out, long ldo, void* stream) {
-  if (!x || !stats || !gamma || !beta || !out || C <= 0 || Cpad < C || (Cpad % 2) || (ldo % 2) || (C % G)) {
-    pi3_set_error("pi3_groupnorm_apply: bad arguments");
+  if (!x || (G > 0 && !stats) || ((gamma != nullptr) != (beta != nullptr)) || !out || C <= 0 || Cpad < C ||
+      (Cpad % 2) || (ldo % 2) || G < 0 || (G > 0 && (C % G)) || act < 0 || act > 5 || act == 1) {
+    pi3_set_error("pi3_groupnorm_apply: bad arguments C=%d G=%d act=%d", C, G, act);
     return PI3_ERR_ARG;
   }
   const long total = (long)B * HW * (Cpad / 2);

@@ -39,6 +39,7 @@ SIGNATURES = {
     "pi3_conv3x3": [_vp, _l, _i, _i, _i, _i, _vp, _i, _vp, _vp, _l, _vp, _l, _i, _i, _vp],
     "pi3_groupnorm_stats": [_vp, _l, _i, _i, _i, _i, _vp, _vp, _l, _vp],
     "pi3_groupnorm_apply": [_vp, _l, _i, _i, _i, _i, _i, _vp, _vp, _vp, _f, _i, _vp, _l, _vp],
+    "pi3_add_rows": [_vp, _l, _vp, _l, _l, _i, _vp],
     "pi3_convt_scatter": [_vp, _l, _i, _i, _i, _i, _i, _i, _vp, _l, _vp],
     "pi3_uv_affine": [_vp, _l, _i, _i, _i, _i, _vp, _l, _i, _vp, _vp, _vp, _i, _vp],
     "pi3_resize_taps": [_vp, _l, _l, _l, _i, _vp, _vp, _vp, _vp, _i, _i, _vp, _l, _l, _l, _vp],

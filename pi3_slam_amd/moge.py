@@ -7,8 +7,11 @@ Mirror of MoGeModel.from_pretrained / infer (moge/model/v2.py:66-97, 181-290) dr
 GroupNorm / transposed-conv scatter / UV planes / resizes / remap in csrc/moge.hip, focal-shift recovery in the same LM
 kernel as the pi3 intrinsics.  Activations: NHWC fp32 [H*W, ld] + bf16 NHWC staging images (channel stride % 64 == 0).
 
-Supported config space: conv_transpose resamplers, relu activation, layer_norm / group_norm res-block norms,
-dim_times_res_block_hidden == 1 (everything else raises NotImplementedError at construction).  The released
+Supported config space (moge/model/modules.py:18-254, every option an UP-sampling ConvStack can carry): resamplers
+conv_transpose / pixel_shuffle / nearest / bilinear; activations relu / leaky_relu / silu / elu; res-block norms
+group_norm / layer_norm / instance_norm / none; dim_times_res_block_hidden >= 1; identity input and output blocks.  The
+down-sampling resamplers (pixel_unshuffle / avg_pool / max_pool) cannot occur in the 5-level up-sampling pyramid of
+MoGeModel.forward (v2.py:141-150) and raise NotImplementedError at construction.  The released
 "Ruicheng/moge-2-vits-normal" checkpoint (weights and config) is not available offline; `from_pretrained("recipe")`
 builds SYNTHETIC_CONFIG with recipe weights, and a local model.pt ({'model_config', 'model'}) is loaded as the reference
 does (v2.py:80-95).  The reference runs this forward under fp16 autocast; here matmuls are bf16 MFMA with fp32
@@ -59,6 +62,25 @@ def _up(x, m):
     return (x + m - 1) // m * m
 
 
+ACTS = {"relu": 2, "leaky_relu": 3, "silu": 4, "elu": 5}          # ops.ACT_* codes of pi3_groupnorm_apply
+NORMS = ("group_norm", "layer_norm", "instance_norm", "none")
+UPSAMPLERS = ("conv_transpose", "pixel_shuffle", "nearest", "bilinear")
+
+
+def _stack_options(cfg: Dict):
+    act = cfg.get("activation", "relu")
+    in_norm, hid_norm = cfg.get("res_block_in_norm", "layer_norm"), cfg.get("res_block_hidden_norm", "group_norm")
+    mult = int(cfg.get("dim_times_res_block_hidden", 1))
+    if act not in ACTS:
+        raise NotImplementedError(f"activation '{act}' is not defined by the reference (modules.py:36-45)")
+    for k in (in_norm, hid_norm):
+        if k not in NORMS:
+            raise NotImplementedError(f"norm '{k}' is not defined by the reference (modules.py:47-56)")
+    if mult < 1:
+        raise NotImplementedError("dim_times_res_block_hidden must be >= 1")
+    return act, in_norm, hid_norm, mult
+
+
 def stack_shapes(name: str, cfg: Dict) -> Dict[str, tuple]:
     """state_dict entries of one ConvStack (moge/model/modules.py:195-240)."""
     dims = cfg["dim_res_blocks"]
@@ -66,33 +88,35 @@ def stack_shapes(name: str, cfg: Dict) -> Dict[str, tuple]:
     dim_in, dim_out = _lst(cfg["dim_in"], n), _lst(cfg["dim_out"], n)
     res = _lst(cfg["resamplers"], n - 1)
     nres = cfg.get("num_res_blocks", 1)
-    if cfg.get("activation", "relu") != "relu" or cfg.get("dim_times_res_block_hidden", 1) != 1:
-        raise NotImplementedError("only relu / hidden multiplier 1 ConvStacks are built")
+    _, in_norm, hid_norm, mult = _stack_options(cfg)
     for r in res:
-        if r != "conv_transpose":
-            raise NotImplementedError(f"resampler '{r}' is not built (conv_transpose only)")
-    for k in (cfg.get("res_block_in_norm", "layer_norm"), cfg.get("res_block_hidden_norm", "group_norm")):
-        if k not in ("layer_norm", "group_norm"):
-            raise NotImplementedError(f"norm '{k}' is not built")
+        if r not in UPSAMPLERS:
+            raise NotImplementedError(f"resampler '{r}' does not up-sample: it cannot occur in MoGeModel's pyramid")
     out: Dict[str, tuple] = {}
     for i in range(n):
         if dim_in[i] is not None:
             out[f"{name}.input_blocks.{i}.weight"] = (dims[i], dim_in[i], 1, 1)
             out[f"{name}.input_blocks.{i}.bias"] = (dims[i],)
     for i in range(n - 1):
-        out[f"{name}.resamplers.{i}.0.weight"] = (dims[i], dims[i + 1], 2, 2)
-        out[f"{name}.resamplers.{i}.0.bias"] = (dims[i + 1],)
-        out[f"{name}.resamplers.{i}.1.weight"] = (dims[i + 1], dims[i + 1], 3, 3)
-        out[f"{name}.resamplers.{i}.1.bias"] = (dims[i + 1],)
+        p, C, Cn = f"{name}.resamplers.{i}", dims[i], dims[i + 1]
+        if res[i] == "conv_transpose":      # ConvTranspose2d(C, Cn, 2, 2) ; Conv2d(Cn, Cn, 3)      (modules.py:159-164)
+            out[f"{p}.0.weight"], out[f"{p}.0.bias"] = (C, Cn, 2, 2), (Cn,)
+            out[f"{p}.1.weight"], out[f"{p}.1.bias"] = (Cn, Cn, 3, 3), (Cn,)
+        elif res[i] == "pixel_shuffle":     # Conv2d(C, 4 Cn, 3) ; PixelShuffle(2) ; Conv2d(Cn, Cn, 3)  (:146-153)
+            out[f"{p}.0.weight"], out[f"{p}.0.bias"] = (4 * Cn, C, 3, 3), (4 * Cn,)
+            out[f"{p}.2.weight"], out[f"{p}.2.bias"] = (Cn, Cn, 3, 3), (Cn,)
+        else:                               # Upsample(2, nearest | bilinear) ; Conv2d(C, Cn, 3)        (:154-158)
+            out[f"{p}.1.weight"], out[f"{p}.1.bias"] = (Cn, C, 3, 3), (Cn,)
     for i in range(n):
+        hid = mult * dims[i]
         for j in range(nres[i] if isinstance(nres, list) else nres):
             p = f"{name}.res_blocks.{i}.{j}.layers"
-            for l in (0, 3):
-                out[f"{p}.{l}.weight"] = (dims[i],)
-                out[f"{p}.{l}.bias"] = (dims[i],)
-            for l in (2, 5):
-                out[f"{p}.{l}.weight"] = (dims[i], dims[i], 3, 3)
-                out[f"{p}.{l}.bias"] = (dims[i],)
+            if in_norm in ("group_norm", "layer_norm"):
+                out[f"{p}.0.weight"], out[f"{p}.0.bias"] = (dims[i],), (dims[i],)
+            if hid_norm in ("group_norm", "layer_norm"):
+                out[f"{p}.3.weight"], out[f"{p}.3.bias"] = (hid,), (hid,)
+            out[f"{p}.2.weight"], out[f"{p}.2.bias"] = (hid, dims[i], 3, 3), (hid,)
+            out[f"{p}.5.weight"], out[f"{p}.5.bias"] = (dims[i], hid, 3, 3), (dims[i],)
     for i in range(n):
         if dim_out[i] is not None:
             out[f"{name}.output_blocks.{i}.weight"] = (dim_out[i], dims[i], 1, 1)
@@ -149,7 +173,7 @@ def moge_recipe_params(name: str, shape) -> tuple:
             else (0.0, 0.02)
     if len(shape) == 1:
         return 1.0, 0.1
-    if ".resamplers." in name and name.endswith(".0.weight"):
+    if ".resamplers." in name and name.endswith(".0.weight") and shape[2] == 2:
         fan_in = shape[0]                       # ConvTranspose2d weight is [in, out, kh, kw]
     else:
         fan_in = int(np.prod(shape[1:]))
@@ -241,6 +265,15 @@ class MoGeEngine:
         self.bb = BACKBONES[cfg["encoder"]["backbone"]]
         self.w: Dict[str, torch.Tensor] = {}
         shapes = moge_param_shapes(cfg)
+        # first convolution of a pixel_shuffle resampler: its output channels are stored (dy, dx, co)-major so that the
+        # PixelShuffle is the same scatter as the transposed convolution's (csrc/moge.hip: pi3_convt_scatter)
+        self._ps_convs = set()
+        for head in ("neck", "points_head", "mask_head", "normal_head"):
+            if cfg.get(head):
+                n = len(cfg[head]["dim_res_blocks"])
+                for i, r in enumerate(_lst(cfg[head]["resamplers"], n - 1)):
+                    if r == "pixel_shuffle":
+                        self._ps_convs.add(f"{head}.resamplers.{i}.0")
         for name, shape in shapes.items():
             if state_dict is None:
                 off, sc = moge_recipe_params(name, shape)
@@ -272,6 +305,9 @@ class MoGeEngine:
         elif ".backbone.blocks." in name and name.endswith(("qkv.weight", "proj.weight", "fc1.weight", "fc2.weight")):
             self.w[name] = t.to(bf).contiguous()
         elif t.dim() == 4 and t.shape[2] == 3:            # 3x3 conv [Co, Ci, 3, 3] -> [Co_pad128, 3*3*Ci_pad64]
+            if name.rsplit(".", 1)[0] in self._ps_convs:  # PixelShuffle(2): channel co*4 + q -> row q*Cn + co
+                Cn = t.shape[0] // 4
+                t = t.reshape(Cn, 4, *t.shape[1:]).transpose(0, 1).reshape(4 * Cn, *t.shape[1:])
             Co, Ci = t.shape[:2]
             w = torch.zeros(_up(Co, 128), 3, 3, _up(Ci, 64), device=dev, dtype=bf)
             w[:Co, :, :, :Ci] = t.permute(0, 2, 3, 1).to(bf)
@@ -288,15 +324,19 @@ class MoGeEngine:
             w = torch.zeros(_up(Co, 128), _up(Ci, 64), device=dev, dtype=bf)
             w[:Co, :Ci] = t.reshape(Co, Ci).to(bf)
             self.w[name] = w.contiguous()
+        elif ".resamplers." in name and name.endswith(".0.bias") and name.rsplit(".", 1)[0] in self._ps_convs:
+            Cn = t.shape[0] // 4
+            self.w[name] = t.reshape(Cn, 4).t().reshape(-1).contiguous()      # (dy, dx, co)-major like the weight rows
+        elif ".resamplers." in name and name.endswith(".0.bias") and (name.rsplit(".", 1)[0] + ".weight") in self.w \
+                and self.w[name.rsplit(".", 1)[0] + ".weight"].shape[0] == 4 * t.shape[0]:
+            self.w[name] = t.repeat(4).contiguous()       # ConvTranspose2d: one bias per output channel, per (dy, dx)
         elif name.endswith(".bias") and (".input_blocks." in name or ".output_blocks." in name
                                          or ".res_blocks." in name and name.split(".")[-2] in ("2", "5")
-                                         or ".resamplers." in name and name.endswith(".1.bias")
+                                         or ".resamplers." in name
                                          or name.startswith("encoder.output_projections")):
             b = torch.zeros(_up(t.shape[0], 128), device=dev)
             b[: t.shape[0]] = t
             self.w[name] = b
-        elif ".resamplers." in name and name.endswith(".0.bias"):
-            self.w[name] = t.repeat(4).contiguous()       # bias per (dy, dx, co)
         else:
             self.w[name] = t.contiguous()
 
@@ -330,31 +370,85 @@ class MoGeEngine:
         return self._consts[key]
 
     # ------------------------------------------------------------------ ConvStack (modules.py:242-254)
-    def _res_block(self, p: str, x: _Act, in_norm: str, hid_norm: str) -> None:
-        HW, C = x.H * x.W, x.C
+    def _norm_act(self, src: _Act, key: str, norm: str, act: int) -> torch.Tensor:
+        """norm + activation of a map -> bf16 NHWC staging image for the following 3x3 convolution."""
+        HW, C = src.H * src.W, src.C
         Cp = _up(C, 64)
-        for (nk, ck, norm, last) in ((f"{p}.0", f"{p}.2", in_norm, False), (f"{p}.3", f"{p}.5", hid_norm, True)):
-            src = x if not last else h
-            G = C // 32 if norm == "group_norm" else 1
-            stats = torch.empty(2 * G, device=self.device, dtype=torch.float64)
-            ops.groupnorm_stats(src.t, HW, C, G, stats)
-            a = self._new(HW, Cp, torch.bfloat16)
-            ops.groupnorm_apply(src.t, HW, C, Cp, G, stats, self.w[nk + ".weight"], self.w[nk + ".bias"], 1e-5,
-                                ops.ACT_RELU, a)
-            if not last:
-                h = _Act(self._new(HW, _up(C, 128)), C, x.H, x.W)
-                ops.conv3x3(a, x.H, x.W, Cp, self.w[ck + ".weight"], self.w[ck + ".bias"], h.t)
-            else:
-                ops.conv3x3(a, x.H, x.W, Cp, self.w[ck + ".weight"], self.w[ck + ".bias"], x.t, resid=x.t)
+        a = self._new(HW, Cp, torch.bfloat16)
+        if norm == "none":
+            ops.groupnorm_apply(src.t, HW, C, Cp, 0, None, None, None, 1e-5, act, a)
+            return a
+        G = {"group_norm": C // 32, "layer_norm": 1, "instance_norm": C}[norm]
+        stats = torch.empty(2 * G, device=self.device, dtype=torch.float64)
+        ops.groupnorm_stats(src.t, HW, C, G, stats)
+        affine = norm != "instance_norm"          # nn.InstanceNorm2d(C): affine=False, no parameters
+        ops.groupnorm_apply(src.t, HW, C, Cp, G, stats, self.w[key + ".weight"] if affine else None,
+                            self.w[key + ".bias"] if affine else None, 1e-5, act, a)
+        return a
+
+    def _res_block(self, p: str, x: _Act, in_norm: str, hid_norm: str, act: int, mult: int) -> None:
+        """ResidualConvBlock (modules.py:18-68) with in == out channels: x += conv(act(norm(conv(act(norm(x))))))."""
+        C, hid = x.C, mult * x.C
+        a = self._norm_act(x, f"{p}.0", in_norm, act)
+        h = _Act(self._new(x.H * x.W, _up(hid, 128)), hid, x.H, x.W)
+        ops.conv3x3(a, x.H, x.W, _up(C, 64), self.w[f"{p}.2.weight"], self.w[f"{p}.2.bias"], h.t)
+        a = self._norm_act(h, f"{p}.3", hid_norm, act)
+        ops.conv3x3(a, x.H, x.W, _up(hid, 64), self.w[f"{p}.5.weight"], self.w[f"{p}.5.bias"], x.t, resid=x.t)
+
+    def _resample(self, p: str, kind: str, x: _Act, Cn: int) -> _Act:
+        """Resampler (modules.py:139-182), scale factor 2."""
+        H, W, C = x.H, x.W, x.C
+        if kind == "conv_transpose":          # ConvTranspose2d(k = s = 2) as a GEMM + scatter, then Conv2d 3x3
+            g = self._new(H * W, 4 * Cn)
+            ops.gemm(self._to_bf16(x), self.w[p + ".0.weight"], g, M=H * W, bias=self.w[p + ".0.bias"])
+            up = self._new(4 * H * W, _up(Cn, 64), torch.bfloat16)
+            ops.convt_scatter(g, H, W, Cn, Cn, _up(Cn, 64), up)
+            out = _Act(self._new(4 * H * W, _up(Cn, 128)), Cn, 2 * H, 2 * W)
+            ops.conv3x3(up, 2 * H, 2 * W, _up(Cn, 64), self.w[p + ".1.weight"], self.w[p + ".1.bias"], out.t)
+            return out
+        if kind == "pixel_shuffle":           # Conv2d(C, 4 Cn, 3) with (dy, dx, co)-major rows + the same scatter
+            g = self._new(H * W, _up(4 * Cn, 128))
+            ops.conv3x3(self._to_bf16(x), H, W, _up(C, 64), self.w[p + ".0.weight"], self.w[p + ".0.bias"], g)
+            up = self._new(4 * H * W, _up(Cn, 64), torch.bfloat16)
+            ops.convt_scatter(g, H, W, Cn, Cn, _up(Cn, 64), up)
+            out = _Act(self._new(4 * H * W, _up(Cn, 128)), Cn, 2 * H, 2 * W)
+            ops.conv3x3(up, 2 * H, 2 * W, _up(Cn, 64), self.w[p + ".2.weight"], self.w[p + ".2.bias"], out.t)
+            return out
+        # nn.Upsample(scale_factor=2, mode=nearest | bilinear(align_corners=False)) then Conv2d(C, Cn, 3)
+        key = ("up2", kind, H, W)
+        if key not in self._consts:
+            def taps(n_in):
+                if kind == "bilinear":
+                    sc, wt = linear_taps(n_in, 2 * n_in, False)
+                else:   # nearest: src = floor(dst * in / out) = dst // 2
+                    sc = np.stack([np.arange(2 * n_in) // 2, np.ones(2 * n_in, dtype=np.int64)], 1).astype(np.int32)
+                    wt = np.zeros((2 * n_in, 8), dtype=np.float32)
+                    wt[:, 0] = 1.0
+                return torch.from_numpy(sc).to(self.device), torch.from_numpy(wt).to(self.device)
+            self._consts[key] = taps(H) + taps(W)
+        ys, yw, xs, xw = self._consts[key]
+        ld = x.t.shape[1]
+        big = self._new(4 * H * W, ld)
+        ops.resize_taps(x.t, (1, W * ld, ld), C, ys, yw, xs, xw, 2 * H, 2 * W, big, (1, 2 * W * ld, ld))
+        a = self._new(4 * H * W, _up(C, 64), torch.bfloat16)
+        if _up(C, 64) > C:
+            a.zero_()
+        ops.cast_rows(big, a, rows=4 * H * W, cols=C if C % 4 == 0 else _up(C, 4))
+        out = _Act(self._new(4 * H * W, _up(Cn, 128)), Cn, 2 * H, 2 * W)
+        ops.conv3x3(a, 2 * H, 2 * W, _up(C, 64), self.w[p + ".1.weight"], self.w[p + ".1.bias"], out.t)
+        return out
 
     def _conv_stack(self, name: str, cfg: Dict, feats: List[Optional[_Act]], uv_levels: bool, base_h: int, base_w: int,
-                    ar: float) -> List[_Act]:
+                    ar: float, all_outputs: bool = False) -> List[Optional[_Act]]:
+        """all_outputs: every level's output is consumed (the neck, v2.py:148); a head is read at its finest level only
+        (v2.py:150-157)."""
         dims = cfg["dim_res_blocks"]
         n = len(dims)
         dim_in, dim_out = _lst(cfg["dim_in"], n), _lst(cfg["dim_out"], n)
+        res = _lst(cfg["resamplers"], n - 1)
         nres = cfg.get("num_res_blocks", 1)
-        in_norm = cfg.get("res_block_in_norm", "layer_norm")
-        hid_norm = cfg.get("res_block_hidden_norm", "group_norm")
+        act_name, in_norm, hid_norm, mult = _stack_options(cfg)
+        act = ACTS[act_name]
         outs: List[_Act] = []
         x: Optional[_Act] = None
         for i in range(n):
@@ -369,31 +463,33 @@ class MoGeEngine:
                 a = self._to_bf16(f)
                 ops.gemm(a, self.w[wk], x.t, M=H * W, K=a.shape[1], bias=self.w[bk], resid=x.t if i > 0 else None)
                 have_feat = True
-            elif dim_in[i] is None and f is not None:
-                raise NotImplementedError("identity input blocks are not built")
+            elif dim_in[i] is None and f is not None:        # nn.Identity input block: x = feature / x = x + feature
+                assert f.C == C and not uv_levels, "an identity input block needs a feature of the block's width"
+                if i == 0:
+                    x.t[:, :C].copy_(f.t[:, :C])
+                    if x.t.shape[1] > C:
+                        x.t[:, C:].zero_()
+                else:
+                    ops.add_rows(x.t, f.t, H * W, C)
+                have_feat = True
             if uv_levels:
                 u, v = self._uv(H, W, ar)
                 wf = self.w[wk + "#f32"]
                 ops.uv_affine(x.t, H, W, C, wf, wf.shape[1] - 2, None if have_feat else self.w[bk][:C].contiguous(),
                               u, v, accumulate=(i > 0 or have_feat))
             for j in range(nres[i] if isinstance(nres, list) else nres):
-                self._res_block(f"{name}.res_blocks.{i}.{j}.layers", x, in_norm, hid_norm)
-            if dim_out[i] is not None:
+                self._res_block(f"{name}.res_blocks.{i}.{j}.layers", x, in_norm, hid_norm, act, mult)
+            if not (all_outputs or i == n - 1):
+                outs.append(None)
+            elif dim_out[i] is not None:
                 o = _Act(self._new(H * W, _up(dim_out[i], 128)), dim_out[i], H, W)
                 ops.gemm(self._to_bf16(x), self.w[f"{name}.output_blocks.{i}.weight"], o.t, M=H * W,
                          bias=self.w[f"{name}.output_blocks.{i}.bias"])
                 outs.append(o)
-            else:
-                outs.append(x if i == n - 1 else None)       # only the finest output of a head is consumed (v2.py:150)
-            if i < n - 1:                                     # Resampler 'conv_transpose' (modules.py:159-164)
-                Cn = dims[i + 1]
-                p = f"{name}.resamplers.{i}"
-                g = self._new(H * W, 4 * Cn)
-                ops.gemm(self._to_bf16(x), self.w[p + ".0.weight"], g, M=H * W, bias=self.w[p + ".0.bias"])
-                up = self._new(4 * H * W, _up(Cn, 64), torch.bfloat16)
-                ops.convt_scatter(g, H, W, Cn, Cn, _up(Cn, 64), up)
-                x = _Act(self._new(4 * H * W, _up(Cn, 128)), Cn, 2 * H, 2 * W)
-                ops.conv3x3(up, 2 * H, 2 * W, _up(Cn, 64), self.w[p + ".1.weight"], self.w[p + ".1.bias"], x.t)
+            else:                                             # nn.Identity output block: the map itself (a copy where
+                outs.append(x if i == n - 1 else _Act(x.t.clone(), x.C, x.H, x.W))   # the next level replaces x)
+            if i < n - 1:
+                x = self._resample(f"{name}.resamplers.{i}", res[i], x, dims[i + 1])
         return outs
 
     # ------------------------------------------------------------------ forward / infer
@@ -457,7 +553,7 @@ class MoGeEngine:
                                   rows=1)
                 k += 1
         # --- neck + heads
-        feats = self._conv_stack("neck", cfg["neck"], [feat, None, None, None, None], True, bh, bw, ar)
+        feats = self._conv_stack("neck", cfg["neck"], [feat, None, None, None, None], True, bh, bw, ar, all_outputs=True)
         out: Dict[str, torch.Tensor] = {"_base": (bh, bw)}
         h4, w4 = bh * 16, bw * 16
         ys, yw = self._taps(h4, H, False)

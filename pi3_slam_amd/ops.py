@@ -350,12 +350,23 @@ def groupnorm_stats(x: torch.Tensor, HW: int, C: int, G: int, stats: torch.Tenso
     _L.check(rc, "pi3_groupnorm_stats")
 
 
+ACT_LEAKY, ACT_SILU, ACT_ELU = 3, 4, 5
+
+
 def groupnorm_apply(x, HW, C, Cpad, G, stats, gamma, beta, eps, act, out) -> None:
+    """G = 0: no normalisation; gamma / beta None: no affine (InstanceNorm2d)."""
     lib = _L.load()
     assert out.dtype == torch.bfloat16 and out.shape[1] >= Cpad
-    rc = lib.pi3_groupnorm_apply(x.data_ptr(), x.stride(0), 1, HW, C, Cpad, G, stats.data_ptr(), gamma.data_ptr(),
-                                 beta.data_ptr(), float(eps), act, out.data_ptr(), out.stride(0), _L.stream_ptr())
+    rc = lib.pi3_groupnorm_apply(x.data_ptr(), x.stride(0), 1, HW, C, Cpad, G, _L.ptr(stats), _L.ptr(gamma),
+                                 _L.ptr(beta), float(eps), act, out.data_ptr(), out.stride(0), _L.stream_ptr())
     _L.check(rc, "pi3_groupnorm_apply")
+
+
+def add_rows(x: torch.Tensor, y: torch.Tensor, rows: int, C: int) -> None:
+    lib = _L.load()
+    assert x.dtype == torch.float32 and y.dtype == torch.float32
+    rc = lib.pi3_add_rows(x.data_ptr(), x.stride(0), y.data_ptr(), y.stride(0), rows, C, _L.stream_ptr())
+    _L.check(rc, "pi3_add_rows")
 
 
 def convt_scatter(g: torch.Tensor, H: int, W: int, Cout: int, Cs: int, Cpad: int, out: torch.Tensor) -> None:

@@ -89,25 +89,27 @@ def test_umeyama_known_answers():
     assert abs(np.linalg.det(Rp) - 1.0) < 1e-9
 
 
-@pytest.mark.parametrize("name", ["moge_small", "moge_chunk", "moge_pinhole_small", "moge_pinhole_chunk"])
+@pytest.mark.parametrize("name", ["moge_small", "moge_chunk", "moge_pinhole_small", "moge_pinhole_chunk",
+                                  "moge_var_pixelshuffle", "moge_var_interp", "moge_var_elu"])
 def test_moge_oracle_matches_reference_vectors(name):
     """MoGe-2 restatement vs the real MoGeModel class (synthetic model_config + recipe weights; the 'pinhole' cases
     edit a few 1x1 convolutions so the predicted map is camera-consistent: focal > 0, well-conditioned shift)."""
     from oracle import moge_ref
-    from oracle.gen_golden_moge import CASES as MCASES, case_state_dict, moge_image
-    from pi3_slam_amd.moge import SYNTHETIC_CONFIG
+    from oracle.gen_golden_moge import CASES as MCASES, case_config, case_state_dict, moge_image
     g = np.load(os.path.join(GOLDEN, name + ".npz"))
     H, W, level = MCASES[name]
-    out = moge_ref.moge_infer(case_state_dict(name), SYNTHETIC_CONFIG, moge_image(name, H, W), level)
+    out = moge_ref.moge_infer(case_state_dict(name), case_config(name), moge_image(name, H, W), level)
     if "pinhole" in name:
         assert g["focal_shift"][0] > 0.5 and abs(float(out["focal"]) - g["focal_shift"][0]) < 1e-4
         assert abs(float(out["shift"]) - g["focal_shift"][1]) < 1e-4
     mask = np.unpackbits(g["mask"])[: H * W].reshape(H, W).astype(bool)
     assert np.array_equal(out["mask"].numpy(), mask)
     np.testing.assert_allclose(out["points_affine"][..., 2].numpy(), g["points_affine_z"], rtol=1e-4, atol=1e-5)
-    np.testing.assert_allclose(out["depth"].numpy()[mask], g["depth"][mask], rtol=1e-4, atol=1e-5)
-    assert np.all(np.isinf(out["depth"].numpy()[~mask]))
     np.testing.assert_allclose(out["metric_scale"].numpy(), g["metric_scale"][0], rtol=1e-5)
+    assert np.all(np.isinf(out["depth"].numpy()[~mask]))
+    if "_var_" in name:       # config-space variants pin the NETWORK (their random maps make the focal solve degenerate)
+        return
+    np.testing.assert_allclose(out["depth"].numpy()[mask], g["depth"][mask], rtol=1e-4, atol=1e-5)
     np.testing.assert_allclose(out["intrinsics"].numpy(), g["intrinsics"], rtol=1e-4)
 
 

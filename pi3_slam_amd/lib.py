@@ -13,7 +13,8 @@ from typing import Optional
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpi3slam_hip.so")
+# PI3_LIB_PATH: load another build of the same library (the AddressSanitizer host build of tests/test_asan_host.py)
+LIB_PATH = os.environ.get("PI3_LIB_PATH") or os.path.join(_HERE, "libpi3slam_hip.so")
 
 _vp, _i, _l, _f, _u64, _d = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_ulonglong, C.c_double
 

@@ -1,0 +1,53 @@
+"""CPU: the host side of every C-ABI entry point under AddressSanitizer (sanitizers on the CPU build
+only - the GPU pool offers no GPU ASAN).  `make asan` builds libpi3slam_hip_asan.so with the host code instrumented;
+a child process preloads the clang ASAN runtime, binds the library through the product's own ctypes table and drives
+every entry point down its argument-validation / error-reporting path (no GPU: nothing may launch).  Any heap / stack /
+global overflow or use-after-free in that code aborts the child with an AddressSanitizer report."""
+import os
+import subprocess
+import sys
+
+from conftest import ROOT
+
+CHILD = r"""
+import ctypes, os, sys
+sys.path.insert(0, os.environ["PI3_ROOT"])
+from pi3_slam_amd import lib
+dll = lib.load(require_gpu=False)
+assert dll.pi3_abi_version() == 2
+bad = []
+for name, argt in lib.SIGNATURES.items():
+    args = []
+    for t in argt:
+        if t is ctypes.c_void_p or (hasattr(t, "_type_") and not isinstance(t._type_, str)):
+            args.append(None)
+        elif t in (ctypes.c_float, ctypes.c_double):
+            args.append(0.0)
+        else:
+            args.append(0)
+    rc = getattr(dll, name)(*args)
+    msg = dll.pi3_last_error()
+    if not (rc < 0 and msg):
+        bad.append((name, rc, msg))
+# long error strings through the formatted-message path
+for _ in range(3):
+    dll.pi3_gemm(None, 1 << 40, None, 1 << 40, 2 ** 31 - 1, 2 ** 31 - 1, 2 ** 31 - 1, 7, None, None, None, 0, None, 0, 9, 9,
+                 0, 0, 0, None, 0, 0.0, 0, None)
+assert dll.pi3_ba_workspace_doubles(100, 200) > 0 and dll.pi3_groupnorm_ws_doubles(1, 905216, 32) > 0
+assert not bad, bad
+print("asan child ok", len(lib.SIGNATURES))
+"""
+
+
+def test_host_code_of_every_entry_point_under_asan():
+    csrc = os.path.join(ROOT, "pi3_slam_amd", "csrc")
+    subprocess.run(["make", "-C", csrc, "-j", "8", "asan"], check=True, capture_output=True)
+    asan_lib = os.path.join(ROOT, "pi3_slam_amd", "libpi3slam_hip_asan.so")
+    rt = subprocess.run(["/opt/rocm/bin/hipcc", "-print-file-name=libclang_rt.asan-x86_64.so"], capture_output=True,
+                        text=True, check=True).stdout.strip()
+    assert os.path.exists(asan_lib) and os.path.exists(rt)
+    env = dict(os.environ, LD_PRELOAD=rt, PI3_LIB_PATH=asan_lib, PI3_ROOT=ROOT,
+               ASAN_OPTIONS="detect_leaks=0:abort_on_error=1:halt_on_error=1:verify_asan_link_order=0")
+    r = subprocess.run([sys.executable, "-c", CHILD], env=env, capture_output=True, text=True, timeout=300)
+    assert "AddressSanitizer" not in r.stderr, r.stderr[-3000:]
+    assert r.returncode == 0 and "asan child ok" in r.stdout, (r.returncode, r.stdout[-500:], r.stderr[-2000:])

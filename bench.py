@@ -32,11 +32,11 @@ sys.path.insert(0, ROOT)
 CL, OV, SRC_H, SRC_W, H, W, KP = 100, 20, 384, 512, 308, 406, 200
 PEAK_BF16_DENSE_TFLOPS = 2500.0   # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md)
 # HBM-side bytes of ONE global-attention launch, from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this
-# kernel (profiles/r01c_attention_pmc.csv; tools/pmc_summary.py): FETCH_SIZE 643 097 KB (x2: gfx950 reports half of a
+# kernel (profiles/r02_attention_pmc.csv, unchanged since profiles/r01c_attention_pmc.csv; tools/pmc_summary.py): FETCH_SIZE 643 097 KB (x2: gfx950 reports half of a
 # wide coalesced read stream) + WRITE_SIZE 128 601 KB.  PMC counters cannot be read from inside this process, so the
 # JSON cites the committed profile; algorithmic bytes are 527 MB (q, k, v read once + o written), L2 hit rate 95.8 %.
-ATTN_TRAFFIC_BYTES = (2 * 643096.75 + 128600.9) * 1024.0
-ATTN_TRAFFIC_SOURCE = "profiles/r01c_attention_pmc.csv"
+ATTN_TRAFFIC_BYTES = (2 * 643094.0 + 128601.7) * 1024.0
+ATTN_TRAFFIC_SOURCE = "profiles/r02_attention_pmc.csv"
 
 
 def synthetic_frames_u8(n: int, h: int, w: int, seed: int) -> torch.Tensor:

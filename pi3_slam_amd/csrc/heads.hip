@@ -84,11 +84,17 @@ __global__ __launch_bounds__(256) void camera_tail_kernel(const float* __restric
                                                           const float* wr, const float* br, float* __restrict__ poses) {
   __shared__ float va[CAM_MAXD], vb[CAM_MAXD], tr[12];
   const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // AdaptiveAvgPool2d(1): eight rows in flight per thread (a single dependent chain of P loads was 1 ms of latency)
   for (int c = tid; c < D; c += 256) {
-    float acc = 0.f;
+    float a8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const float* col = feat + (long)f * fstride + c;
-    for (int p = 0; p < P; ++p) acc += col[(long)p * ld];
-    va[c] = acc / (float)P;
+    int p = 0;
+    for (; p + 8 <= P; p += 8) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a8[u] += col[(long)(p + u) * ld];
+    }
+    for (; p < P; ++p) a8[0] += col[(long)p * ld];
+    va[c] = (((a8[0] + a8[1]) + (a8[2] + a8[3])) + ((a8[4] + a8[5]) + (a8[6] + a8[7]))) / (float)P;
   }
   __syncthreads();
   cam_linear(w1, b1, va, vb, D, D, true, wave, lane);

@@ -11,46 +11,64 @@
 // depth_edge (pi3/utils/geometry.py:347-375): diff = maxpool3(z) + maxpool3(-z) with max_pool2d's implicit -inf
 // padding (borders use the valid neighbours only); edge = nan_to_num(diff / z) > rtol.
 // ---------------------------------------------------------------------------------------------------------------
+// One workgroup = a strip of MK_ROWS image rows of one frame.  The z channel of the strip and its two halo rows is
+// staged in LDS with fully coalesced reads of the interleaved (x, y, z) rows (the first version read 9 neighbours per
+// pixel at a 12-byte stride through the caches: 1.4 TB/s); each z is then read from HBM once (+ 2 / MK_ROWS halo).
+#define MK_ROWS 8
+#define MK_MAXW 1024
 __global__ __launch_bounds__(256) void masks_kernel(const float* __restrict__ conf, const float* __restrict__ lp,
                                                     int F, int H, int W, float thr, float rtol,
                                                     uint8_t* __restrict__ out) {
-  const long n = (long)F * H * W;
-  const long i = (long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
-  const int x = (int)(i % W);
-  const int y = (int)((i / W) % H);
-  const float z = lp[3 * i + 2];
-  float mx = z, mn = z;
-  bool anynan = isnan(z);  // max_pool2d propagates NaN (a NaN in the window wins), fmaxf would drop it
+  __shared__ float zs[(MK_ROWS + 2) * MK_MAXW];
+  const int strips = (H + MK_ROWS - 1) / MK_ROWS;
+  const int f = blockIdx.x / strips, y0 = (blockIdx.x % strips) * MK_ROWS;
+  const int tid = threadIdx.x;
+  const int ylo = max(y0 - 1, 0), yhi = min(y0 + MK_ROWS + 1, H);       // staged rows [ylo, yhi)
+  const float* base = lp + ((long)f * H + ylo) * W * 3;
+  const int nfl = (yhi - ylo) * W * 3;
+  for (int e = tid; e < nfl; e += 256) {
+    const float v = base[e];
+    if (e % 3 == 2) zs[e / 3] = v;          // pixel (ylo + (e/3) / W, (e/3) % W)
+  }
+  __syncthreads();
+  const int rows = min(MK_ROWS, H - y0);
+  for (int e = tid; e < rows * W; e += 256) {
+    const int ry = e / W, x = e - ry * W;
+    const int y = y0 + ry;
+    const float z = zs[(y - ylo) * W + x];
+    float mx = z, mn = z;
+    bool anynan = isnan(z);  // max_pool2d propagates NaN (a NaN in the window wins), fmaxf would drop it
 #pragma unroll
-  for (int dy = -1; dy <= 1; ++dy)
+    for (int dy = -1; dy <= 1; ++dy)
 #pragma unroll
-    for (int dx = -1; dx <= 1; ++dx) {
-      const int yy = y + dy, xx = x + dx;
-      if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
-        const float v = lp[3 * (i + (long)dy * W + dx) + 2];
-        mx = fmaxf(mx, v);
-        mn = fminf(mn, v);
-        anynan = anynan || isnan(v);
+      for (int dx = -1; dx <= 1; ++dx) {
+        const int yy = y + dy, xx = x + dx;
+        if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
+          const float v = zs[(yy - ylo) * W + xx];
+          mx = fmaxf(mx, v);
+          mn = fminf(mn, v);
+          anynan = anynan || isnan(v);
+        }
       }
-    }
-  float ratio = anynan ? __uint_as_float(0x7fc00000u) : (mx + (-mn)) / z;
-  if (isnan(ratio)) ratio = 0.f;
-  else if (isinf(ratio)) ratio = ratio > 0.f ? FLT_MAX : -FLT_MAX;
-  const bool edge = ratio > rtol;
-  const float sg = 1.0f / (1.0f + expf(-conf[i]));
-  out[i] = (sg > thr && !edge) ? 1 : 0;
+    float ratio = anynan ? __uint_as_float(0x7fc00000u) : (mx + (-mn)) / z;
+    if (isnan(ratio)) ratio = 0.f;
+    else if (isinf(ratio)) ratio = ratio > 0.f ? FLT_MAX : -FLT_MAX;
+    const bool edge = ratio > rtol;
+    const long i = ((long)f * H + y) * W + x;
+    const float sg = 1.0f / (1.0f + expf(-conf[i]));
+    out[i] = (sg > thr && !edge) ? 1 : 0;
+  }
 }
 
 extern "C" int pi3_compute_masks(const float* conf, const float* local_points, int F, int H, int W, float conf_thr,
                                  float rtol, unsigned char* masks, void* stream) {
-  if (!conf || !local_points || !masks || F <= 0 || H <= 0 || W <= 0) {
-    pi3_set_error("pi3_compute_masks: bad arguments");
+  if (!conf || !local_points || !masks || F <= 0 || H <= 0 || W <= 0 || W > MK_MAXW) {
+    pi3_set_error("pi3_compute_masks: bad arguments (W <= %d)", MK_MAXW);
     return PI3_ERR_ARG;
   }
-  const long n = (long)F * H * W;
-  hipLaunchKernelGGL(masks_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, conf,
-                     local_points, F, H, W, conf_thr, rtol, masks);
+  const long nwg = (long)F * ((H + MK_ROWS - 1) / MK_ROWS);
+  hipLaunchKernelGGL(masks_kernel, dim3((unsigned)nwg), dim3(256), 0, (hipStream_t)stream, conf, local_points, F, H, W,
+                     conf_thr, rtol, masks);
   return pi3_check_launch("compute_masks");
 }
 

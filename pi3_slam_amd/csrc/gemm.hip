@@ -191,7 +191,7 @@ extern "C" int pi3_gemm(const void* A, long lda, const void* W, long ldw, int M,
   p.rpg = rpg; p.gstride = gstride; p.goff = goff; p.addtab = addtab; p.ldadd = ldadd;
   p.qscale = qscale; p.qcols = qcols;
   p.cH = 0; p.cW = 0; p.cC = 0;
-  p.qk_mode = 0; p.qk_k2max = nullptr;
+  p.qk_mode = 0; p.qk_k2max = nullptr; p.tile_gm = 0;
   hipStream_t s = (hipStream_t)stream;
   if (in_dtype == 0) {  // large bf16 GEMMs: 256x256 pipelined kernel (PI3_GEMM_IMPL=1 forces the 128x128 kernel)
     static int impl = -1;
@@ -255,7 +255,7 @@ extern "C" int pi3_gemm_qkv(const void* A, long lda, const void* W, long ldw, in
   p.A = A; p.lda = lda; p.W = W; p.ldw = ldw; p.M = M; p.N = N; p.K = K;
   p.bias = bias; p.gamma = nullptr; p.resid = nullptr; p.ldr = 0; p.out = qkv; p.ldo = ldo;
   p.rpg = 0; p.gstride = 0; p.goff = 0; p.addtab = nullptr; p.ldadd = 0; p.qscale = 1.f; p.qcols = 0;
-  p.cH = 0; p.cW = 0; p.cC = 0;
+  p.cH = 0; p.cW = 0; p.cC = 0; p.tile_gm = 0;
   p.qk_mode = 1; p.qk_H = H; p.qk_T = T; p.qk_pos = pos; p.qk_cs = cs;
   p.qk_qw = qw; p.qk_qb = qb; p.qk_kw = kw; p.qk_kb = kb; p.qk_eps = eps; p.qk_qscale = qscale;
   p.qk_k2max = k2max; p.qk_attnS = attn_S > 0 ? attn_S : M;
@@ -269,7 +269,7 @@ extern "C" int pi3_gemm_qkv(const void* A, long lda, const void* W, long ldw, in
     if (rc <= 0) return rc;
   }
   // two-pass form: plain projection, then the in-place q/k pass, then the key-norm pre-pass
-  p.qk_mode = 0; p.qk_k2max = nullptr;
+  p.qk_mode = 0; p.qk_k2max = nullptr; p.tile_gm = 0;
   int rc = pi3_gemm256_try(p, 0, 0, s);
   if (rc > 0) rc = launch_gemm<true, true, 0>(p, s);
   if (rc != 0) return rc;
@@ -298,7 +298,7 @@ extern "C" int pi3_conv3x3(const void* img, long ldc, int B, int H, int W, int C
   p.bias = bias; p.gamma = nullptr; p.resid = resid; p.ldr = ldr; p.out = out; p.ldo = ldo;
   p.rpg = 0; p.gstride = 0; p.goff = 0; p.addtab = nullptr; p.ldadd = 0; p.qscale = 1.f; p.qcols = 0;
   p.cH = H; p.cW = W; p.cC = C;
-  p.qk_mode = 0; p.qk_k2max = nullptr;
+  p.qk_mode = 0; p.qk_k2max = nullptr; p.tile_gm = 0;
   hipStream_t s = (hipStream_t)stream;
   if (out_dtype == 0 && act == 0) return launch_gemm<true, true, 0, true>(p, s);
   if (out_dtype == 1 && act == 0) return launch_gemm<true, false, 0, true>(p, s);

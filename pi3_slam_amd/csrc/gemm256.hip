@@ -263,7 +263,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
   const int nbm = (p.M + G2_BM - 1) / G2_BM, nbn = p.N / G2_BN;
   const int nwg = nbm * nbn;
   const int id = xcd_remap(blockIdx.x, nwg);
-  constexpr int GM = 8;
+  const int GM = p.tile_gm > 0 ? p.tile_gm : 8;
   const int per_group = GM * nbn;
   const int g = id / per_group;
   const int gm = min(GM, nbm - g * GM);
@@ -408,15 +408,166 @@ static int launch256(const GemmParams& p, hipStream_t stream) {
   return pi3_check_launch("gemm256");
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Two-workgroups-per-CU form (PI3_GEMM_IMPL=3 / per-shape choice): 128 (m) x 256 (n) tile, 256 threads = 4 waves, each
+// wave the same 128 x 64 output block (and therefore the same epilogues) as in gemm256_kernel, BK = 32, a 3-stage
+// LDS-DMA ring of 24 KiB stages (72 KiB per workgroup: two workgroups fit a CU's 160 KiB, their 4 + 4 waves give every
+// SIMD one wave of each).  The two workgroups of a CU are independent, so one's epilogue (an HBM-rate store stream the
+// 256 x 256 kernel cannot hide at one workgroup per CU) runs under the other's main loop, and barrier / LDS-latency
+// stalls of one are filled by the other.  Price: 1.5 x the L2 -> LDS bytes per flop of the 256 x 256 tile.
+// MEASURED (round 2, M = 64300): qkv 0.525 / proj 0.257 / fc1 0.702 / fc2 0.657 ms against 0.439 / 0.222 / 0.640 / 0.510 ms
+// of gemm256_kernel on the same box, tile-group sizes 4...64 within 5 % of each other: the epilogue does overlap, but
+// the main loop drops from ~1.25 to ~0.85 PF/s (LDS array busy 75 % of the MFMA time instead of 62 %: the same
+// fragment reads plus 1.5 x the DMA writes, and one barrier per 32 MFMAs).  Kept as a correct A/B variant, not default.
+//   stage image: act 128 rows x 64 B, then W 256 rows x 64 B; 16-byte chunk c of row r sits at c ^ F[(r >> 2) & 3],
+//   F = {0, 2, 3, 1}: conflict-free for the ds_read_b128 fragment pattern on 64-byte rows (each 16-lane group of the
+//   instruction then covers one whole 256-byte bank row).
+//   iteration u: s_waitcnt vmcnt(6) (stage u landed, stage u+1 may fly) -> s_barrier -> LDS-DMA of stage u+2 (its slot
+//   was last read in iteration u-1, which every wave has left) -> 12 fragment reads -> 32 MFMAs.
+// ---------------------------------------------------------------------------------------------------------------
+#define G3_BM 128
+#define G3_BN 256
+#define G3_STAGE 24576
+#define G3_LDS (3 * G3_STAGE)        // 72 KiB; the epilogue reuses it (4 waves x 18 KiB)
+
+template <bool OUT_BF16, int ACT, bool QK = false>
+__global__ __launch_bounds__(256, 2) void gemm3_kernel(GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+  const int nbm = (p.M + G3_BM - 1) / G3_BM, nbn = p.N / G3_BN;
+  const int nwg = nbm * nbn;
+  const int id = xcd_remap(blockIdx.x, nwg);
+  const int GM = p.tile_gm > 0 ? p.tile_gm : 16;
+  const int per_group = GM * nbn;
+  const int g = id / per_group;
+  const int gm = min(GM, nbm - g * GM);
+  const int rem = id - g * per_group;
+  const int bm = g * GM + rem % gm;
+  const int bn = rem / gm;
+
+  const char* Ab = (const char*)p.A;
+  const char* Wb = (const char*)p.W;
+  const long lda_b = p.lda * 2, ldw_b = p.ldw * 2;
+  const int nk = p.K >> 5;
+
+  // swizzle table F = {0, 2, 3, 1} packed 2 bits each: 0b01'11'10'00 = 0x78
+  auto F = [](int q) { return (0x78 >> (2 * q)) & 3; };
+
+  // ---- staging addresses: lane i of a 1 KiB segment covers row i >> 2 (16 rows), slot i & 3
+  const int srow = lane >> 2, spos = lane & 3;
+  const char* a_src[2];
+  const char* w_src[4];
+  int a_dst[2], w_dst[4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int seg = wave * 2 + i, row = seg * 16 + srow;
+    int grow = bm * G3_BM + row;
+    grow = grow < p.M ? grow : p.M - 1;
+    a_src[i] = Ab + (long)grow * lda_b + ((spos ^ F((row >> 2) & 3)) << 4);
+    a_dst[i] = seg * 1024;
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int seg = wave * 4 + i, row = seg * 16 + srow;
+    w_src[i] = Wb + (long)(bn * G3_BN + row) * ldw_b + ((spos ^ F((row >> 2) & 3)) << 4);
+    w_dst[i] = 8192 + seg * 1024;
+  }
+#define G3_STAGE_IN(U)                                                                                    \
+  {                                                                                                       \
+    char* sb = smem + ((U) % 3) * G3_STAGE;                                                               \
+    const long kb = (long)(U) * 64;                                                                       \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                         \
+      __builtin_amdgcn_global_load_lds(GLB_PTR(a_src[i] + kb), LDS_PTR(sb + a_dst[i]), 16, 0, 0);        \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                         \
+      __builtin_amdgcn_global_load_lds(GLB_PTR(w_src[i] + kb), LDS_PTR(sb + w_dst[i]), 16, 0, 0);        \
+  }
+
+  f32x4 acc[4][8];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // fragment addresses inside a stage: rows mi*16 + frow (act) / wave*64 + ni*16 + frow (W), chunk lane >> 4
+  const int frow = lane & 15;
+  const int foff = frow * 64 + (((lane >> 4) ^ F((frow >> 2) & 3)) << 4);
+  const int w_base = 8192 + wave * 64 * 64 + foff;
+
+  G3_STAGE_IN(0)
+  if (nk > 1) G3_STAGE_IN(1)
+
+  for (int u = 0; u < nk; ++u) {
+    if (u + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (u + 2 < nk) G3_STAGE_IN(u + 2)
+    const char* sb = smem + (u % 3) * G3_STAGE;
+    bf16x8 fw[4], fa[8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) fw[i] = *(const bf16x8*)(sb + w_base + i * 1024);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) fa[j] = *(const bf16x8*)(sb + foff + j * 1024);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[i], fa[j], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+  }
+  // every wave must be out of its last fragment reads before the epilogue reuses the ring
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+
+  if constexpr (OUT_BF16)
+    g2_epilogue_lds<OUT_BF16, ACT, QK>(p, acc, bm * G3_BM, bn * G3_BN + wave * 64, smem + wave * G2_EPI_WAVE, lane);
+  else
+    gemm_epilogue<OUT_BF16, ACT, 4, 8>(p, acc, bm * G3_BM, bn * G3_BN + wave * 64, lane);
+#undef G3_STAGE_IN
+}
+
+template <bool OUT_BF16, int ACT, bool QK = false>
+static int launch3(const GemmParams& p, hipStream_t stream) {
+  const int nbm = (p.M + G3_BM - 1) / G3_BM, nbn = p.N / G3_BN;
+  auto kern = gemm3_kernel<OUT_BF16, ACT, QK>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, G3_LDS);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(nbm * nbn), dim3(256), G3_LDS, stream, p);
+  return pi3_check_launch("gemm3");
+}
+
 // Used by pi3_gemm (gemm.hip) for bf16 operands when N % 256 == 0 and M is large.  Returns 1 if not applicable.
 int pi3_gemm256_try(const GemmParams& p, int out_dtype, int act, hipStream_t stream) {
   if ((p.N % G2_BN) != 0 || (p.K % 64) != 0 || p.M < 1024) return 1;
   if (out_dtype == 0 && (p.resid || p.addtab)) return 1;   // the bf16 streaming pass carries no residual / table add
+  static int gm_knob = -1;   // PI3_GEMM_GM: m-tiles per scheduling group (A/B knob; any value gives the same results)
+  if (gm_knob < 0) {
+    const char* e = getenv("PI3_GEMM_GM");
+    gm_knob = e ? atoi(e) : 0;
+  }
+  const_cast<GemmParams&>(p).tile_gm = gm_knob;
+  static int impl3 = -1;     // PI3_GEMM_IMPL=3: the two-workgroups-per-CU 128x256 kernel for every large GEMM (A/B knob)
+  if (impl3 < 0) {
+    const char* e = getenv("PI3_GEMM_IMPL");
+    impl3 = (e && atoi(e) == 3) ? 1 : 0;
+  }
   if (p.qk_mode) {   // fused q/k head epilogue: bf16 output, no activation, one head per wave column block
     if (out_dtype != 0 || act != 0 || p.gamma || p.rpg || p.N != 3 * p.qk_H * 64 ||
         (p.qk_k2max && p.qk_attnS < 128))
       return 1;
+    if (impl3 && (p.K % 32) == 0) return launch3<true, 0, true>(p, stream);
     return launch256<true, 0, false, true, true>(p, stream);
+  }
+  if (impl3 && (p.K % 32) == 0) {
+    if (out_dtype == 0 && act == 0) return launch3<true, 0>(p, stream);
+    if (out_dtype == 0 && act == 1) return launch3<true, 1>(p, stream);
+    if (out_dtype == 1 && act == 0) return launch3<false, 0>(p, stream);
   }
 #ifdef PI3_DEV_ABLATIONS   // timing-only variant that writes NOTHING: development builds only
   static int abl = -1;

@@ -343,6 +343,81 @@ def extras(engine, moge, make_creator, run, dev):
             "note": "660 PNG files 512x384 (100 distinct), decoded by the loader workers, device resize, chunk files written "
                     "by the writer thread.  frames_per_s counts from the moment the first decoded chunk leaves the loader "
                     "(worker processes forked and first 100 PNGs decoded), frames_per_s_incl_loader_start from the call"}
+        # configs[4] on one GPU: a 4 000-frame 512x384 stream through the online sliding-window class (chunk-parallel
+        # over ranks when a process group exists; here one rank), hipGraph-captured per-chunk forward, in-order results
+        from pi3_slam_amd.online import Pi3SLAMOnline
+        n_stream = 4000
+        sdir = os.path.join(tmp, "stream")
+        os.makedirs(sdir)
+        stream_files = []
+        for i in range(n_stream):
+            q = os.path.join(sdir, f"frame_{i:05d}.png")
+            os.link(files[i % n_distinct], q)
+            stream_files.append(q)
+        workers = min(8, max(2, len(os.sched_getaffinity(0)) // 2))
+        online = {}
+        for mode, graph in (("hip_graph", True), ("eager", False)):
+            slam = Pi3SLAMOnline(model=engine, chunk_length=CL, overlap=OV, device=str(dev), keypoint_type="grid",
+                                 max_num_keypoints=KP, do_metric_depth=moge is not None, moge_model=moge, hip_graph=graph,
+                                 output_dir=os.path.join(tmp, "online_" + mode), bundle_adjust=False,
+                                 num_loader_workers=workers)
+            slam.process_chunks(stream_files[:180])           # graph capture of the chunk shape: untimed
+            torch.cuda.synchronize(dev)
+            before = slam.get_statistics()["num_frames"]
+            t0 = time.perf_counter()
+            res = slam.process_chunks(stream_files)
+            torch.cuda.synchronize(dev)
+            dt = time.perf_counter() - t0
+            st = slam.get_timing_statistics()
+            online[mode] = {
+                "frames_per_s": n_stream / dt, "chunk_frames_per_s": sum(r["chunk"]["_metrics"]["num_frames"] for r in res) / dt,
+                "chunks": len(res), "wall_s": dt, "new_frames_accounted": slam.get_statistics()["num_frames"] - before,
+                "pi3_forward_ms_mean": 1e3 * st.get("pi3_forward", {}).get("mean_s", float("nan")),
+                "consume_ms_max": 1e3 * st.get("consume_chunk", {}).get("max_s", float("nan"))}
+            del slam
+        out["online_stream_4k"] = dict(
+            online["hip_graph"], hip_graph=True, bundle_adjust=False, input_frames=n_stream,
+            eager_launches=online["eager"],
+            note="Pi3SLAMOnline.process_chunks on 4000 PNG files (100 distinct), cl=100 ov=20 -> 50 chunks; decode threads, "
+                 "device resize, hipGraph replay of the forward (eager_launches: the same run with plain launches), "
+                 "Sim(3) alignment of every chunk to its predecessor, results drained in order.  frames_per_s counts input "
+                 "frames (every chunk re-processes its 20 overlap frames: chunk_frames_per_s).  Bundle adjustment is off: "
+                 "recipe weights give no consistent geometry")
+        # configs[3] shape: EuRoC 752x480 frames, the reference's own cam0 calibration (undistortion on the device),
+        # -> 280x448, --estimate-intrinsics, grid K = 200
+        calib = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden", "calib_euroc_cam0_calib.json")
+        if os.path.exists(calib):
+            edir = os.path.join(tmp, "euroc")
+            os.makedirs(edir)
+            efr = synthetic_frames_u8(50, 480, 752, 6).numpy()
+            efiles = []
+            for i in range(340):                              # 4 full chunks (stride 80) + a 20-frame tail
+                q = os.path.join(edir, f"{1403636579763555584 + i * 50000000}.png")
+                if i < 50:
+                    Image.fromarray(efr[i]).save(q, compress_level=1)
+                else:
+                    os.link(efiles[i % 50], q)
+                efiles.append(q)
+            from pi3_slam_amd.chunk_creator import OfflineChunkCreator, OfflineCreatorConfig
+            cc = OfflineCreatorConfig(model_path="recipe", output_dir=os.path.join(tmp, "euroc_out"), chunk_length=CL,
+                                      overlap=OV, device=str(dev), do_metric_depth=moge is not None, keypoint_type="grid",
+                                      max_num_keypoints=KP, estimate_camera_params=True, cam_dist_path=calib,
+                                      num_loader_workers=min(8, max(2, len(os.sched_getaffinity(0)) // 2)),
+                                      device_resize=True)
+            ecr = OfflineChunkCreator(cc, model=engine, moge_model=moge)
+            ecr.process_and_save(efiles[:120])
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            saved = ecr.process_and_save(efiles)
+            dt = time.perf_counter() - t0
+            out["euroc_752x480_undistort_intrinsics"] = {
+                "frames_per_s": ecr.last_run["frames"] / ecr.last_run["wall_after_first_chunk_decoded_s"],
+                "frames_per_s_incl_loader_start": ecr.last_run["frames"] / dt, "frames": ecr.last_run["frames"],
+                "chunks": len(saved), "target_size": list(ecr.target_size),
+                "undistortion_on_device": ecr.undistortion_maps is not None,
+                "note": "340 PNG files 752x480 (50 distinct) + calib_euroc_cam0_calib.json: decode threads, device "
+                        "undistortion + resize to 280x448 (S = 64 500), forward, masks, scale, LM intrinsics, K = 200 gather, "
+                        "chunk files written"}
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
     return out

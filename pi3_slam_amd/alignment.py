@@ -24,13 +24,30 @@ def _chunk_frame(chunk: Dict) -> Dict:
     return chunk.get("_chunk_frame") or chunk
 
 
+def upload(t: torch.Tensor, device, dtype: Optional[torch.dtype] = None) -> torch.Tensor:
+    """Host tensor -> device through a pinned staging buffer and an asynchronous copy on the current stream.  A copy
+    from pageable memory is a synchronous call that was measured to return only when the forward running beside it on
+    the compute stream had finished (the first such copy of every alignment: 250 ms of host wait per chunk, 15 ms of idle
+    device before the next launch); the pinned form returns at once.  torch's host allocator keeps the staging block
+    alive until the copy has run."""
+    if t.device.type != "cpu" or torch.device(device).type == "cpu":
+        return t.to(device) if dtype is None else t.to(device, dtype)
+    if dtype is not None and t.dtype != dtype:
+        t = t.to(dtype)
+    if not t.is_pinned():
+        p = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+        p.copy_(t)
+        t = p
+    return t.to(device, non_blocking=True)
+
+
 def _overlap_block(chunk: Dict[str, torch.Tensor], frames: List[int], device) -> Dict[str, torch.Tensor]:
     idx = torch.tensor(frames, dtype=torch.long)
     src = _chunk_frame(chunk)
     out = {}
     for k in ("points", "keypoints", "masks"):
         t = src[k] if k == "points" else chunk[k]
-        out[k] = t[idx.to(t.device)].to(device).contiguous()
+        out[k] = upload(t[idx.to(t.device)], device).contiguous()
     return out
 
 
@@ -49,7 +66,7 @@ def estimate_sim3(chunk_ref: Dict, chunk_qry: Dict, view_graph_matches: List[Tup
     qry = _overlap_block(chunk_qry, [q for _, q in pairs], device)
     idx = ops.sim3_match_keypoints(ref["keypoints"].to(torch.float16), qry["keypoints"].to(torch.float16))
     # "last camera" of the reference reconstruction = its last view (reconstruction_alignment.py:79)
-    last_pose = _chunk_frame(chunk_ref)["camera_poses"][n_ref - 1].to(device, torch.float32).contiguous()
+    last_pose = upload(_chunk_frame(chunk_ref)["camera_poses"][n_ref - 1], device, torch.float32).contiguous()
     w_ref = ref["masks"].reshape(len(pairs), -1).to(torch.uint8).contiguous() if use_masks else None
     w_qry = qry["masks"].reshape(len(pairs), -1).to(torch.uint8).contiguous() if use_masks else None
     # chunk-file points are fp16 and go in as they are; bundle-adjusted chunks carry refined fp32 points
@@ -81,15 +98,15 @@ def transform_chunk(chunk: Dict, M4: torch.Tensor, device="cuda:0", absolute: bo
     stack rounding.  absolute=True replaces the accumulated similarity by M4 instead of composing M4 with it."""
     if "_chunk_frame" not in chunk:
         chunk["_chunk_frame"] = {"points": chunk["points"], "camera_poses": chunk["camera_poses"]}
-    M4 = M4.detach().to(device, torch.float64).reshape(4, 4).contiguous()
+    M4 = upload(M4.detach(), device, torch.float64).reshape(4, 4).contiguous()
     if absolute or "_sim3_global" not in chunk:
         G = M4
     else:   # M4 . G_old, on the device like every other 4x4 product of the path (pi3_sim3_compose_prefix)
-        G = ops.sim3_compose_prefix(torch.stack([M4.reshape(16), chunk["_sim3_global"].to(device).reshape(16)])
+        G = ops.sim3_compose_prefix(torch.stack([M4.reshape(16), upload(chunk["_sim3_global"], device).reshape(16)])
                                     .contiguous())[1].reshape(4, 4)
     src = chunk["_chunk_frame"]
-    pts = src["points"].to(device, torch.float32).contiguous()      # fresh fp32 copies of the originals
-    poses = src["camera_poses"].to(device, torch.float32).contiguous()
+    pts = upload(src["points"], device, torch.float32).contiguous()      # fresh fp32 copies of the originals
+    poses = upload(src["camera_poses"], device, torch.float32).contiguous()
     if pts.data_ptr() == src["points"].data_ptr():
         pts = pts.clone()
     if poses.data_ptr() == src["camera_poses"].data_ptr():
@@ -119,7 +136,7 @@ def align_and_refine_reconstructions(chunk_ref: Dict, chunk_qry: Dict, view_grap
         if not sim3_accepted(o):
             print("❌ Sim3 alignment failed")
             return False, {"error": "sim3_failed", "num_common_tracks": n_used}
-        G = ops.sim3_compose_prefix(torch.stack([global_transform(chunk_ref).reshape(16).to(device),
+        G = ops.sim3_compose_prefix(torch.stack([upload(global_transform(chunk_ref).reshape(16), device),
                                                  out[13:29]]).contiguous())[1].reshape(4, 4)
         transform_chunk(chunk_qry, G, device, absolute=True)
         info = {"success": True, "num_common_tracks": n_used,

@@ -95,8 +95,11 @@ class _Staged:
 
 @dataclass
 class _InFlight:
-    """A chunk whose kernels and packed D2H are queued; `done` fires when the pinned buffer holds the results."""
-    pinned: Optional[torch.Tensor]
+    """A chunk whose kernels are queued; `done` fires when `packed` (one device byte buffer with every small result
+    tensor) is complete.  The copy to the host is issued by finish(), after that event: a D2H command queued behind the
+    forward would sit at the head of the copy engine's queue for the whole forward and hold up every other device->host
+    copy of the process (the alignment of the previous chunk waited 420 ms for its 33 doubles that way)."""
+    packed: Optional[torch.Tensor]
     layout: List[Tuple[str, torch.dtype, tuple, int, int]]
     done: torch.cuda.Event
     timing: Dict[str, torch.cuda.Event]
@@ -152,6 +155,7 @@ class OfflineChunkCreator:
         self.target_size: Optional[Tuple[int, int]] = None
         self._copy_stream = torch.cuda.Stream(self.device)
         self._moge_stream = torch.cuda.Stream(self.device)
+        self._d2h_stream = torch.cuda.Stream(self.device)
         self._pinned_pool: Dict[int, List[torch.Tensor]] = {}
 
     @staticmethod
@@ -283,11 +287,32 @@ class OfflineChunkCreator:
             else:
                 self._moge_stream.wait_stream(cur)
             with torch.cuda.stream(self._moge_stream):
-                infer = (self.moge_model.infer_graphed if cfg.hip_graph and hasattr(self.moge_model, "infer_graphed")
-                         else self.moge_model.infer)
+                infer = (self.moge_model.infer_graphed
+                         if cfg.hip_graph and hasattr(self.moge_model, "infer_graphed")
+                         and os.environ.get("PI3_MOGE_GRAPH", "1") != "0" else self.moge_model.infer)
                 moge_depth = infer(imgs[0, 0])["depth"]
             moge_depth.record_stream(cur)
         mark("moge queued")
+
+        # keypoints depend on the frame size only: extracted now and uploaded on the copy stream (idle at this point).
+        # Queued on the compute stream the upload would wait behind the forward at the head of the H2D engine's queue
+        # and hold up every other upload of the process, e.g. the previous chunk's alignment beside this forward.
+        kp = kp_dev = kp_err = None
+        if self.keypoint_extractor is not None:
+            try:
+                kp = self.keypoint_extractor.extract(chunk_images_for_kp if chunk_images_for_kp is not None else imgs)
+                kp_dev = kp["keypoints"]
+                if not kp_dev.is_cuda:
+                    kp_host = kp_dev.to(torch.float32).contiguous().pin_memory()
+                    with torch.cuda.stream(self._copy_stream):
+                        kp_dev = kp_host.to(dev, non_blocking=True)
+                        kp_ready = torch.cuda.Event()
+                        kp_ready.record(self._copy_stream)
+                    cur.wait_event(kp_ready)
+                    kp_dev.record_stream(cur)
+            except Exception as e:  # noqa: BLE001
+                kp_err = e
+        mark("keypoints queued")
 
         ev["f0"].record(cur)
         if cfg.hip_graph and hasattr(self.model, "forward_graphed"):
@@ -317,15 +342,24 @@ class OfflineChunkCreator:
         dense = None
         if self.keypoint_extractor is not None:
             try:
-                kp = self.keypoint_extractor.extract(chunk_images_for_kp if chunk_images_for_kp is not None else imgs)
+                if kp_err is not None:
+                    raise kp_err
                 g = self._interpolate_world_points_for_keypoints(
                     dict(points=pi3["points"][0], local_points=pi3["local_points"][0], conf=pi3["conf"][0],
-                         masks=masks, images=imgs[0]), kp["keypoints"])
+                         masks=masks, images=imgs[0]), kp_dev)
                 for k in ("points", "local_points", "conf", "keypoints", "colors"):
                     out[k] = g[k]
                 out["masks"] = g["masks"].view(torch.uint8)
-                host["descriptors"] = kp["descriptors"].to(torch.float16)
-                host["scores"] = kp["scores"].to(torch.float16)
+                if kp.get("constant"):     # zeros / ones: fp16 copies of cached constants (a memcpy, no conversion)
+                    key = ("kp_const", tuple(kp["descriptors"].shape))
+                    if key not in self.__dict__.setdefault("_host_consts", {}):
+                        self._host_consts[key] = (torch.zeros(kp["descriptors"].shape, dtype=torch.float16),
+                                                  torch.ones(kp["scores"].shape, dtype=torch.float16))
+                    d16, s16 = self._host_consts[key]
+                    host["descriptors"], host["scores"] = d16.clone(), s16.clone()
+                else:
+                    host["descriptors"] = kp["descriptors"].to(torch.float16)
+                    host["scores"] = kp["scores"].to(torch.float16)
             except Exception as e:  # noqa: BLE001
                 print(f"⚠️  Keypoint extraction failed: {e}")
                 for k in ("points", "local_points", "conf", "keypoints", "colors", "masks"):
@@ -348,30 +382,41 @@ class OfflineChunkCreator:
             if pad:
                 parts.append(torch.zeros(pad, dtype=torch.uint8, device=dev))
             off += b.numel() + pad
-        pinned = self._pinned(off)
-        pinned.copy_(torch.cat(parts), non_blocking=True)
+        packed = torch.cat(parts)
         done = torch.cuda.Event()
         done.record(cur)
         mark("pack queued")
         if trace is not None:
             print("   [trace] launch: " + ", ".join(f"{b[0]} +{(b[1] - a[1]) * 1e3:.1f} ms" for a, b in zip(trace, trace[1:])))
-        return _InFlight(pinned, layout, done, ev, host, dense, dict(st.meta, paths=st.paths, num_frames=N),
+        return _InFlight(packed, layout, done, ev, host, dense, dict(st.meta, paths=st.paths, num_frames=N),
                          t_launch=time.time())
 
     # ------------------------------------------------------------------ finish
     def _finish(self, fl: _InFlight) -> Dict:
         """Wait for one chunk's results and build its chunk-file dictionary (host tensors)."""
         fl.done.synchronize()
+        pinned = self._pinned(fl.packed.numel())
+        with torch.cuda.stream(self._d2h_stream):      # nothing else is ever queued on this stream
+            pinned.copy_(fl.packed, non_blocking=True)
+        self._d2h_stream.synchronize()
+        fl.packed = None
         got: Dict[str, torch.Tensor] = {}
         for k, dt, shape, off, nbytes in fl.layout:
-            got[k] = fl.pinned[off:off + nbytes].clone().view(dt).reshape(shape)
-        self._pinned_pool.setdefault(fl.pinned.numel(), []).append(fl.pinned)
+            got[k] = pinned[off:off + nbytes].clone().view(dt).reshape(shape)
+        self._pinned_pool.setdefault(pinned.numel(), []).append(pinned)
         N = fl.meta["num_frames"]
         infer_s = max(1e-6, fl.timing["f0"].elapsed_time(fl.timing["f1"]) / 1e3)
         post_s = fl.timing["f1"].elapsed_time(fl.timing["post"]) / 1e3
         fps = N / infer_s if N > 0 else 0.0
         print(f"   ⏱️ Inference: {infer_s:.3f}s for {N} frames  ->  {fps:.2f} FPS")
         metrics = {"infer_s": float(infer_s), "num_frames": int(N), "fps": float(fps), "post_s": float(post_s)}
+        last = self.__dict__.get("_last_forward_end")      # device idle between consecutive forwards (pipelined runs)
+        if last is not None:
+            try:
+                metrics["gap_before_forward_s"] = last.elapsed_time(fl.timing["f0"]) / 1e3
+            except RuntimeError:
+                pass
+        self._last_forward_end = fl.timing["f1"]
         if "_stage_in" in fl.meta:     # H2D + device resize / undistortion on the copy stream
             a, b = fl.meta.pop("_stage_in")
             metrics["stage_in_s"] = a.elapsed_time(b) / 1e3
@@ -395,8 +440,9 @@ class OfflineChunkCreator:
             result["descriptors"] = fl.host["descriptors"]
             result["scores"] = fl.host["scores"]
         else:
-            for k, v in fl.dense.items():
-                result[k] = v.cpu()
+            with torch.cuda.stream(self._d2h_stream):   # not behind the next chunk's forward on the compute stream
+                for k, v in fl.dense.items():
+                    result[k] = v.cpu()
         if cam:
             result["intrinsics"] = cam.get("intrinsics")
         return result

@@ -289,7 +289,7 @@ class Pi3Engine:
                 self.forward(static_in)
                 torch.cuda.synchronize(self.device)
                 graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph):
+                with torch.cuda.graph(graph, capture_error_mode="thread_local"):   # other threads may allocate meanwhile
                     static_out = self.forward(static_in)
             finally:
                 self._pinning = False

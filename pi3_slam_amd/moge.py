@@ -596,7 +596,7 @@ class MoGeEngine:
             self.infer(static_in, resolution_level=resolution_level)        # allocates the cached tables
             torch.cuda.synchronize(self.device)
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"):   # other threads may allocate meanwhile
                 static_out = self.infer(static_in, resolution_level=resolution_level)
             graphs[key] = (graph, static_in, static_out)
         graph, static_in, static_out = graphs[key]

@@ -75,19 +75,19 @@ def pack_boundary(chunk: Dict[str, torch.Tensor], overlap: int, K: int, device="
     ov = min(overlap, n)
 
     def blk(sl):
-        kp = chunk["keypoints"][sl].to(torch.float16).contiguous().view(torch.int16).to(torch.float32)
-        pt = chunk["points"][sl].to(torch.float32).contiguous()   # fp16 file values are exact in fp32; refined ones stay fp32
-        mk = chunk["masks"][sl].reshape(-1).to(torch.float32)
-        out = torch.zeros(overlap * K * 6, device=device)
-        kp, pt, mk = kp.to(device), pt.to(device), mk.to(device)
-        out[: ov * K * 2] = kp.reshape(-1)
-        out[overlap * K * 2: overlap * K * 2 + ov * K * 3] = pt.reshape(-1)
-        out[overlap * K * 5: overlap * K * 5 + ov * K] = mk
+        out = torch.zeros(overlap * K * 6)
+        out[: ov * K * 2] = (chunk["keypoints"][sl].to(torch.float16).contiguous().view(torch.int16)
+                             .to(torch.float32).reshape(-1))
+        # fp16 file values are exact in fp32; refined ones stay fp32
+        out[overlap * K * 2: overlap * K * 2 + ov * K * 3] = chunk["points"][sl].to(torch.float32).reshape(-1)
+        out[overlap * K * 5: overlap * K * 5 + ov * K] = chunk["masks"][sl].reshape(-1).to(torch.float32)
         return out
 
-    head, tail = blk(slice(0, ov)), blk(slice(n - ov, n))
-    pose = chunk["camera_poses"][n - 1].reshape(-1).to(device, torch.float32)
-    return torch.cat([torch.tensor([float(n)], device=device), head, tail, pose])
+    # assembled on the host, one pinned asynchronous upload (alignment.upload): nothing here waits for the device
+    flat = torch.cat([torch.tensor([float(n)]), blk(slice(0, ov)), blk(slice(n - ov, n)),
+                      chunk["camera_poses"][n - 1].reshape(-1).to(torch.float32).cpu()])
+    from .alignment import upload
+    return upload(flat, device)
 
 
 def boundary_numel(overlap: int, K: int) -> int:
@@ -132,14 +132,16 @@ def relative_sim3_from_boundaries(prev: Dict, cur: Dict, overlap: int, device, u
     pairs = [(i + d, i) for i in range(overlap) if 0 <= i + d < ov_p and i < min(overlap, n_cur)]
     if not pairs:
         raise ValueError("no overlapping views between the two chunks")
-    ri = torch.tensor([r for r, _ in pairs], dtype=torch.long)
-    qi = torch.tensor([q for _, q in pairs], dtype=torch.long)
+    # the pairs are one run of consecutive views on both sides: slices, no index tensor to upload
+    ri = slice(pairs[0][0], pairs[0][0] + len(pairs))
+    qi = slice(pairs[0][1], pairs[0][1] + len(pairs))
+    from .alignment import upload
     ref, qry = prev["tail"], cur["head"]
-    kp_r = ref["keypoints"][ri].to(device).contiguous()
-    kp_q = qry["keypoints"][qi].to(device).contiguous()
+    kp_r = upload(ref["keypoints"][ri], device).contiguous()
+    kp_q = upload(qry["keypoints"][qi], device).contiguous()
     idx = ops.sim3_match_keypoints(kp_r, kp_q)
-    return ops.sim3_umeyama(ref["points"][ri].to(device).contiguous(), qry["points"][qi].to(device).contiguous(),
-                            idx, prev["last_pose"].to(device, torch.float32).contiguous(), None, None, use_filter)
+    return ops.sim3_umeyama(upload(ref["points"][ri], device).contiguous(), upload(qry["points"][qi], device).contiguous(),
+                            idx, upload(prev["last_pose"], device, torch.float32).contiguous(), None, None, use_filter)
 
 
 def compose_global(rel: torch.Tensor) -> torch.Tensor:
@@ -153,13 +155,20 @@ def default_solver(overlap: int, device, chunk_length: Optional[int]):
     """solve(prev_block, cur_block) -> f64 [17] = [accepted, T(16)] on `device`, with the device kernels."""
     from .alignment import sim3_accepted
 
+    eye = {}
+
     def solve(prev: Dict, cur: Dict) -> torch.Tensor:
         out = relative_sim3_from_boundaries(prev, cur, overlap, device, chunk_length=chunk_length)
-        ok = sim3_accepted(out.cpu())
-        res = torch.zeros(17, dtype=torch.float64, device=device)
-        res[0] = 1.0 if ok else 0.0
-        res[1:] = out[13:29] if ok else torch.eye(4, dtype=torch.float64, device=device).reshape(16)
-        return res
+        if out.device.type == "cpu":
+            ok = sim3_accepted(out)
+            return torch.cat([torch.tensor([1.0 if ok else 0.0], dtype=torch.float64),
+                              out[13:29] if ok else torch.eye(4, dtype=torch.float64).reshape(16)])
+        # the acceptance rule of alignment.sim3_accepted evaluated on the device: the record goes straight into the
+        # all-gather, the host reads it once for the whole wave
+        if "I" not in eye:
+            eye["I"] = torch.eye(4, dtype=torch.float64, device=out.device).reshape(16)
+        ok = (out[29] >= 3) & torch.isfinite(out[:29]).all()
+        return torch.cat([ok.to(torch.float64).reshape(1), torch.where(ok, out[13:29], eye["I"])])
     return solve
 
 
@@ -174,13 +183,14 @@ def align_wave(rank: int, world: int, w0: int, n_chunks: int, blocks: List[Dict]
     Failure policy (same as the sequential path and the reference, offline_reconstructor.py:100-102): a chunk whose
     solve is rejected stays in its own frame, G_c = I, and the chunks after it chain onto it.
     Returns ([G_c for the chunks of this wave] as f64 4x4 CPU tensors, [accepted flags])."""
+    from .alignment import upload
     c = w0 + rank
-    mine = torch.zeros(17, dtype=torch.float64, device=comm_device)
-    mine[0] = 1.0
-    mine[1:] = torch.eye(4, dtype=torch.float64).reshape(16).to(comm_device)
     pred = blocks[rank - 1] if rank > 0 else prev_tail
     if c < n_chunks and pred is not None:
-        mine = solve(pred, blocks[rank]).to(comm_device)
+        mine = upload(solve(pred, blocks[rank]), comm_device)
+    else:
+        mine = upload(torch.cat([torch.ones(1, dtype=torch.float64), torch.eye(4, dtype=torch.float64).reshape(16)]),
+                      comm_device)
     rel = [torch.empty_like(mine) for _ in range(world)]
     dist.all_gather(rel, mine.contiguous())
     n_wave = min(world, n_chunks - w0)
@@ -196,9 +206,9 @@ def align_wave(rank: int, world: int, w0: int, n_chunks: int, blocks: List[Dict]
         nonlocal base, pending
         if pending:
             stack = torch.stack([base.reshape(16)] + pending).contiguous()
-            out = compose(stack) if compose is not None else _prefix_cpu(stack)
+            out = (compose(stack) if compose is not None else _prefix_cpu(stack)).cpu()
             for g in out[1:]:
-                Gs.append(g.reshape(4, 4).cpu())
+                Gs.append(g.reshape(4, 4).clone())
             base, pending = Gs[-1], []
 
     for r in range(n_wave):
@@ -235,7 +245,8 @@ class WaveAligner:
         if solve is None:
             from . import ops
             solve = default_solver(overlap, device, chunk_length)
-            compose = lambda T: ops.sim3_compose_prefix(T.to(device))   # noqa: E731
+            from .alignment import upload
+            compose = lambda T: ops.sim3_compose_prefix(upload(T, device))   # noqa: E731
         self.solve, self.compose = solve, compose
         self.G_last = torch.eye(4, dtype=torch.float64)
         self.prev_tail: Optional[Dict] = None
@@ -243,8 +254,9 @@ class WaveAligner:
     def step(self, chunk: Optional[Dict], w0: int, n_chunks: int) -> Tuple[List[torch.Tensor], List[bool]]:
         """chunk: this rank's chunk dict (chunk index w0 + rank) or None.  Collectives: sizes (2 ints per rank), boundary
         blocks (~50 KB per rank), [accepted, T] records (136 B per rank)."""
-        sz = torch.tensor([int(chunk["keypoints"].shape[1]), int(chunk["points"].shape[0])] if chunk is not None
-                          else [0, 0], device=self.comm_dev)
+        from .alignment import upload
+        sz = upload(torch.tensor([int(chunk["keypoints"].shape[1]), int(chunk["points"].shape[0])] if chunk is not None
+                                 else [0, 0]), self.comm_dev)
         szs = [torch.zeros_like(sz) for _ in range(self.world)]
         dist.all_gather(szs, sz)
         szs = [t.tolist() for t in szs]
@@ -252,7 +264,7 @@ class WaveAligner:
         if chunk is not None:
             local = pack_boundary(chunk, self.overlap, K, device=self.comm_dev)
         else:   # ragged last wave: an empty block (n_frames = 0)
-            local = torch.zeros(boundary_numel(self.overlap, K), device=self.comm_dev)
+            local = torch.zeros(boundary_numel(self.overlap, K), device=self.comm_dev)   # a fill kernel, no copy
         blocks = [unpack_boundary(b, self.overlap, K, n_frames=szs[r][1])
                   for r, b in enumerate(allgather_boundaries(local, self.comm_dev))]
         Gs, oks = align_wave(self.rank, self.world, w0, n_chunks, blocks, self.prev_tail, self.G_last, self.solve,

@@ -262,19 +262,24 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
 
   const int nbm = (p.M + G2_BM - 1) / G2_BM, nbn = p.N / G2_BN;
   const int nwg = nbm * nbn;
-  const int id = xcd_remap(blockIdx.x, nwg);
+  const char* Ab = (const char*)p.A;
+  const char* Wb = (const char*)p.W;
+  const long lda_b = p.lda * 2, ldw_b = p.ldw * 2;
+  const int nk = p.K >> 6;
   const int GM = p.tile_gm > 0 ? p.tile_gm : 8;
   const int per_group = GM * nbn;
+
+  // Persistent form: the grid is one workgroup per CU (a multiple of 8, so a workgroup stays on its XCD) and every
+  // workgroup walks the tiles vb = blockIdx.x, + gridDim.x, ... - the order a tile-per-workgroup launch dispatches them
+  // in.  The output stores of tile i are still in flight while the LDS-DMA prologue of tile i + 1 is issued, and the
+  // per-workgroup launch / drain latency is paid once per kernel.  gridDim.x = nwg gives the tile-per-workgroup form.
+  for (int vb = blockIdx.x; vb < nwg; vb += gridDim.x) {
+  const int id = xcd_remap(vb, nwg);
   const int g = id / per_group;
   const int gm = min(GM, nbm - g * GM);
   const int rem = id - g * per_group;
   const int bm = g * GM + rem % gm;
   const int bn = rem / gm;
-
-  const char* Ab = (const char*)p.A;
-  const char* Wb = (const char*)p.W;
-  const long lda_b = p.lda * 2, ldw_b = p.ldw * 2;
-  const int nk = p.K >> 6;
 
   f32x4 acc[4][8];
 #pragma unroll
@@ -393,6 +398,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
     else
       gemm_epilogue<OUT_BF16, ACT, 4, 8>(p, acc, bm * G2_BM + wm * 128, bn * G2_BN + wn * 64, lane);
   }
+  // the next tile's prologue overwrites the LDS the epilogue transposes went through: every wave must be out of them
+  if (vb + (int)gridDim.x < nwg) { PHASE_END() }
+  }   // tiles of this workgroup
 }
 
 template <bool OUT_BF16, int ACT, bool NOEPI = false, bool STAG = false, bool QK = false>
@@ -404,7 +412,19 @@ static int launch256(const GemmParams& p, hipStream_t stream) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS_TOTAL);
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, dim3(nbm * nbn), dim3(512), G2_LDS_TOTAL, stream, p);
+  static int persist = -1, ncu = 0;     // PI3_GEMM_PERSIST: 1 (default) one workgroup per CU walking tiles | 0 a workgroup per tile
+  if (persist < 0) {
+    const char* e = getenv("PI3_GEMM_PERSIST");
+    persist = e ? atoi(e) : 1;
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+      ncu = prop.multiProcessorCount & ~7;
+    if (ncu <= 0) ncu = 256;
+  }
+  const int nwg = nbm * nbn;
+  const int grid = (persist && nwg > ncu) ? ncu : nwg;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), G2_LDS_TOTAL, stream, p);
   return pi3_check_launch("gemm256");
 }
 

@@ -338,3 +338,43 @@ def test_online_sliding_window_matches_offline_two_stage(tmp_path, built_lib):
     # the offline flow stores chunks as fp16 / reloads them; the online one aligns the same tensors in memory
     assert np.abs(t_on - t_off).max() < 1e-4
     assert "pi3_forward" in slam.get_timing_statistics() and os.path.getsize(tmp_path / "online" / "points.ply") > 0
+
+
+def test_consumer_side_alignment_does_not_wait_for_the_running_forward(built_lib):
+    """Pipeline rule: no host<->device copy is ever queued behind a forward, so the consumer's Sim(3)
+    alignment of chunk k-1 and the stage-in of chunk k+1 run BESIDE the forward of chunk k.  Before the rule held, the
+    alignment's first upload returned only when the running forward ended (~60 % of a forward per chunk on average)
+    and a stage-in took 80-180 ms instead of ~2 ms.  Full-size model so that a forward is long enough to tell."""
+    import time
+    from pi3_slam_amd.alignment import align_and_refine_reconstructions, create_view_graph_matches
+    from pi3_slam_amd.chunk_creator import OfflineChunkCreator, OfflineCreatorConfig
+    from pi3_slam_amd.engine import Pi3Engine
+    from pi3_slam_amd.weights import Pi3Config
+    dev = "cuda:0"
+    engine = Pi3Engine(Pi3Config(), dev)
+    n, ov = 60, 12
+    cfg = OfflineCreatorConfig(model_path="recipe", output_dir="/tmp/pi3_test_unused", chunk_length=n, overlap=ov, device=dev,
+                               do_metric_depth=False, keypoint_type="grid", max_num_keypoints=200, device_resize=True)
+    cr = OfflineChunkCreator(cfg, model=engine, moge_model=None)
+    cr.target_size = (308, 406)
+    frames = torch.randint(0, 256, (n, 384, 512, 3), dtype=torch.uint8).pin_memory()
+    paths = [[f"f{i}.png"] for i in range(n)]
+    matches = create_view_graph_matches(n, ov)
+    side = torch.cuda.Stream(dev, priority=-1)
+    items = ({"frames": frames, "kind": "u8", "paths": paths, "meta": {"chunk_index": i}} for i in range(7))
+    prev, waits, forwards, stage = None, [], [], []
+    for meta, chunk in cr.process_chunks(items):
+        if prev is not None:
+            t0 = time.perf_counter()
+            with torch.cuda.stream(side):
+                ok, _ = align_and_refine_reconstructions(prev, chunk, matches, device=dev)
+            waits.append(time.perf_counter() - t0)
+            assert ok
+        forwards.append(chunk["_metrics"]["infer_s"])
+        stage.append(chunk["_metrics"].get("stage_in_s", 0.0))
+        prev = chunk
+    fwd = float(np.median(forwards))
+    assert fwd > 0.1                                   # the premise: a forward long enough to hide behind
+    # steady state (the first two chunks include first-use allocations and table builds)
+    assert max(waits[2:]) < 0.25 * fwd, (waits, fwd)
+    assert max(stage[2:]) < 0.25 * fwd, (stage, fwd)

@@ -285,11 +285,18 @@ __global__ __launch_bounds__(BA_MAXN) void ba_schur_rows(BaProblem pb, const dou
   }
   const bool lane_cam = kp < N;
   const int s0 = (N * slice) / BA_SLICES, s1 = (N * (slice + 1)) / BA_SLICES;
-  for (int s = s0; s < s1; ++s) {
-    for (int k = 0; k < K; ++k) {
-      const long i = (long)s * K + k;
+  // tracks of the slice, 64 at a time: each lane tests one track for an observation by camera j, the ballot is the
+  // list of tracks to work on (both waves of the workgroup scan the same 64 tracks and walk the same bits, in
+  // ascending track order: the sums keep the order a sequential walk gives them)
+  const long i0 = (long)s0 * K, i1 = (long)s1 * K;
+  for (long base = i0; base < i1; base += 64) {
+    const long il = base + (kp & 63);
+    unsigned long long seen = __ballot(il < i1 && pb.validT[il * N + j] != 0);
+    while (seen) {
+      const int bit = __builtin_ctzll(seen);
+      seen &= seen - 1;
+      const long i = base + bit;
       const long oj = i * N + j;
-      if (!pb.validT[oj]) continue;                               // uniform over the workgroup
       const double X[3] = {pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]};
       double Ci[6], D[3];
       if (!ba_point_inverse(Cblk + 6 * i, radius, Ci, D)) continue;
@@ -340,96 +347,194 @@ __global__ __launch_bounds__(BA_MAXN) void ba_schur_rows(BaProblem pb, const dou
     for (int a = 0; a < 6; ++a) rhs_part[((long)slice * N + j) * 6 + a] = rj[a];
 }
 
-// ---- pass 4: assemble S = sum of slices + B + D, rhs = -(g_c - sum slices); one WG; then Cholesky + solves (in place)
-__global__ __launch_bounds__(1024) void ba_solve_cameras(int N, const double* __restrict__ S_part,
-                                                         const double* __restrict__ rhs_part,
-                                                         const double* __restrict__ Bblk, const double* __restrict__ gc,
-                                                         double* __restrict__ S, double* __restrict__ dcam,
-                                                         double* __restrict__ Dcam, BaState* st) {
-  __shared__ double colbuf[6 * BA_MAXN];
-  __shared__ double piv;
-  __shared__ int fail;
-  const int tid = threadIdx.x, n = 6 * N;
+// ---- pass 4: the reduced camera system.  S = sum of slices + B + D (lower triangle used), rhs = -(g_c - sum slices),
+// then a BLOCKED right-looking Cholesky (panels of BA_NB columns: factor the diagonal block in LDS, solve the panel rows
+// against it, rank-BA_NB update of the trailing matrix by a grid of tiles) and blocked triangular solves.  The factor
+// goes to its own array L, S is only ever updated below the current panel.  (The first version factored column by
+// column in one workgroup with the matrix in L2: 22 ms of the 34 ms an iteration took at N = 100.)
+#define BA_NB 48
+
+__global__ __launch_bounds__(256) void ba_assemble_cameras(int N, const double* __restrict__ S_part,
+                                                           const double* __restrict__ rhs_part,
+                                                           const double* __restrict__ Bblk, const double* __restrict__ gc,
+                                                           double* __restrict__ S, double* __restrict__ dcam,
+                                                           double* __restrict__ Dcam, BaState* st) {
   if (st->done != 0.0) return;
-  const double radius = st->radius;
-  for (long e = tid; e < (long)n * n; e += 1024) {
+  const int n = 6 * N;
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e == 0) st->chol_fail = 0.0;
+  if (e < (long)n * n) {
+    const int r = (int)(e / n), c = (int)(e - (long)r * n);
     double v = 0.0;
     for (int sl = 0; sl < BA_SLICES; ++sl) v += S_part[(long)sl * n * n + e];
+    if (r / 6 == c / 6) {      // + B_t (symmetric, packed upper) + the LM diagonal
+      const int t = r / 6, a6 = r - 6 * t, b6 = c - 6 * t;
+      const int p = a6 < b6 ? a6 : b6, q = a6 < b6 ? b6 : a6;
+      double bv = Bblk[21 * t + p * 6 - p * (p - 1) / 2 + (q - p)];
+      if (a6 == b6) {
+        const double d = fmin(fmax(bv, 1e-6), 1e32) / st->radius;
+        Dcam[r] = d;
+        bv += d;
+      }
+      v += bv;
+    }
     S[e] = v;
   }
-  __syncthreads();
-  for (int e = tid; e < N * 36; e += 1024) {      // + B_t (symmetric, packed upper) + LM diagonal on the block diagonal
-    const int t = e / 36, a = (e % 36) / 6, b = e % 6;
-    const int p = a < b ? a : b, q = a < b ? b : a;
-    const int idx = p * 6 - p * (p - 1) / 2 + (q - p);
-    double v = Bblk[21 * t + idx];
-    if (a == b) {
-      const double d = fmin(fmax(v, 1e-6), 1e32) / radius;
-      Dcam[6 * t + a] = d;
-      v += d;
-    }
-    S[(long)(6 * t + a) * n + 6 * t + b] += v;
-  }
-  for (int e = tid; e < n; e += 1024) {
+  if (e < n) {
     double v = 0.0;
     for (int sl = 0; sl < BA_SLICES; ++sl) v += rhs_part[(long)sl * n + e];
     dcam[e] = -(gc[e] - v);
   }
+}
+
+// diagonal block [c0, c0 + nb) of S -> its Cholesky factor in L (one workgroup, block in LDS)
+__global__ __launch_bounds__(256) void ba_chol_diag(int n, int c0, int nb, const double* __restrict__ S,
+                                                    double* __restrict__ L, BaState* st) {
+  __shared__ double blk[BA_NB][BA_NB + 1];
+  __shared__ int fail;
+  const int tid = threadIdx.x;
+  if (st->done != 0.0 || st->chol_fail != 0.0) return;
+  for (int e = tid; e < nb * nb; e += 256) {
+    const int i = e / nb, j = e - i * nb;
+    blk[i][j] = j <= i ? S[(long)(c0 + i) * n + c0 + j] : 0.0;
+  }
   if (tid == 0) fail = 0;
   __syncthreads();
-  // right-looking Cholesky, lower triangle, column by column (n <= 768; the matrix lives in L2)
-  for (int c = 0; c < n; ++c) {
-    if (tid == 0) {
-      const double d = S[(long)c * n + c];
-      if (!(d > 0.0)) fail = 1;
-      piv = sqrt(d > 0.0 ? d : 1.0);
+  for (int c = 0; c < nb; ++c) {
+    const double d = blk[c][c];
+    if (!(d > 0.0)) {                 // every thread reads the same value: a uniform exit
+      if (tid == 0) fail = 1;
+      break;
     }
+    const double ip = 1.0 / sqrt(d);
     __syncthreads();
-    if (fail) break;
-    const double ip = 1.0 / piv;
-    for (int r = c + tid; r < n; r += 1024) {
-      const double v = S[(long)r * n + c] * ip;
-      S[(long)r * n + c] = v;
-      colbuf[r] = v;
-    }
+    for (int r = c + tid; r < nb; r += 256) blk[r][c] = (r == c) ? sqrt(d) : blk[r][c] * ip;
     __syncthreads();
-    // trailing update S[r][q] -= L[r][c] L[q][c] for c < q <= r
-    const int m = n - c - 1;
-    for (long e = tid; e < (long)m * m; e += 1024) {
-      const int r = c + 1 + (int)(e / m), q = c + 1 + (int)(e % m);
-      if (q <= r) S[(long)r * n + q] -= colbuf[r] * colbuf[q];
+    const int m = nb - c - 1;
+    for (int e = tid; e < m * m; e += 256) {
+      const int r = c + 1 + e / m, q = c + 1 + e % m;
+      if (q <= r) blk[r][q] -= blk[r][c] * blk[q][c];
     }
     __syncthreads();
   }
+  __syncthreads();
   if (fail) {
     if (tid == 0) st->chol_fail = 1.0;
+    return;
+  }
+  for (int e = tid; e < nb * nb; e += 256) {
+    const int i = e / nb, j = e - i * nb;
+    if (j <= i) L[(long)(c0 + i) * n + c0 + j] = blk[i][j];
+  }
+}
+
+// rows below the diagonal block: L[r][c0 + j] = (S[r][c0 + j] - sum_{k<j} L[r][c0 + k] L11[j][k]) / L11[j][j]
+__global__ __launch_bounds__(64) void ba_chol_panel(int n, int c0, int nb, const double* __restrict__ S,
+                                                    double* __restrict__ L, const BaState* st) {
+  __shared__ double l11[BA_NB][BA_NB + 1];
+  __shared__ double xs[64][BA_NB + 1];
+  const int tid = threadIdx.x;
+  if (st->done != 0.0 || st->chol_fail != 0.0) return;
+  for (int e = tid; e < nb * nb; e += 64) {
+    const int i = e / nb, j = e - i * nb;
+    l11[i][j] = j <= i ? L[(long)(c0 + i) * n + c0 + j] : 0.0;
+  }
+  __syncthreads();
+  const int r = c0 + nb + blockIdx.x * 64 + tid;
+  if (r >= n) return;
+  for (int j = 0; j < nb; ++j) {
+    double v = S[(long)r * n + c0 + j];
+    for (int k = 0; k < j; ++k) v -= xs[tid][k] * l11[j][k];
+    v /= l11[j][j];
+    xs[tid][j] = v;
+    L[(long)r * n + c0 + j] = v;
+  }
+}
+
+// trailing update S[r][q] -= sum_k L[r][c0 + k] L[q][c0 + k] for c0 + nb <= q <= r: one 48 x 48 tile per workgroup
+__global__ __launch_bounds__(256) void ba_chol_update(int n, int c0, int nb, double* __restrict__ S,
+                                                      const double* __restrict__ L, const BaState* st) {
+  __shared__ double lr[BA_NB][BA_NB + 1], lq[BA_NB][BA_NB + 1];
+  const int tid = threadIdx.x;
+  if (blockIdx.x > blockIdx.y) return;       // tiles above the diagonal
+  if (st->done != 0.0 || st->chol_fail != 0.0) return;
+  const int t0 = c0 + nb, r0 = t0 + blockIdx.y * BA_NB, q0 = t0 + blockIdx.x * BA_NB;
+  for (int e = tid; e < BA_NB * nb; e += 256) {
+    const int i = e / nb, k = e - i * nb;
+    lr[i][k] = r0 + i < n ? L[(long)(r0 + i) * n + c0 + k] : 0.0;
+    lq[i][k] = q0 + i < n ? L[(long)(q0 + i) * n + c0 + k] : 0.0;
+  }
+  __syncthreads();
+  for (int e = tid; e < BA_NB * BA_NB; e += 256) {
+    const int i = e / BA_NB, j = e - i * BA_NB;
+    const int r = r0 + i, q = q0 + j;
+    if (r >= n || q > r) continue;
+    double acc = 0.0;
+    for (int k = 0; k < nb; ++k) acc += lr[i][k] * lq[j][k];
+    S[(long)r * n + q] -= acc;
+  }
+}
+
+// L y = rhs, L^T x = y, panel by panel; the solution lives in LDS, the diagonal blocks pass through LDS too
+__global__ __launch_bounds__(1024) void ba_chol_solve(int n, const double* __restrict__ L, double* __restrict__ dcam,
+                                                      const BaState* st) {
+  __shared__ double x[6 * BA_MAXN];
+  __shared__ double blk[BA_NB][BA_NB + 1];
+  const int tid = threadIdx.x;
+  if (st->done != 0.0) return;
+  if (st->chol_fail != 0.0) {
     for (int e = tid; e < n; e += 1024) dcam[e] = 0.0;
     return;
   }
-  if (tid == 0) st->chol_fail = 0.0;
-  // forward / backward substitution by one wave; the solution vector lives in LDS (DS operations of one wave execute
-  // in program order, so lane 0's write of x[r] is seen by every lane's reads in the next step)
+  for (int e = tid; e < n; e += 1024) x[e] = dcam[e];
   __syncthreads();
-  for (int e = tid; e < n; e += 1024) colbuf[e] = dcam[e];
-  __syncthreads();
-  if (tid < 64) {
-    for (int r = 0; r < n; ++r) {
-      double acc = 0.0;
-      for (int q = tid; q < r; q += 64) acc += S[(long)r * n + q] * colbuf[q];
-      acc = wave_sum_f64(acc);
-      if (tid == 0) colbuf[r] = (colbuf[r] - acc) / S[(long)r * n + r];
-      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  for (int c0 = 0; c0 < n; c0 += BA_NB) {               // forward
+    const int nb = min(BA_NB, n - c0);
+    for (int e = tid; e < nb * nb; e += 1024) {
+      const int i = e / nb, j = e - i * nb;
+      blk[i][j] = j <= i ? L[(long)(c0 + i) * n + c0 + j] : 0.0;
     }
-    for (int r = n - 1; r >= 0; --r) {
-      double acc = 0.0;
-      for (int q = r + 1 + tid; q < n; q += 64) acc += S[(long)q * n + r] * colbuf[q];
-      acc = wave_sum_f64(acc);
-      if (tid == 0) colbuf[r] = (colbuf[r] - acc) / S[(long)r * n + r];
-      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __syncthreads();
+    if (tid < 64) {    // one wave, in program order (DS operations of a wave execute in order)
+      for (int r = 0; r < nb; ++r) {
+        double acc = tid < r ? blk[r][tid] * x[c0 + tid] : 0.0;
+        acc = wave_sum_f64(acc);
+        if (tid == 0) x[c0 + r] = (x[c0 + r] - acc) / blk[r][r];
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+      }
     }
+    __syncthreads();
+    for (int r = c0 + nb + tid; r < n; r += 1024) {
+      double acc = 0.0;
+      for (int k = 0; k < nb; ++k) acc += L[(long)r * n + c0 + k] * x[c0 + k];
+      x[r] -= acc;
+    }
+    __syncthreads();
   }
-  __syncthreads();
-  for (int e = tid; e < n; e += 1024) dcam[e] = colbuf[e];
+  for (int c0 = ((n - 1) / BA_NB) * BA_NB; c0 >= 0; c0 -= BA_NB) {   // backward
+    const int nb = min(BA_NB, n - c0);
+    for (int e = tid; e < nb * nb; e += 1024) {
+      const int i = e / nb, j = e - i * nb;
+      blk[i][j] = j <= i ? L[(long)(c0 + i) * n + c0 + j] : 0.0;
+    }
+    __syncthreads();
+    if (tid < 64) {
+      for (int r = nb - 1; r >= 0; --r) {
+        double acc = (tid > r && tid < nb) ? blk[tid][r] * x[c0 + tid] : 0.0;
+        acc = wave_sum_f64(acc);
+        if (tid == 0) x[c0 + r] = (x[c0 + r] - acc) / blk[r][r];
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+      }
+    }
+    __syncthreads();
+    for (int r = tid; r < c0; r += 1024) {
+      double acc = 0.0;
+      for (int k = 0; k < nb; ++k) acc += L[(long)(c0 + k) * n + r] * x[c0 + k];
+      x[r] -= acc;
+    }
+    __syncthreads();
+  }
+  for (int e = tid; e < n; e += 1024) dcam[e] = x[e];
 }
 
 // ---- pass 5: back-substitution for the points and candidate parameters; model decrease partials
@@ -597,7 +702,7 @@ static inline int ba_nblk(int N, int K) { return (int)(((long)N * K + 255) / 256
 extern "C" long pi3_ba_workspace_doubles(int N, int K) {
   const long n6 = 6L * N, nk = (long)N * K;
   return 16 /*state*/ + 6 * nk + 3 * nk + 3 * nk /*pts_new*/ + 12L * N /*poses_new*/ + 21L * N + 6L * N /*gc*/ +
-         6L * N /*dcam*/ + 6L * N /*Dcam*/ + BA_SLICES * n6 * n6 + BA_SLICES * n6 + n6 * n6 + 3L * ba_nblk(N, K) +
+         6L * N /*dcam*/ + 6L * N /*Dcam*/ + BA_SLICES * n6 * n6 + BA_SLICES * n6 + 2 * n6 * n6 + 3L * ba_nblk(N, K) +
          3L * N + 64;
 }
 
@@ -632,6 +737,7 @@ extern "C" int pi3_bundle_adjust(double* points, double* poses, const double* in
   double* S_part = w; w += BA_SLICES * n6 * n6;
   double* rhs_part = w; w += BA_SLICES * n6;
   double* S = w; w += n6 * n6;
+  double* Lfac = w; w += n6 * n6;
   double* cost_part = w; w += nblk;
   double* model_part = w; w += nblk;
   double* cost_part2 = w; w += nblk;
@@ -656,7 +762,20 @@ extern "C" int pi3_bundle_adjust(double* points, double* poses, const double* in
     hipLaunchKernelGGL(ba_camera_blocks, dim3(N), dim3(256), 0, st, pb, points, poses, Bblk, gc, prior_cost, state);
     hipLaunchKernelGGL(ba_schur_rows, dim3(N, BA_SLICES), dim3(BA_MAXN), 0, st, pb, points, poses, Cblk, gp, S_part,
                        rhs_part, state);
-    hipLaunchKernelGGL(ba_solve_cameras, dim3(1), dim3(1024), 0, st, N, S_part, rhs_part, Bblk, gc, S, dcam, Dcam, state);
+    const int n = (int)n6;
+    hipLaunchKernelGGL(ba_assemble_cameras, dim3((unsigned)((n6 * n6 + 255) / 256)), dim3(256), 0, st, N, S_part, rhs_part,
+                       Bblk, gc, S, dcam, Dcam, state);
+    for (int c0 = 0; c0 < n; c0 += BA_NB) {
+      const int nb = n - c0 < BA_NB ? n - c0 : BA_NB;
+      hipLaunchKernelGGL(ba_chol_diag, dim3(1), dim3(256), 0, st, n, c0, nb, S, Lfac, state);
+      const int below = n - c0 - nb;
+      if (below > 0) {
+        hipLaunchKernelGGL(ba_chol_panel, dim3((below + 63) / 64), dim3(64), 0, st, n, c0, nb, S, Lfac, state);
+        const int nt = (below + BA_NB - 1) / BA_NB;
+        hipLaunchKernelGGL(ba_chol_update, dim3(nt, nt), dim3(256), 0, st, n, c0, nb, S, Lfac, state);
+      }
+    }
+    hipLaunchKernelGGL(ba_chol_solve, dim3(1), dim3(1024), 0, st, n, Lfac, dcam, state);
     hipLaunchKernelGGL(ba_backsub_points, dim3(nblk), dim3(256), 0, st, pb, points, poses, Cblk, gp, dcam, pts_new,
                        model_part, state);
     hipLaunchKernelGGL(ba_update_cameras, dim3((N + 63) / 64), dim3(64), 0, st, N, poses, dcam, gc, Dcam, poses_new,

@@ -20,7 +20,7 @@
 #include "common.h"
 
 #define BA_MAXN 128
-#define BA_SLICES 4
+#define BA_SLICES 32
 
 struct BaState {
   double cost, cost_new, radius, decrease, model_change, iters, accepted_steps, done, initial_cost, chol_fail, accept;
@@ -265,10 +265,41 @@ __device__ __forceinline__ bool ba_point_inverse(const double* C6, double radius
   return true;
 }
 
-// ---- pass 3: Schur complement rows.  WG (camera j, slice): lanes = cameras k'.  S_part[slice][6j+a][6k'+b] and the
-// slice's share of rhs_j = -(g_j - sum_i E_ij Cinv_i g_i).  Layout T ([s][k][t]) makes a track's cameras contiguous.
-__global__ __launch_bounds__(BA_MAXN) void ba_schur_rows(BaProblem pb, const double* __restrict__ pts,
-                                                         const double* __restrict__ poses,
+// ---- pass 3a: per observation (track i, camera t) the 6 x 3 block E_it = w Jc^T Jp of the normal equations, once per
+// iteration, in the [track][camera] layout: a track's blocks are contiguous (144 B each), which is what pass 3b reads.
+// ok[i N + t] = 1 when the observation exists and the point is in front of the camera.
+__global__ __launch_bounds__(256) void ba_obs_blocks(BaProblem pb, const double* __restrict__ pts,
+                                                     const double* __restrict__ poses, double* __restrict__ Eblk,
+                                                     uint8_t* __restrict__ ok, const BaState* st) {
+  const int N = pb.N;
+  const long o = (long)blockIdx.x * 256 + threadIdx.x;
+  if (st->done != 0.0 || o >= (long)N * pb.K * N) return;
+  const long i = o / N;
+  const int t = (int)(o - i * N);
+  uint8_t good = 0;
+  if (pb.validT[o]) {
+    const double X[3] = {pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]};
+    double r[2], Jc[2][6], Jp[2][3], w;
+    if (ba_project(poses + 12 * t, pb.intr + 4 * t, X, (double)pb.uvT[2 * o], (double)pb.uvT[2 * o + 1], r, Jc, Jp)) {
+      huber_rho(r[0] * r[0] + r[1] * r[1], pb.huber, w);
+      double* E = Eblk + 18 * o;
+#pragma unroll
+      for (int a = 0; a < 6; ++a) {
+        E[3 * a + 0] = w * (Jc[0][a] * Jp[0][0] + Jc[1][a] * Jp[1][0]);
+        E[3 * a + 1] = w * (Jc[0][a] * Jp[0][1] + Jc[1][a] * Jp[1][1]);
+        E[3 * a + 2] = w * (Jc[0][a] * Jp[0][2] + Jc[1][a] * Jp[1][2]);
+      }
+      good = 1;
+    }
+  }
+  ok[o] = good;
+}
+
+// ---- pass 3b: Schur complement rows.  WG (camera j, slice): lanes = cameras k' <= j (S is symmetric and only its lower
+// triangle is factored).  S_part[slice][6j+a][6k'+b] -= sum_i (E_ij Cinv_i) E_ik'^T and the slice's share of
+// rhs_j = -(g_j - sum_i E_ij Cinv_i g_i).  Per track of camera j: one broadcast read of E_ij, one 144-byte read per lane.
+__global__ __launch_bounds__(BA_MAXN) void ba_schur_rows(BaProblem pb, const double* __restrict__ Eblk,
+                                                         const uint8_t* __restrict__ ok,
                                                          const double* __restrict__ Cblk, const double* __restrict__ gp,
                                                          double* __restrict__ S_part, double* __restrict__ rhs_part,
                                                          const BaState* st) {
@@ -283,7 +314,8 @@ __global__ __launch_bounds__(BA_MAXN) void ba_schur_rows(BaProblem pb, const dou
 #pragma unroll
     for (int b = 0; b < 6; ++b) S[a][b] = 0.0;
   }
-  const bool lane_cam = kp < N;
+  const bool lane_cam = kp <= j;                      // lower triangle (kp < N follows from j < N)
+  const bool wave_has_cams = (kp & ~63) <= j;         // the second wave has nothing to add while j < 64 (rhs_j is wave 0's)
   const int s0 = (N * slice) / BA_SLICES, s1 = (N * (slice + 1)) / BA_SLICES;
   // tracks of the slice, 64 at a time: each lane tests one track for an observation by camera j, the ballot is the
   // list of tracks to work on (both waves of the workgroup scan the same 64 tracks and walk the same bits, in
@@ -291,26 +323,19 @@ __global__ __launch_bounds__(BA_MAXN) void ba_schur_rows(BaProblem pb, const dou
   const long i0 = (long)s0 * K, i1 = (long)s1 * K;
   for (long base = i0; base < i1; base += 64) {
     const long il = base + (kp & 63);
-    unsigned long long seen = __ballot(il < i1 && pb.validT[il * N + j] != 0);
+    unsigned long long seen = __ballot(il < i1 && ok[il * N + j] != 0);
+    if (!wave_has_cams) seen = 0;
     while (seen) {
       const int bit = __builtin_ctzll(seen);
       seen &= seen - 1;
       const long i = base + bit;
-      const long oj = i * N + j;
-      const double X[3] = {pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]};
       double Ci[6], D[3];
       if (!ba_point_inverse(Cblk + 6 * i, radius, Ci, D)) continue;
-      // E_ij = Jc^T w Jp for camera j (every lane computes it: no LDS traffic, no barrier)
-      double r[2], Jc[2][6], Jp[2][3], w;
-      if (!ba_project(poses + 12 * j, pb.intr + 4 * j, X, (double)pb.uvT[2 * oj], (double)pb.uvT[2 * oj + 1], r, Jc, Jp))
-        continue;
-      huber_rho(r[0] * r[0] + r[1] * r[1], pb.huber, w);
+      const double* Ej = Eblk + 18 * (i * N + j);     // uniform address: one broadcast load
       double Y[6][3];   // E_ij Cinv
 #pragma unroll
       for (int a = 0; a < 6; ++a) {
-        const double e0 = w * (Jc[0][a] * Jp[0][0] + Jc[1][a] * Jp[1][0]);
-        const double e1 = w * (Jc[0][a] * Jp[0][1] + Jc[1][a] * Jp[1][1]);
-        const double e2 = w * (Jc[0][a] * Jp[0][2] + Jc[1][a] * Jp[1][2]);
+        const double e0 = Ej[3 * a], e1 = Ej[3 * a + 1], e2 = Ej[3 * a + 2];
         Y[a][0] = e0 * Ci[0] + e1 * Ci[1] + e2 * Ci[2];
         Y[a][1] = e0 * Ci[1] + e1 * Ci[3] + e2 * Ci[4];
         Y[a][2] = e0 * Ci[2] + e1 * Ci[4] + e2 * Ci[5];
@@ -319,24 +344,17 @@ __global__ __launch_bounds__(BA_MAXN) void ba_schur_rows(BaProblem pb, const dou
 #pragma unroll
       for (int a = 0; a < 6; ++a) rj[a] += Y[a][0] * g0 + Y[a][1] * g1 + Y[a][2] * g2;
       // this lane's camera k'
-      if (!lane_cam) continue;
-      const long ok = i * N + kp;
-      if (!pb.validT[ok]) continue;
-      double r2[2], Jc2[2][6], Jp2[2][3], w2;
-      if (!ba_project(poses + 12 * kp, pb.intr + 4 * kp, X, (double)pb.uvT[2 * ok], (double)pb.uvT[2 * ok + 1], r2, Jc2, Jp2))
-        continue;
-      huber_rho(r2[0] * r2[0] + r2[1] * r2[1], pb.huber, w2);
+      if (!lane_cam || !ok[i * N + kp]) continue;
+      const double* Ek = Eblk + 18 * (i * N + kp);
 #pragma unroll
       for (int b = 0; b < 6; ++b) {
-        const double e0 = w2 * (Jc2[0][b] * Jp2[0][0] + Jc2[1][b] * Jp2[1][0]);
-        const double e1 = w2 * (Jc2[0][b] * Jp2[0][1] + Jc2[1][b] * Jp2[1][1]);
-        const double e2 = w2 * (Jc2[0][b] * Jp2[0][2] + Jc2[1][b] * Jp2[1][2]);
+        const double e0 = Ek[3 * b], e1 = Ek[3 * b + 1], e2 = Ek[3 * b + 2];
 #pragma unroll
         for (int a = 0; a < 6; ++a) S[a][b] -= Y[a][0] * e0 + Y[a][1] * e1 + Y[a][2] * e2;
       }
     }
   }
-  if (lane_cam) {
+  if (kp < N) {      // cameras above j: zeros (the upper triangle is never read by the factorisation)
     double* out = S_part + (long)slice * n6 * n6;
 #pragma unroll
     for (int a = 0; a < 6; ++a)
@@ -702,7 +720,7 @@ static inline int ba_nblk(int N, int K) { return (int)(((long)N * K + 255) / 256
 extern "C" long pi3_ba_workspace_doubles(int N, int K) {
   const long n6 = 6L * N, nk = (long)N * K;
   return 16 /*state*/ + 6 * nk + 3 * nk + 3 * nk /*pts_new*/ + 12L * N /*poses_new*/ + 21L * N + 6L * N /*gc*/ +
-         6L * N /*dcam*/ + 6L * N /*Dcam*/ + BA_SLICES * n6 * n6 + BA_SLICES * n6 + 2 * n6 * n6 + 3L * ba_nblk(N, K) +
+         6L * N /*dcam*/ + 6L * N /*Dcam*/ + BA_SLICES * n6 * n6 + BA_SLICES * n6 + 2 * n6 * n6 + 18 * nk * N + (nk * N + 7) / 8 + 3L * ba_nblk(N, K) +
          3L * N + 64;
 }
 
@@ -738,6 +756,8 @@ extern "C" int pi3_bundle_adjust(double* points, double* poses, const double* in
   double* rhs_part = w; w += BA_SLICES * n6;
   double* S = w; w += n6 * n6;
   double* Lfac = w; w += n6 * n6;
+  double* Eblk = w; w += 18 * nk * N;
+  uint8_t* obs_ok = (uint8_t*)w; w += (nk * N + 7) / 8;
   double* cost_part = w; w += nblk;
   double* model_part = w; w += nblk;
   double* cost_part2 = w; w += nblk;
@@ -760,7 +780,9 @@ extern "C" int pi3_bundle_adjust(double* points, double* poses, const double* in
   for (int it = 0; it < max_iters; ++it) {
     hipLaunchKernelGGL(ba_linearize_points, dim3(nblk), dim3(256), 0, st, pb, points, poses, Cblk, gp, cost_part, state);
     hipLaunchKernelGGL(ba_camera_blocks, dim3(N), dim3(256), 0, st, pb, points, poses, Bblk, gc, prior_cost, state);
-    hipLaunchKernelGGL(ba_schur_rows, dim3(N, BA_SLICES), dim3(BA_MAXN), 0, st, pb, points, poses, Cblk, gp, S_part,
+    hipLaunchKernelGGL(ba_obs_blocks, dim3((unsigned)((nk * N + 255) / 256)), dim3(256), 0, st, pb, points, poses, Eblk,
+                       obs_ok, state);
+    hipLaunchKernelGGL(ba_schur_rows, dim3(N, BA_SLICES), dim3(BA_MAXN), 0, st, pb, Eblk, obs_ok, Cblk, gp, S_part,
                        rhs_part, state);
     const int n = (int)n6;
     hipLaunchKernelGGL(ba_assemble_cameras, dim3((unsigned)((n6 * n6 + 255) / 256)), dim3(256), 0, st, N, S_part, rhs_part,

@@ -278,6 +278,9 @@ def main() -> None:
                           "note": "GPU-event times per chunk (copy stream / compute stream); stages of consecutive chunks "
                                   "overlap, so they do not add up to ms_per_step"},
         }
+        line["second_metric"] = {"metric": "7-Scenes APE", "value": None,
+                                 "note": "not measurable offline: needs the released pi3 / MoGe weights, the dataset and evo "
+                                         "(BASELINE.json; SURVEY.md §8d)"}
         if world == 1 and not args.no_extras:
             with contextlib.redirect_stdout(sys.stderr):
                 line["extras"] = extras(engine, moge, make_creator, run, dev)

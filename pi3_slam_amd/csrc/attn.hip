@@ -268,7 +268,7 @@ __global__ __launch_bounds__(256, MIN_WAVES) void attn_fwd_kernel(AttnParams p) 
 
 int pi3_attention64_launch(const void* q, const void* k, const void* v, long tok_stride, long batch_stride, void* o,
                            long o_tok_stride, long o_batch_stride, int B, int S, int H, float* k2max_ws,
-                           int k2max_ready, hipStream_t stream);
+                           int k2max_ready, int nw_req, hipStream_t stream);
 
 extern "C" int pi3_attention(const void* q, const void* k, const void* v, long tok_stride, long batch_stride,
                              void* o, long o_tok_stride, long o_batch_stride, int B, int S, int H, int head_dim,
@@ -290,7 +290,18 @@ extern "C" int pi3_attention(const void* q, const void* k, const void* v, long t
   }
   if (impl == 2 || (impl == 0 && S >= 4096))
     return pi3_attention64_launch(q, k, v, tok_stride, batch_stride, o, o_tok_stride, o_batch_stride, B, S, H,
-                                  k2max_ws, k2max_ready, (hipStream_t)stream);
+                                  k2max_ws, k2max_ready, 0, (hipStream_t)stream);
+  // frame-wise sequences (643 tokens): the 64-row kernel with four-wave workgroups (256 query rows share a staged
+  // tile, LDS-DMA staging, and - when the producer supplies max |k|^2 - the bounded-score loop) measured 8-10 % ahead
+  // of the 32-row kernel below.  PI3_ATTN_SHORT=0 keeps the 32-row kernel (A/B knob).
+  static int shortk = -1;
+  if (shortk < 0) {
+    const char* e = getenv("PI3_ATTN_SHORT");
+    shortk = e ? atoi(e) : 1;
+  }
+  if (impl == 0 && shortk && S >= 256)
+    return pi3_attention64_launch(q, k, v, tok_stride, batch_stride, o, o_tok_stride, o_batch_stride, B, S, H,
+                                  k2max_ws, k2max_ready, 4, (hipStream_t)stream);
   AttnParams p;
   p.q = (const bf16_t*)q; p.k = (const bf16_t*)k; p.v = (const bf16_t*)v;
   p.tok_stride = tok_stride; p.batch_stride = batch_stride;

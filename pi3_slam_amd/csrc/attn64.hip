@@ -460,20 +460,22 @@ int pi3_attention_knorm_launch(const void* k, long tok_stride, long batch_stride
 
 int pi3_attention64p_launch(const Attn64Params& p, long nwg, hipStream_t stream);   // attn64p.hip: software-pipelined form
 
-// Called by pi3_attention (attn.hip) for long sequences; same argument meaning.
+// Called by pi3_attention (attn.hip); same argument meaning, plus nw_req (0: the knob's choice, 4: four-wave workgroups).
 // k2max_ws: caller-provided [B*H] floats (or null -> online-max loop); k2max_ready: already filled by the producer.
 int pi3_attention64_launch(const void* q, const void* k, const void* v, long tok_stride, long batch_stride, void* o,
                            long o_tok_stride, long o_batch_stride, int B, int S, int H, float* k2max_ws,
-                           int k2max_ready, hipStream_t stream) {
+                           int k2max_ready, int nw_req, hipStream_t stream) {
   Attn64Params p;
   p.q = (const bf16_t*)q; p.k = (const bf16_t*)k; p.v = (const bf16_t*)v;
   p.tok_stride = tok_stride; p.batch_stride = batch_stride;
   p.o = (bf16_t*)o; p.o_tok_stride = o_tok_stride; p.o_batch_stride = o_batch_stride;
-  static int nw = -1;   // PI3_ATTN_NW: 4 or 8 waves per workgroup (A/B knob)
-  if (nw < 0) {
+  static int nw_knob = -1;   // PI3_ATTN_NW: 4 or 8 waves per workgroup for long sequences (A/B knob)
+  if (nw_knob < 0) {
     const char* e = getenv("PI3_ATTN_NW");
-    nw = e ? atoi(e) : 8;
+    nw_knob = e ? atoi(e) : 8;
   }
+  // nw_req = 4: the caller (short, frame-wise sequences) wants 256-row workgroups whatever the knob says
+  const int nw = nw_req == 4 ? 4 : nw_knob;
   const int qrows = nw == 8 ? 512 : 256;
   p.S = S; p.H = H; p.B = B; p.nqb = (S + qrows - 1) / qrows;
   const long nwg = (long)p.nqb * H * B;

@@ -21,9 +21,9 @@ def run_block(w: Dict[str, torch.Tensor], prefix: str, x: torch.Tensor, S: int, 
     fused = rope or qk_norm
     k2max = None
     if fused:
-        # q/k LayerNorm(64) + RoPE-2D + softmax scale (+ max |k|^2 for the long-sequence attention) ride in the qkv
+        # q/k LayerNorm(64) + RoPE-2D + softmax scale (+ max |k|^2 per (batch, head) for the attention's bounded-score loop) ride in the qkv
         # epilogue: one launch, no second pass over the packed qkv buffer
-        if attn_S >= 4096:
+        if attn_S >= 256:        # both the long-sequence and the frame-wise kernel take the bounded-score loop with it
             k2max = torch.empty(attn_B * heads, device=x.device, dtype=torch.float32)
         ops.gemm_qkv(xn, w[f"{prefix}.attn.qkv.weight"], qkv[:S], M=S, H=heads, bias=w[f"{prefix}.attn.qkv.bias"], T=T,
                      pos=pos if rope else None, cs=cs if rope else None,

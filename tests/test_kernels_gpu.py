@@ -112,6 +112,37 @@ def test_attention_deferred_rescale_branch(dev):
     assert (out.float()[17] - ref[17]).abs().max() < 2e-2 and (out.float()[600] - ref[600]).abs().max() < 2e-2
 
 
+def test_attention_32_row_kernel_multi_tile(dev):
+    """Sequences of 256 .. 4095 tokens go to the 64-row kernel with four-wave workgroups (attn.hip); the 32-row kernel
+    keeps the shorter ones.  Its multi-tile sweep, tail tile and deferred rescale are checked here with the A/B knob
+    (read once per process, hence the child process)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PI3_ATTN_SHORT="0", PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "attn32_worker.py")], env=env, capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode == 0 and "attn32 ok" in r.stdout, r.stdout + r.stderr
+
+
+def test_attention_frame_sequences_bounded_score_path(dev):
+    """Frame-wise attention (643 tokens per frame) with max |k|^2 supplied, as the fused qkv epilogue does: the 64-row
+    kernel's bounded-score loop on four-wave workgroups, one wave pushed over the bound (online-max loop)."""
+    from pi3_slam_amd import ops
+    B, S, H = 5, 643, 2
+    qkv = torch.randn(B * S, 3 * H * 64, device=dev)
+    qkv[:, :H * 64] *= ops.QSCALE * 2.0
+    qkv[S:S + 64, :64] *= 10.0                                # batch 1, head 0, first wave: over the bound
+    qkv = qkv.bfloat16()
+    k = qkv.float().view(B, S, 3, H, 64)[:, :, 1]
+    k2max = (k * k).sum(-1).amax(dim=1).reshape(-1).contiguous()          # [B][H]
+    out = torch.empty(B * S, H * 64, device=dev, dtype=torch.bfloat16)
+    ops.attention(qkv, out, B, S, H, k2max=k2max)
+    mx, mean = rel(out, attn_ref(qkv, B, S, H))
+    assert mx < 8e-3 and mean < 5e-3 and torch.isfinite(out.float()).all()
+
+
 def test_attention_linearity_in_v_full_size(dev):
     """Size-independent property at a global-attention-like size: out is linear in V for fixed q, k."""
     from pi3_slam_amd import ops

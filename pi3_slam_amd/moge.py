@@ -624,6 +624,7 @@ class MoGeEngine:
         u, v = self._uv(H, W, ar)
         fs = ops.focal_shift(pts.view(1, H, W, 3), None, u, v, mask=mask.view(1, H, W))
         depth = torch.empty(H, W, device=self.device)
+        mask_network = mask.clone()      # sigmoid(mask logit) > 0.5 alone; moge_depth also clears pixels with depth <= 0
         ops.moge_depth(pts, fs["shift"], out.get("log_metric_scale"), mask, H * W, depth)
         focal = fs["focal"]
         fx = focal / 2 * (1 + ar ** 2) ** 0.5 / ar
@@ -633,4 +634,4 @@ class MoGeEngine:
         K = self._consts["K_base"].clone()
         K[0, 0], K[1, 1] = fx[0], fy[0]
         return {"depth": depth, "mask": mask.bool(), "intrinsics": K, "points_affine": pts, "focal": focal[0],
-                "shift": fs["shift"][0]}
+                "shift": fs["shift"][0], "mask_network": mask_network.bool()}

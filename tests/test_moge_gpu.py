@@ -145,8 +145,13 @@ def test_moge_config_space_variants_against_reference_vectors(built_lib, name):
     z = out["points_affine"][..., 2].cpu().numpy()
     d = np.abs(z - g["points_affine_z"])
     assert d.mean() <= 2.0 * g["bf16err_z"][0] and d.max() <= 2.0 * g["bf16err_z"][1], (d.mean(), d.max(), g["bf16err_z"])
-    mask_ref = np.unpackbits(g["mask"])[: H * W].reshape(H, W).astype(bool)
-    assert (out["mask"].cpu().numpy() != mask_ref).mean() < 5e-3
+    # the NETWORK's mask (sigmoid > 0.5).  The final mask also drops pixels whose shifted depth is <= 0, and on these
+    # random-weight variants the shift solve is degenerate: the reference's own fp32 and bf16 runs of moge_var_elu
+    # disagree on it (shift -1.53 against 0.0, stored in the fixture), so the final mask is not a vector to compare with
+    # (the pinhole fixtures gate depth, shift and the final mask tightly).
+    mp = g["mask_prob"]
+    clear = np.abs(mp - 0.5) > 2e-3
+    assert (out["mask_network"].cpu().numpy() != (mp > 0.5))[clear].mean() < 5e-3
 
 
 def test_moge_rejects_configs_outside_the_reference():

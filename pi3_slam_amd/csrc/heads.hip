@@ -59,50 +59,72 @@ extern "C" int pi3_unpatchify_points(const float* pfeat, long ldp, const float* 
 // Camera-head tail (camera_head.py:55-72): feat [F*P][ld] fp32 is the output of the two ResConvBlocks (run as fp32
 // GEMMs).  Per frame: mean over the P patch tokens (AdaptiveAvgPool2d(1)), two Linear+ReLU (D x D), fc_t (3 x D),
 // fc_rot (9 x D), rows of the 3x3 normalised (F.normalize, eps 1e-12), SO(3) projection (rot3.h), 4x4 pose.
-// One 256-thread workgroup per frame; a wave computes one output neuron at a time (coalesced weight rows).
+// One 1024-thread workgroup per frame.  The kernel is a chain of dependent loads, so its time is set by how many are in
+// flight: the pool splits the rows over 8 phases with four float4 loads outstanding per thread, and a wave computes four
+// output neurons at a time (coalesced weight rows, 32 loads in flight) - 16 waves share a layer's neurons.
 // ---------------------------------------------------------------------------------------------------------------
 #define CAM_MAXD 1024
+#define CAM_WAVES 16
 __device__ __forceinline__ void cam_linear(const float* __restrict__ Wt, const float* __restrict__ bias,
                                            const float* vin, float* vout, int nout, int D, bool relu, int wave,
                                            int lane) {
-  for (int j = wave; j < nout; j += 4) {
-    const float* wr = Wt + (long)j * D;
-    float acc = 0.f;
-    for (int k = lane; k < D; k += 64) acc += wr[k] * vin[k];
-    acc = wave_sum(acc);
-    if (lane == 0) {
-      float v = acc + bias[j];
-      vout[j] = relu ? fmaxf(v, 0.f) : v;
+  for (int j0 = 4 * wave; j0 < nout; j0 += 4 * CAM_WAVES) {
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int k = lane; k < D; k += 64) {
+      const float x = vin[k];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (j0 + u < nout) acc[u] += Wt[(long)(j0 + u) * D + k] * x;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float a = wave_sum(acc[u]);
+      if (lane == 0 && j0 + u < nout) {
+        const float v = a + bias[j0 + u];
+        vout[j0 + u] = relu ? fmaxf(v, 0.f) : v;
+      }
     }
   }
 }
 
-__global__ __launch_bounds__(256) void camera_tail_kernel(const float* __restrict__ feat, long ld, long fstride,
-                                                          int P, int D,
-                                                          const float* w1, const float* b1, const float* w2,
-                                                          const float* b2, const float* wt, const float* bt,
-                                                          const float* wr, const float* br, float* __restrict__ poses) {
+__global__ __launch_bounds__(1024) void camera_tail_kernel(const float* __restrict__ feat, long ld, long fstride,
+                                                           int P, int D,
+                                                           const float* w1, const float* b1, const float* w2,
+                                                           const float* b2, const float* wt, const float* bt,
+                                                           const float* wr, const float* br, float* __restrict__ poses) {
   __shared__ float va[CAM_MAXD], vb[CAM_MAXD], tr[12];
+  __shared__ __attribute__((aligned(16))) float part[8][CAM_MAXD];
   const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  // AdaptiveAvgPool2d(1): eight rows in flight per thread (a single dependent chain of P loads was 1 ms of latency)
-  for (int c = tid; c < D; c += 256) {
-    float a8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    const float* col = feat + (long)f * fstride + c;
-    int p = 0;
-    for (; p + 8 <= P; p += 8) {
+  // AdaptiveAvgPool2d(1): thread = (column group of 4, row phase); partial sums per phase, added in phase order
+  const int ng = D >> 2;                       // float4 column groups (D % 4 == 0, checked on the host)
+  const int np = min(8, 1024 / ng);            // row phases
+  const int g = tid % ng, ph = tid / ng;
+  if (ph < np) {
+    f32x4 a4[4];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) a8[u] += col[(long)(p + u) * ld];
+    for (int u = 0; u < 4; ++u) a4[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const float* col = feat + (long)f * fstride + 4 * g;
+    int p = ph;
+    for (; p + 3 * np < P; p += 4 * np) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) a4[u] += *(const f32x4*)(col + (long)(p + u * np) * ld);
     }
-    for (; p < P; ++p) a8[0] += col[(long)p * ld];
-    va[c] = (((a8[0] + a8[1]) + (a8[2] + a8[3])) + ((a8[4] + a8[5]) + (a8[6] + a8[7]))) / (float)P;
+    for (; p < P; p += np) a4[0] += *(const f32x4*)(col + (long)p * ld);
+    *(f32x4*)&part[ph][4 * g] = (a4[0] + a4[1]) + (a4[2] + a4[3]);
+  }
+  __syncthreads();
+  for (int c = tid; c < D; c += 1024) {
+    float v = 0.f;
+    for (int q = 0; q < np; ++q) v += part[q][c];
+    va[c] = v / (float)P;
   }
   __syncthreads();
   cam_linear(w1, b1, va, vb, D, D, true, wave, lane);
   __syncthreads();
   cam_linear(w2, b2, vb, va, D, D, true, wave, lane);
   __syncthreads();
-  cam_linear(wt, bt, va, tr, 3, D, false, wave, lane);
-  cam_linear(wr, br, va, tr + 3, 9, D, false, wave, lane);
+  if (wave < 8) cam_linear(wt, bt, va, tr, 3, D, false, wave, lane);
+  else cam_linear(wr, br, va, tr + 3, 9, D, false, wave - 8, lane);
   __syncthreads();
   if (tid == 0) {
     double A[9], R[9];
@@ -129,11 +151,11 @@ extern "C" int pi3_camera_tail(const float* feat, long ld, long fstride, int F, 
                                const float* w2, const float* b2, const float* wt, const float* bt, const float* wr,
                                const float* br, float* poses, void* stream) {
   if (!feat || !w1 || !b1 || !w2 || !b2 || !wt || !bt || !wr || !br || !poses || F <= 0 || P <= 0 || D <= 0 ||
-      D > CAM_MAXD) {
-    pi3_set_error("pi3_camera_tail: bad arguments F=%d P=%d D=%d (D <= %d)", F, P, D, CAM_MAXD);
+      D > CAM_MAXD || (D % 4) || (ld % 4) || (fstride % 4) || ((uintptr_t)feat & 15)) {
+    pi3_set_error("pi3_camera_tail: bad arguments F=%d P=%d D=%d (D <= %d, D %% 4 == 0, 16-byte aligned rows)", F, P, D, CAM_MAXD);
     return PI3_ERR_ARG;
   }
-  hipLaunchKernelGGL(camera_tail_kernel, dim3(F), dim3(256), 0, (hipStream_t)stream, feat, ld, fstride, P, D, w1, b1,
+  hipLaunchKernelGGL(camera_tail_kernel, dim3(F), dim3(1024), 0, (hipStream_t)stream, feat, ld, fstride, P, D, w1, b1,
                      w2, b2, wt, bt, wr, br, poses);
   return pi3_check_launch("camera_tail");
 }

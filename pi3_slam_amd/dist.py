@@ -259,7 +259,7 @@ class WaveAligner:
                                  else [0, 0]), self.comm_dev)
         szs = [torch.zeros_like(sz) for _ in range(self.world)]
         dist.all_gather(szs, sz)
-        szs = [t.tolist() for t in szs]
+        szs = torch.stack(szs).cpu().tolist()          # one device -> host copy for the whole wave
         K = max(k for k, _ in szs)
         if chunk is not None:
             local = pack_boundary(chunk, self.overlap, K, device=self.comm_dev)

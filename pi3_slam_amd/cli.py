@@ -45,8 +45,11 @@ RECON_FLAGS: Sequence[Tuple[str, Dict]] = (
     ("--device", dict(default="cuda")),
 )
 RECON_SWITCHES = (("--save-per-chunk", "per-chunk ply files as well"),
-                  ("--use-inverse-depth", "accepted for compatibility (no bundle adjustment in this build)"),
-                  ("--save-observations", "also write the projected track observations"))
+                  ("--use-inverse-depth", "accepted for compatibility (the device bundle adjustment parametrises points in xyz)"),
+                  ("--save-observations", "also write the projected track observations"),
+                  ("--no-bundle-adjust", "closed-form Sim(3) chain only: skip the per-chunk and the prior-constrained "
+                                         "bundle adjustment (utils/chunk_reconstruction.py:188-219, "
+                                         "utils/reconstruction_alignment.py:107-171)"))
 
 
 def list_images(root: str) -> List[str]:
@@ -100,7 +103,7 @@ def run_reconstruct(a: argparse.Namespace) -> None:
     OfflineReconstructor(chunk_dir=a.chunks, output_dir=a.output, chunk_length=a.chunk_length, overlap=a.overlap,
                          max_observations_per_track=a.max_observations_per_track, save_per_chunk=a.save_per_chunk,
                          use_inverse_depth=a.use_inverse_depth, device=a.device,
-                         save_observations=a.save_observations).run()
+                         save_observations=a.save_observations, bundle_adjust=not a.no_bundle_adjust).run()
 
 
 def main(argv=None) -> None:

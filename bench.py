@@ -380,6 +380,24 @@ def extras(engine, moge, make_creator, run, dev):
             "note": "660 PNG files 512x384 (100 distinct), decoded by the loader workers, device resize, chunk files written "
                     "by the writer thread.  frames_per_s counts from the moment the first decoded chunk leaves the loader "
                     "(worker processes forked and first 100 PNGs decoded), frames_per_s_incl_loader_start from the call"}
+        # stage 2 of the offline flow (reconstruct_offline.py -> OfflineReconstructor.run, the reference's "Reconstruction
+        # FPS", slam/offline_reconstructor.py:114-125) over the chunk files just written: load, Sim(3) chain, TUM / PLY
+        from pi3_slam_amd.reconstructor import OfflineReconstructor
+        stage2 = {}
+        for tag, ba in (("closed_form_only", False), ("with_bundle_adjust", True)):
+            rec = OfflineReconstructor(os.path.join(tmp, "out"), os.path.join(tmp, "rec_" + tag), device=str(dev),
+                                       bundle_adjust=ba)
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            rec.run()
+            torch.cuda.synchronize(dev)
+            dt2 = time.perf_counter() - t0
+            stage2[tag] = {"frames_per_s": nfr / dt2, "wall_s": dt2, "chunks": len(saved)}
+        out["reconstruct_stage2"] = dict(stage2, note=(
+            "OfflineReconstructor.run over the 9 chunk files of from_disk_process_and_save (torch.load, alignment of every "
+            "chunk to its predecessor, trajectory_tum.txt + ply files).  with_bundle_adjust adds the per-chunk (10 LM "
+            "iterations) and prior-constrained (50) device bundle adjustment on recipe-weight geometry, i.e. its cost "
+            "on data it cannot improve"))
         # configs[4] on one GPU: a 4 000-frame 512x384 stream through the online sliding-window class (chunk-parallel
         # over ranks when a process group exists; here one rank), hipGraph-captured per-chunk forward, in-order results
         from pi3_slam_amd.online import Pi3SLAMOnline

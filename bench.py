@@ -266,6 +266,10 @@ def main() -> None:
                        "chunks_per_step_per_gpu": 1, "parallelism": f"chunk-parallel x{world}",
                        "timed_from": "pinned host uint8 frames (H2D + device resize inside the timed region)",
                        "moge_metric_scale_in_timed_region": moge is not None,
+                       "metric_scale_usable_chunks": sum(1 for s in stats if s.get("metric_scale") is not None),
+                       "metric_scale_note": "MoGe forward, masked ratio median and the rescale kernels run in every chunk; "
+                                            "with recipe weights frame 0's mask is usually empty (random depth is all edges), "
+                                            "the median is then NaN and the rescale applies 1.0, as the warning on stderr says",
                        "algorithmic_tflop_per_chunk": fl["total"] / 1e12},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_DENSE_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_BF16_DENSE_TFLOPS, "traffic": ATTN_TRAFFIC_BYTES,

@@ -315,7 +315,9 @@ class OfflineChunkCreator:
         mark("keypoints queued")
 
         ev["f0"].record(cur)
-        if cfg.hip_graph and hasattr(self.model, "forward_graphed"):
+        # the graph of a shape costs one eager run + one capture the first time: worth it for the nominal chunk shape, which
+        # repeats, not for the ragged last chunk of a sequence (in a 4 000-frame stream its capture was 2.6 % of the run)
+        if cfg.hip_graph and hasattr(self.model, "forward_graphed") and N == int(cfg.chunk_length):
             pi3 = self.model.forward_graphed(imgs)     # static outputs: packed below, before the next replay
         else:
             pi3 = self.model(imgs)

@@ -15,8 +15,11 @@
 // and two waves per SIMD do not cover that; prefetching the next step's 12 fragments needs 32 more registers than the
 // 256 this occupancy allows.  Prefetching only the 4 K fragments a step ahead (16 registers, still no scratch in the
 // loop) was built and measured too: 14.65 ms against 14.33 ms of the three-phase kernel on that device, i.e. slower
-// again, so the LDS round trips are not what bounds the loop either; with the clock at 1.9-2.05 GHz of 2.4 under this
-// load the kernel behaves power-limited (a denser stream is paid back in clock, MI355X_MICROARCH.md DVFS give-back).
+// again, so the LDS round trips are not what bounds the loop either.  PMC (tools/gpu_pmc_attn_pipe.sh, end of round 2):
+// this kernel and the three-phase one take the same 26.8-26.9 M cycles per XCD at the same 1.83-1.86 GHz, MFMA busy 0.68
+// in both; this one issues 5 % fewer vector instructions and waits 11 % less on instructions, and is not a cycle
+// shorter: two nearly full resources (~19 M cycles of vector issue, 18.2 M of matrix pipe per SIMD) overlapped by a
+// compiler-ordered stream.  (An earlier note here blamed a power limit; the clocks are equal, that reading was wrong.)
 // Kept behind PI3_ATTN_PIPE=1 as the starting point for a hand-scheduled stream; the
 // three-phase kernel stays the default.  Register cost is unchanged: two score
 // half-tiles (even / odd) and two packed probability half-tiles are live, exactly the 64 + 32 registers the unpipelined

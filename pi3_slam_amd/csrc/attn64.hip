@@ -51,6 +51,9 @@ struct Attn64Params {
   const float* k2max;   // [B][H] max over keys of |k|^2, or null (always online max)
   unsigned long long* dbg;   // -DPI3_ATTN_STAMPS builds only: s_memtime stamps of workgroup 0
 };
+#ifndef A64_ABL   // development builds only (-DA64_ABL=n, a separate .so): timing ablations with WRONG results.
+#define A64_ABL 0   // 1 no exp, 3 no P.V MFMAs, 4 no Q.K^T MFMAs, 5 no barrier / DMA wait, 6 no row-sum MFMAs, 7 one LDS fragment reused
+#endif
 #define A64_BOUND2 8100.0f   // (90)^2: p in [2^-90, 2^90], l <= 2^106, O <= 2^110: inside fp32 / bf16 range
 #ifdef PI3_ATTN_STAMPS
 __device__ __forceinline__ unsigned long long a64_stamp() {
@@ -109,15 +112,15 @@ __device__ __forceinline__ void a64_softmax(f32x16 (&sc)[2], float& m, f32x16 (&
         u32x4 pw;
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) {
-          const float p0 = __builtin_amdgcn_exp2f(sc[kt][8 * s2 + 2 * jj]);
-          const float p1 = __builtin_amdgcn_exp2f(sc[kt][8 * s2 + 2 * jj + 1]);
+          const float p0 = A64_ABL == 1 ? sc[kt][8 * s2 + 2 * jj] : __builtin_amdgcn_exp2f(sc[kt][8 * s2 + 2 * jj]);
+          const float p1 = A64_ABL == 1 ? sc[kt][8 * s2 + 2 * jj + 1] : __builtin_amdgcn_exp2f(sc[kt][8 * s2 + 2 * jj + 1]);
           if constexpr (!MSUM) {
             ps0 += p0;
             ps1 += p1;
           }
           pw[jj] = pack_bf16x2(p0, p1);
         }
-        if constexpr (MSUM) {
+        if constexpr (MSUM && A64_ABL != 6) {
           u32x2 lo2, hi2;
           lo2[0] = pw[0]; lo2[1] = pw[1]; hi2[0] = pw[2]; hi2[1] = pw[3];
           lacc = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(ones, __builtin_bit_cast(s16x4, lo2), lacc, 0, 0, 0);
@@ -302,8 +305,9 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd64_kernel(Attn64Params p) 
         scA[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, qfA[0], (f32x16)(0.f), 0, 0, 0);                     \
         scB[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, qfB[0], (f32x16)(0.f), 0, 0, 0);                     \
       }                                                                                                           \
+      if (A64_ABL != 4)                                                                                           \
       _Pragma("unroll") for (int s = 1; s < 4; ++s) {                                                             \
-        const int off = ((2 * s + h) ^ kswz) << 4;                                                                \
+        const int off = A64_ABL == 7 ? ((h ^ kswz) << 4) : (((2 * s + h) ^ kswz) << 4);                           \
         const bf16x8 a0 = *(const bf16x8*)(kl + off);                                                             \
         const bf16x8 a1 = *(const bf16x8*)(kl + 32 * 128 + off);                                                  \
         scA[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, qfA[s], scA[0], 0, 0, 0);                            \
@@ -320,7 +324,8 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd64_kernel(Attn64Params p) 
         const int row0 = 32 * kt + 16 * s2 + vrow_l;                                                              \
         _Pragma("unroll") for (int dt = 0; dt < 2; ++dt) {                                                        \
           const int ch = (4 * dt + vch_l) ^ vswz;                                                                 \
-          const char* a = vl + row0 * 128 + (ch << 4) + vin_l;                                                    \
+          const char* a = A64_ABL == 7 ? vl + vrow_l * 128 + (vch_l << 4) + vin_l : vl + row0 * 128 + (ch << 4) + vin_l; \
+          if (A64_ABL == 3) { asm volatile("" ::"v"(pfA[kt][s2]), "v"(pfB[kt][s2])); continue; }                  \
           const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(                                             \
               (__attribute__((address_space(3))) bf16x4*)LDS_PTR(a));                                             \
           const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(                                             \
@@ -334,9 +339,9 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd64_kernel(Attn64Params p) 
     A64_STAMP(T, 2)                                                                                               \
     if (!(LAST)) {                                                                                                \
       if constexpr (!GLDS) write_tile(buf ^ 1);                                                                   \
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                       \
+      else if (A64_ABL != 5) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                     \
       A64_STAMP(T, 3)                                                                                             \
-      __syncthreads();                                                                                            \
+      if (A64_ABL != 5) __syncthreads();                                                                          \
       A64_STAMP(T, 4)                                                                                             \
     }                                                                                                             \
   }

@@ -39,6 +39,9 @@ struct Attn64Params {
   const float* k2max;
   unsigned long long* dbg;
 };
+#ifndef P64_ABL   // development builds only (-DP64_ABL=1: no exp; timing ablation with WRONG results, never in the product .so)
+#define P64_ABL 0
+#endif
 #define P64_BOUND2 8100.0f
 #define P64_KT 64
 #define P64_THR 6.0f
@@ -62,8 +65,8 @@ __device__ __forceinline__ void p64_exp_half(const f32x16& sc, bf16x8 (&pf)[2], 
     u32x4 pw;
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj) {
-      const float p0 = __builtin_amdgcn_exp2f(sc[8 * s2 + 2 * jj]);
-      const float p1 = __builtin_amdgcn_exp2f(sc[8 * s2 + 2 * jj + 1]);
+      const float p0 = P64_ABL == 1 ? sc[8 * s2 + 2 * jj] : __builtin_amdgcn_exp2f(sc[8 * s2 + 2 * jj]);
+      const float p1 = P64_ABL == 1 ? sc[8 * s2 + 2 * jj + 1] : __builtin_amdgcn_exp2f(sc[8 * s2 + 2 * jj + 1]);
       pw[jj] = pack_bf16x2(p0, p1);
     }
     u32x2 lo2, hi2;

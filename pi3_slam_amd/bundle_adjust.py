@@ -69,11 +69,36 @@ def build_observations(chunk: Dict, W: int, H: int, max_observations_per_track: 
     return uv.contiguous(), valid.contiguous(), intr
 
 
+def sanity_gate(pts0: torch.Tensor, rc0: torch.Tensor, pts1: torch.Tensor, rc1: torch.Tensor,
+                est: torch.Tensor, est_before: Optional[torch.Tensor]) -> Optional[str]:
+    """Why a finished adjustment must NOT be taken over, or None.  Ceres reports success for any run that ends
+    without a numerical failure, and so does ba.hip; on geometry the chunk's own projections contradict (e.g. recipe
+    weights) LM walks the cameras away by many scene extents and every track ends up an outlier.  Two plain facts are
+    checked: at least three of the tracks that took part are still estimated (fewer cannot even fix a pose), and no
+    camera centre moved further than the extent of the scene (bounding-box diagonal of the input points and centres)."""
+    took_part = est_before if est_before is not None else torch.ones_like(est)
+    left = int((est & took_part).sum())
+    if int(took_part.sum()) >= 3 and left < 3:
+        return f"{left} of {int(took_part.sum())} tracks survived the outlier test"
+    finite = torch.isfinite(pts0).all(dim=1)
+    cloud = torch.cat([pts0[finite], rc0[:, 9:]], dim=0)
+    extent = float((cloud.max(dim=0).values - cloud.min(dim=0).values).norm())
+    moved = float((rc1[:, 9:] - rc0[:, 9:]).norm(dim=1).max())
+    if not moved <= extent:
+        return f"a camera moved {moved:.3g} units, the scene extent is {extent:.3g}"
+    return None
+
+
 def bundle_adjust_chunk(chunk: Dict, W: int, H: int, max_observations_per_track: int = 5, device="cuda:0",
-                        settings: Dict = PER_CHUNK, priors: Optional[Dict[int, torch.Tensor]] = None) -> Dict:
+                        settings: Dict = PER_CHUNK, priors: Optional[Dict[int, torch.Tensor]] = None,
+                        release_observations: bool = False) -> Dict:
     """Refine chunk['points'] (-> fp32) and chunk['camera_poses'] in place; chunk['track_estimated'] (N, K) bool marks
-    the tracks SetOutlierTracksToUnestimated keeps.  priors: {view index: cam->world 4x4 of the reference view}.
-    Returns {'success', 'initial_cost', 'final_cost', 'iterations', 'accepted_steps', 'removed_tracks'}."""
+    the tracks SetOutlierTracksToUnestimated keeps (cumulative: a track set to unestimated by an earlier adjustment
+    takes no part in a later one, as Theia's BundleAdjustReconstruction only adds IsEstimated() tracks).
+    priors: {view index: cam->world 4x4 of the reference view}.  release_observations: drop the cached observation
+    arrays (device memory, ~18 MB at N=100, K=200) once this adjustment is done - no later one will follow.
+    Returns {'success', 'initial_cost', 'final_cost', 'iterations', 'accepted_steps', 'removed_tracks'[, 'rejected']};
+    a result the sanity gate rejects leaves the chunk untouched and reports success=False with the reason."""
     if "keypoints" not in chunk or chunk.get("keypoints") is None:
         return {"success": False, "reason": "no keypoints"}
     N, K = chunk["points"].shape[:2]
@@ -84,8 +109,13 @@ def bundle_adjust_chunk(chunk: Dict, W: int, H: int, max_observations_per_track:
     if "_observations" not in chunk:
         chunk["_observations"] = build_observations(chunk, W, H, max_observations_per_track, device)
     uv, valid, intr = chunk["_observations"]
+    est_before = chunk.get("track_estimated")
+    if est_before is not None:       # tracks an earlier adjustment set to unestimated stay out (chunk_reconstruction.py:218
+        est_before = est_before.to(device).bool()                      # then reconstruction_alignment.py:159)
+        valid = valid & est_before[:, None, :].to(valid.dtype)
     pts = chunk["points"].to(device, torch.float64).reshape(N * K, 3).contiguous()
     rc = poses_to_rc(chunk["camera_poses"].to(device))
+    pts0, rc0 = pts.clone(), rc.clone()
     pr = pc = pf = None
     if priors:
         pr = torch.zeros(N, 9, dtype=torch.float64, device=device)
@@ -100,14 +130,24 @@ def bundle_adjust_chunk(chunk: Dict, W: int, H: int, max_observations_per_track:
     est = ops.ba_outlier_tracks(pts, rc, intr, uv, valid, settings["max_reprojection_px"],
                                 settings["min_triangulation_angle_deg"])
     s = summary.cpu()
+    if est_before is not None:
+        est = est & est_before
+    if release_observations:
+        chunk.pop("_observations", None)
     ok = bool(torch.isfinite(s[0])) and bool(torch.isfinite(pts).all()) and bool(torch.isfinite(rc).all())
+    info = {"success": ok, "initial_cost": float(s[8]), "final_cost": float(s[0]), "iterations": int(s[5]),
+            "accepted_steps": int(s[6]), "removed_tracks": int((~est).sum().item())}
+    why = sanity_gate(pts0, rc0, pts, rc, est, est_before) if ok else None
+    if why is not None:
+        print(f"   ⚠️  bundle adjustment not applied: {why}")
+        info.update(success=False, rejected=why)
+        return info
     if ok:
         dst = chunk["points"].device
         chunk["points"] = pts.reshape(N, K, 3).to(torch.float32).to(dst)
         chunk["camera_poses"] = rc_to_poses(rc).to(torch.float32).to(chunk["camera_poses"].device)
         chunk["track_estimated"] = est.to(dst)
-    return {"success": ok, "initial_cost": float(s[8]), "final_cost": float(s[0]), "iterations": int(s[5]),
-            "accepted_steps": int(s[6]), "removed_tracks": int((~est).sum().item())}
+    return info
 
 
 def overlap_priors(chunk_ref: Dict, view_graph_matches: List[Tuple[int, int]]) -> Dict[int, torch.Tensor]:

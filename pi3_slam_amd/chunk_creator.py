@@ -287,10 +287,16 @@ class OfflineChunkCreator:
             else:
                 self._moge_stream.wait_stream(cur)
             with torch.cuda.stream(self._moge_stream):
-                infer = (self.moge_model.infer_graphed
-                         if cfg.hip_graph and hasattr(self.moge_model, "infer_graphed")
-                         and os.environ.get("PI3_MOGE_GRAPH", "1") != "0" else self.moge_model.infer)
-                moge_depth = infer(imgs[0, 0])["depth"]
+                graphed = (cfg.hip_graph and hasattr(self.moge_model, "infer_graphed")
+                           and os.environ.get("PI3_MOGE_GRAPH", "1") != "0")
+                if graphed:
+                    # the graph's output is ONE static buffer, and chunk k+1's replay is queued on this stream while
+                    # chunk k's forward still runs on the compute stream (this stream waits for the stage-in only):
+                    # without a private copy, chunk k's scale would be taken from chunk k+1's first frame.
+                    # record_stream does not protect graph-pool memory, a copy does.
+                    moge_depth = self.moge_model.infer_graphed(imgs[0, 0])["depth"].clone()
+                else:
+                    moge_depth = self.moge_model.infer(imgs[0, 0])["depth"]
             moge_depth.record_stream(cur)
         mark("moge queued")
 

@@ -629,10 +629,13 @@ __global__ __launch_bounds__(256) void ba_decide(int nblk, int N, long n_pts3, c
                                                  const double* __restrict__ model_cam, int first, double* __restrict__ pts,
                                                  const double* __restrict__ pts_new, double* __restrict__ poses,
                                                  const double* __restrict__ poses_new, int max_iters, BaState* st) {
-  __shared__ double sh[2];
-  __shared__ int commit;
+  __shared__ int commit, was_done;
   const int tid = threadIdx.x;
-  if (st->done != 0.0) return;
+  // thread 0 may SET st->done further down: a wave that read it only after that store would leave before the commit
+  // copy and tear the last accepted step.  One read, shared through LDS, decides for the whole workgroup.
+  if (tid == 0) was_done = st->done != 0.0;
+  __syncthreads();
+  if (was_done) return;
   if (tid == 0) {
     double c = 0.0;
     for (int b = 0; b < nblk; ++b) c += cost_part[b];
@@ -671,7 +674,6 @@ __global__ __launch_bounds__(256) void ba_decide(int nblk, int N, long n_pts3, c
     for (long e = tid; e < n_pts3; e += 256) pts[e] = pts_new[e];
     for (int e = tid; e < 12 * N; e += 256) poses[e] = poses_new[e];
   }
-  (void)sh;
 }
 
 // ---- outlier tracks: SetOutlierTracksToUnestimated(tracks, max_reprojection_error_px, min_triangulation_angle_deg)

@@ -27,6 +27,22 @@
 #define G2_LDS (2 * G2_BUF)
 #define G2_EPI_WAVE 18432        // per-wave epilogue staging: 128 rows x 144 B (bf16) or 64 rows x 272 B (f32) <= 18 KiB
 #define G2_LDS_TOTAL (8 * G2_EPI_WAVE > G2_LDS ? 8 * G2_EPI_WAVE : G2_LDS)
+// fused q/k epilogue: the RoPE tables of the launch live in the 16 KiB of LDS above the pipeline / transpose buffers
+// (pos [T][2] int + cos/sin [npos][16][2] float, staged once per workgroup): round 2 fetched them per 16-row group with
+// two DEPENDENT global loads (position, then the table row) in front of the arithmetic.
+#define G2_TAB_BYTES 16384
+#define G2_LDS_QK (G2_LDS_TOTAL + G2_TAB_BYTES)
+
+// sum over the four 16-lane rows of a wave (lanes l, l^16, l^32, l^48), result in every lane: two VALU swaps instead of
+// two ds_bpermute round trips (the LayerNorm(64) statistic is a chain of two such sums per 16-row group)
+__device__ __forceinline__ float g2_sum_rows4(float s) {
+  unsigned u = __float_as_uint(s);
+  auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);     // {rows 0,0,2,2 | rows 1,1,3,3}
+  s = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+  u = __float_as_uint(s);
+  auto b = __builtin_amdgcn_permlane32_swap(u, u, false, false);     // {lower half twice | upper half twice}
+  return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
 
 // stage one half-tile (128 rows x 128 B) of a row-major bf16 matrix: 16 segments of 1 KiB, 2 per wave
 __device__ __forceinline__ void g2_stage_half(const char* gbase, long ld_bytes, int row0, int rows, long k_bytes,
@@ -58,7 +74,8 @@ __device__ __forceinline__ void g2_stage_half(const char* gbase, long ld_bytes, 
 // pi3_qknorm_rope pass (and the reference under autocast): the Linear output is rounded to bf16 first.
 template <bool OUT_BF16, int ACT, bool QK = false>
 __device__ __forceinline__ void g2_epilogue_lds(const GemmParams& p, f32x4 (&acc)[4][8], int m_base, int n_base,
-                                                char* wl, int lane) {
+                                                char* wl, int lane, const int* pos_l = nullptr,
+                                                const float* cs_l = nullptr) {
   const int frow = lane & 15;
   const int nq = (lane >> 4) * 4;
   // ---- fused q/k head epilogue state
@@ -82,6 +99,10 @@ __device__ __forceinline__ void g2_epilogue_lds(const GemmParams& p, f32x4 (&acc
         lnb[ni] = *(const f32x4*)(b + ni * 16 + nq);
       }
     }
+  }
+  int qk_t0 = 0;              // token index of the wave's first row (rows of a wave are consecutive tokens)
+  if constexpr (QK) {
+    if (p.qk_pos) qk_t0 = m_base % p.qk_T;
   }
   f32x4 bias4[4], gamma4[4];
 #pragma unroll
@@ -120,8 +141,7 @@ __device__ __forceinline__ void g2_epilogue_lds(const GemmParams& p, f32x4 (&acc
             float s = 0.f;
 #pragma unroll
             for (int ni = 0; ni < 4; ++ni) s += (x[ni][0] + x[ni][1]) + (x[ni][2] + x[ni][3]);
-            s += __shfl_xor(s, 16, 64);
-            s += __shfl_xor(s, 32, 64);
+            s = g2_sum_rows4(s);
             const float mean = s * (1.0f / 64.0f);
             float q = 0.f;
 #pragma unroll
@@ -131,20 +151,31 @@ __device__ __forceinline__ void g2_epilogue_lds(const GemmParams& p, f32x4 (&acc
                 x[ni][r] -= mean;
                 q += x[ni][r] * x[ni][r];
               }
-            q += __shfl_xor(q, 16, 64);
-            q += __shfl_xor(q, 32, 64);
+            q = g2_sum_rows4(q);
             const float rstd = rsqrtf(q * (1.0f / 64.0f) + p.qk_eps);
 #pragma unroll
             for (int ni = 0; ni < 4; ++ni) x[ni] = x[ni] * rstd * lnw[ni] + lnb[ni];
           }
           if (p.qk_pos) {
-            const int m = m_base + pass * ROWS_PER_PASS + mq * 16 + frow;
-            const int t = (m < p.M ? m : p.M - 1) % p.qk_T;
-            const int py = p.qk_pos[2 * t], px = p.qk_pos[2 * t + 1];
-            const float* ty = p.qk_cs + ((long)py * 16 + nq) * 2;     // (cos, sin) of freq nq .. nq+3
-            const float* tx = p.qk_cs + ((long)px * 16 + nq) * 2;
-            const f32x4 cy0 = *(const f32x4*)ty, cy1 = *(const f32x4*)(ty + 4);
-            const f32x4 cx0 = *(const f32x4*)tx, cx1 = *(const f32x4*)(tx + 4);
+            f32x4 cy0, cy1, cx0, cx1;
+            if (pos_l) {     // tables in LDS; the row's token index without a division (rows beyond M: any valid token)
+              int t = qk_t0 + pass * ROWS_PER_PASS + mq * 16 + frow;
+              if (p.qk_T >= 256) t = t >= p.qk_T ? t - p.qk_T : t;
+              else t %= p.qk_T;
+              const int py = pos_l[2 * t], px = pos_l[2 * t + 1];
+              const float* ty = cs_l + (py * 16 + nq) * 2;            // (cos, sin) of freq nq .. nq+3
+              const float* tx = cs_l + (px * 16 + nq) * 2;
+              cy0 = *(const f32x4*)ty; cy1 = *(const f32x4*)(ty + 4);
+              cx0 = *(const f32x4*)tx; cx1 = *(const f32x4*)(tx + 4);
+            } else {
+              const int m = m_base + pass * ROWS_PER_PASS + mq * 16 + frow;
+              const int t = (m < p.M ? m : p.M - 1) % p.qk_T;
+              const int py = p.qk_pos[2 * t], px = p.qk_pos[2 * t + 1];
+              const float* ty = p.qk_cs + ((long)py * 16 + nq) * 2;
+              const float* tx = p.qk_cs + ((long)px * 16 + nq) * 2;
+              cy0 = *(const f32x4*)ty; cy1 = *(const f32x4*)(ty + 4);
+              cx0 = *(const f32x4*)tx; cx1 = *(const f32x4*)(tx + 4);
+            }
             const float cyv[4] = {cy0[0], cy0[2], cy1[0], cy1[2]}, syv[4] = {cy0[1], cy0[3], cy1[1], cy1[3]};
             const float cxv[4] = {cx0[0], cx0[2], cx1[0], cx1[2]}, sxv[4] = {cx0[1], cx0[3], cx1[1], cx1[3]};
 #pragma unroll
@@ -173,8 +204,7 @@ __device__ __forceinline__ void g2_epilogue_lds(const GemmParams& p, f32x4 (&acc
             }
           }
           if (qk_part == 1 && p.qk_k2max) {
-            ksq += __shfl_xor(ksq, 16, 64);
-            ksq += __shfl_xor(ksq, 32, 64);
+            ksq = g2_sum_rows4(ksq);
             const int m = m_base + pass * ROWS_PER_PASS + mq * 16 + frow;
             if (m < p.M) {
               if (m < qk_split) k2 = fmaxf(k2, ksq);
@@ -269,6 +299,36 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
   const int GM = p.tile_gm > 0 ? p.tile_gm : 8;
   const int per_group = GM * nbn;
 
+  // fused q/k epilogue: RoPE tables -> LDS, once per workgroup (the launch passes G2_LDS_QK bytes of LDS then)
+  const int* pos_l = nullptr;
+  const float* cs_l = nullptr;
+  if constexpr (QK) {
+    if (p.qk_pos && p.qk_T * 8 + 16 <= G2_TAB_BYTES) {
+      int* scratch = (int*)(smem + G2_LDS_TOTAL);
+      int* pl = scratch + 4;
+      if (tid == 0) scratch[0] = 0;
+      __syncthreads();
+      int mx = 0;
+      for (int i = tid; i < 2 * p.qk_T; i += 512) {
+        const int v = p.qk_pos[i];
+        pl[i] = v;
+        mx = max(mx, v);
+      }
+      mx = (int)wave_max((float)mx);
+      if (lane == 0) atomicMax(scratch, mx);
+      __syncthreads();
+      const int npos = scratch[0] + 1;
+      const int tab0 = 16 + ((p.qk_T * 8 + 15) & ~15);
+      if (tab0 + npos * 128 <= G2_TAB_BYTES) {       // uniform: every thread sees the same npos
+        float* cl = (float*)(smem + G2_LDS_TOTAL + tab0);
+        for (int i = tid; i < npos * 32; i += 512) cl[i] = p.qk_cs[i];
+        pos_l = pl;
+        cs_l = cl;
+      }
+      __syncthreads();
+    }
+  }
+
   // Persistent form: the grid is one workgroup per CU (a multiple of 8, so a workgroup stays on its XCD) and every
   // workgroup walks the tiles vb = blockIdx.x, + gridDim.x, ... - the order a tile-per-workgroup launch dispatches them
   // in.  The output stores of tile i are still in flight while the LDS-DMA prologue of tile i + 1 is issued, and the
@@ -278,8 +338,11 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
   const int g = id / per_group;
   const int gm = min(GM, nbm - g * GM);
   const int rem = id - g * per_group;
-  const int bm = g * GM + rem % gm;
-  const int bn = rem / gm;
+  // order 0: consecutive ids walk the group's m-tiles first (a round of 32 ids on an XCD = GM row panels x 32 / GM
+  // column panels); order 1: the column tiles of one row panel first (the activation panel of a row is fetched by
+  // one round of workgroups of one XCD; the weight panels are the re-read operand instead)
+  const int bm = p.tile_order ? g * GM + rem / nbn : g * GM + rem % gm;
+  const int bn = p.tile_order ? rem % nbn : rem / gm;
 
   f32x4 acc[4][8];
 #pragma unroll
@@ -394,7 +457,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
     // row segments per 4 lanes straight from the accumulators, and the LDS round trip measured slower for them
     if constexpr (OUT_BF16)
       g2_epilogue_lds<OUT_BF16, ACT, QK>(p, acc, bm * G2_BM + wm * 128, bn * G2_BN + wn * 64,
-                                         smem + wave * G2_EPI_WAVE, lane);
+                                         smem + wave * G2_EPI_WAVE, lane, pos_l, cs_l);
     else
       gemm_epilogue<OUT_BF16, ACT, 4, 8>(p, acc, bm * G2_BM + wm * 128, bn * G2_BN + wn * 64, lane);
   }
@@ -408,8 +471,9 @@ static int launch256(const GemmParams& p, hipStream_t stream) {
   const int nbm = (p.M + G2_BM - 1) / G2_BM, nbn = p.N / G2_BN;
   auto kern = gemm256_kernel<OUT_BF16, ACT, NOEPI, STAG, QK>;
   static bool attr_set = false;
+  constexpr int LDS_BYTES = QK ? G2_LDS_QK : G2_LDS_TOTAL;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS_TOTAL);
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     attr_set = true;
   }
   static int persist = -1, ncu = 0;     // PI3_GEMM_PERSIST: 1 (default) one workgroup per CU walking tiles | 0 a workgroup per tile
@@ -424,7 +488,7 @@ static int launch256(const GemmParams& p, hipStream_t stream) {
   }
   const int nwg = nbm * nbn;
   const int grid = (persist && nwg > ncu) ? ncu : nwg;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), G2_LDS_TOTAL, stream, p);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), LDS_BYTES, stream, p);
   return pi3_check_launch("gemm256");
 }
 
@@ -572,6 +636,12 @@ int pi3_gemm256_try(const GemmParams& p, int out_dtype, int act, hipStream_t str
     gm_knob = e ? atoi(e) : 0;
   }
   const_cast<GemmParams&>(p).tile_gm = gm_knob;
+  static int order_knob = -1;   // PI3_GEMM_ORDER: 0 m-tiles first inside a group (default) | 1 column tiles first (A/B knob)
+  if (order_knob < 0) {
+    const char* e = getenv("PI3_GEMM_ORDER");
+    order_knob = e ? atoi(e) : 0;
+  }
+  const_cast<GemmParams&>(p).tile_order = order_knob;
   static int impl3 = -1;     // PI3_GEMM_IMPL=3: the two-workgroups-per-CU 128x256 kernel for every large GEMM (A/B knob)
   if (impl3 < 0) {
     const char* e = getenv("PI3_GEMM_IMPL");

@@ -17,6 +17,7 @@ struct GemmParams {
   // [B][cH][cW][cC] (cC % 64 == 0), row m = pixel, K = 9 * cC with k = (ky*3 + kx) * cC + ci; cW == 0 -> plain GEMM
   int cH, cW, cC;
   int tile_gm;               // gemm256: m-tiles per scheduling group (0 = default 8); consecutive ids walk a group's m-tiles
+  int tile_order;            // gemm256: 0 = m-tiles first inside a group, 1 = column tiles first
   // fused q/k epilogue of the packed qkv projection (gemm256 only; FlashAttentionRope.forward,
   // pi3/models/layers/attention.py:323-334): columns [0, H*64) = q, [H*64, 2*H*64) = k, rest = v.  For q and k heads:
   // per-head LayerNorm(64) (optional: qk_w != null), RoPE-2D (optional), softmax scale folded into q, and max_s |k|^2

@@ -11,64 +11,110 @@
 // depth_edge (pi3/utils/geometry.py:347-375): diff = maxpool3(z) + maxpool3(-z) with max_pool2d's implicit -inf
 // padding (borders use the valid neighbours only); edge = nan_to_num(diff / z) > rtol.
 // ---------------------------------------------------------------------------------------------------------------
-// One workgroup = a strip of MK_ROWS image rows of one frame.  The z channel of the strip and its two halo rows is
-// staged in LDS with fully coalesced reads of the interleaved (x, y, z) rows (the first version read 9 neighbours per
-// pixel at a 12-byte stride through the caches: 1.4 TB/s); each z is then read from HBM once (+ 2 / MK_ROWS halo).
-#define MK_ROWS 8
+// One workgroup = a strip of MK_ROWS image rows of one frame (14: 308 = 22 x 14, 280 = 20 x 14; halo re-read 2 / 14).
+// Phase 1 stages the z channel of the strip and its two halo rows in LDS from the interleaved (x, y, z) rows with
+// 16-byte loads: a float4 at strip offset s = 3 pix + r holds the z of pixel pix at lane element (2 - r) mod 3 (and a
+// second one, of pix + 1, when r == 2), and a thread's next float4 is 1024 floats on = 341 pixels + 1 float, so the
+// walk needs no division at all (round 2 read one float per instruction and did `% 3` and `/ 3` per element: 1.1 TB/s).
+// An aligned 16-byte load that holds one valid float cannot cross a page, so the ragged first / last float4 are safe.
+// Phase 2 walks the strip as ONE contiguous pixel range (full rows of a [F][H][W] array are contiguous): four
+// consecutive pixels per thread, float4 confidence load, uchar4 mask store, one row/column split per group.
+#define MK_ROWS 14
 #define MK_MAXW 1024
+
+__device__ __forceinline__ uint8_t mask_pixel(const float* zs, int ylo, int y, int x, int H, int W, float c, float thr,
+                                              float rtol) {
+  const float z = zs[(y - ylo) * W + x];
+  float mx = z, mn = z;
+  bool anynan = isnan(z);  // max_pool2d propagates NaN (a NaN in the window wins), fmaxf would drop it
+#pragma unroll
+  for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+    for (int dx = -1; dx <= 1; ++dx) {
+      const int yy = y + dy, xx = x + dx;
+      if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
+        const float v = zs[(yy - ylo) * W + xx];
+        mx = fmaxf(mx, v);
+        mn = fminf(mn, v);
+        anynan = anynan || isnan(v);
+      }
+    }
+  float ratio = anynan ? __uint_as_float(0x7fc00000u) : (mx + (-mn)) / z;
+  if (isnan(ratio)) ratio = 0.f;
+  else if (isinf(ratio)) ratio = ratio > 0.f ? FLT_MAX : -FLT_MAX;
+  const bool edge = ratio > rtol;
+  const float sg = 1.0f / (1.0f + expf(-c));
+  return (sg > thr && !edge) ? 1 : 0;
+}
+
 __global__ __launch_bounds__(256) void masks_kernel(const float* __restrict__ conf, const float* __restrict__ lp,
                                                     int F, int H, int W, float thr, float rtol,
                                                     uint8_t* __restrict__ out) {
-  __shared__ float zs[(MK_ROWS + 2) * MK_MAXW];
+  extern __shared__ __attribute__((aligned(16))) float zs[];          // (MK_ROWS + 2) * W floats
   const int strips = (H + MK_ROWS - 1) / MK_ROWS;
   const int f = blockIdx.x / strips, y0 = (blockIdx.x % strips) * MK_ROWS;
   const int tid = threadIdx.x;
   const int ylo = max(y0 - 1, 0), yhi = min(y0 + MK_ROWS + 1, H);       // staged rows [ylo, yhi)
-  const float* base = lp + ((long)f * H + ylo) * W * 3;
-  const int nfl = (yhi - ylo) * W * 3;
-  for (int e = tid; e < nfl; e += 256) {
-    const float v = base[e];
-    if (e % 3 == 2) zs[e / 3] = v;          // pixel (ylo + (e/3) / W, (e/3) % W)
+  {
+    const float* first = lp + ((long)f * H + ylo) * W * 3;
+    const uintptr_t addr = (uintptr_t)first, aligned = addr & ~(uintptr_t)15;
+    const int lead = (int)((addr - aligned) >> 2);                      // floats in front of the strip in float4 0
+    const float4* src = (const float4*)aligned;
+    const int npix = (yhi - ylo) * W;
+    const int nq = (lead + 3 * npix + 3) >> 2;
+    const int s3 = 4 * tid - lead + 3;                                  // strip offset of element 0, biased by +3 (>= 0)
+    int pix = s3 / 3 - 1, r = s3 - 3 * (s3 / 3);
+    for (int q = tid; q < nq; q += 256) {
+      const float4 v = src[q];
+      const float za = r == 0 ? v.z : (r == 1 ? v.y : v.x);
+      if (pix >= 0 && pix < npix) zs[pix] = za;
+      if (r == 2 && pix + 1 < npix) zs[pix + 1] = v.w;
+      pix += 341;                                                       // 256 threads x 4 floats = 1024 = 3 * 341 + 1
+      if (++r == 3) { r = 0; ++pix; }
+    }
   }
   __syncthreads();
   const int rows = min(MK_ROWS, H - y0);
-  for (int e = tid; e < rows * W; e += 256) {
-    const int ry = e / W, x = e - ry * W;
-    const int y = y0 + ry;
-    const float z = zs[(y - ylo) * W + x];
-    float mx = z, mn = z;
-    bool anynan = isnan(z);  // max_pool2d propagates NaN (a NaN in the window wins), fmaxf would drop it
+  const int npx = rows * W;
+  const long p0 = ((long)f * H + y0) * W;                               // first pixel of the strip, frame-linear
+  const bool vec_ok = (((uintptr_t)conf & 15) == 0) && (((uintptr_t)out & 3) == 0);
+  const int lead2 = (int)(p0 & 3);
+  const int ngroups = (lead2 + npx + 3) >> 2;
+  for (int g = tid; g < ngroups; g += 256) {
+    const int e0 = 4 * g - lead2;                                       // strip-linear index of the group's first pixel
+    const int eb = max(e0, 0);
+    int ry = eb / W, x = eb - ry * W;
+    if (vec_ok && e0 >= 0 && e0 + 4 <= npx) {
+      const float4 c = *(const float4*)(conf + p0 + e0);
+      const float cc[4] = {c.x, c.y, c.z, c.w};
+      uchar4 m;
+      uint8_t mm[4];
 #pragma unroll
-    for (int dy = -1; dy <= 1; ++dy)
-#pragma unroll
-      for (int dx = -1; dx <= 1; ++dx) {
-        const int yy = y + dy, xx = x + dx;
-        if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
-          const float v = zs[(yy - ylo) * W + xx];
-          mx = fmaxf(mx, v);
-          mn = fminf(mn, v);
-          anynan = anynan || isnan(v);
-        }
+      for (int i = 0; i < 4; ++i) {
+        mm[i] = mask_pixel(zs, ylo, y0 + ry, x, H, W, cc[i], thr, rtol);
+        if (++x >= W) { x = 0; ++ry; }
       }
-    float ratio = anynan ? __uint_as_float(0x7fc00000u) : (mx + (-mn)) / z;
-    if (isnan(ratio)) ratio = 0.f;
-    else if (isinf(ratio)) ratio = ratio > 0.f ? FLT_MAX : -FLT_MAX;
-    const bool edge = ratio > rtol;
-    const long i = ((long)f * H + y) * W + x;
-    const float sg = 1.0f / (1.0f + expf(-conf[i]));
-    out[i] = (sg > thr && !edge) ? 1 : 0;
+      m.x = mm[0]; m.y = mm[1]; m.z = mm[2]; m.w = mm[3];
+      *(uchar4*)(out + p0 + e0) = m;
+    } else {
+      for (int e = eb; e < min(e0 + 4, npx); ++e) {
+        out[p0 + e] = mask_pixel(zs, ylo, y0 + ry, x, H, W, conf[p0 + e], thr, rtol);
+        if (++x >= W) { x = 0; ++ry; }
+      }
+    }
   }
 }
 
 extern "C" int pi3_compute_masks(const float* conf, const float* local_points, int F, int H, int W, float conf_thr,
                                  float rtol, unsigned char* masks, void* stream) {
-  if (!conf || !local_points || !masks || F <= 0 || H <= 0 || W <= 0 || W > MK_MAXW) {
-    pi3_set_error("pi3_compute_masks: bad arguments (W <= %d)", MK_MAXW);
+  if (!conf || !local_points || !masks || F <= 0 || H <= 0 || W <= 0 || W > MK_MAXW ||
+      ((uintptr_t)local_points & 3) != 0) {
+    pi3_set_error("pi3_compute_masks: bad arguments (W <= %d, 4-byte aligned maps)", MK_MAXW);
     return PI3_ERR_ARG;
   }
   const long nwg = (long)F * ((H + MK_ROWS - 1) / MK_ROWS);
-  hipLaunchKernelGGL(masks_kernel, dim3((unsigned)nwg), dim3(256), 0, (hipStream_t)stream, conf, local_points, F, H, W,
-                     conf_thr, rtol, masks);
+  hipLaunchKernelGGL(masks_kernel, dim3((unsigned)nwg), dim3(256), (size_t)(MK_ROWS + 2) * W * sizeof(float),
+                     (hipStream_t)stream, conf, local_points, F, H, W, conf_thr, rtol, masks);
   return pi3_check_launch("compute_masks");
 }
 
@@ -237,10 +283,17 @@ __global__ __launch_bounds__(256) void gather_keypoints_kernel(
   const float kx = kps[2 * i], ky = kps[2 * i + 1];
   const Bil b = bil_setup(kx, ky, H, W);
   const long fo = (long)f * H * W;
+  // The fp32 value must exist before it is rounded to fp16, as in the reference (grid_sample returns fp32, .to(float16)
+  // rounds it a second time).  Left to itself LLVM folds fptrunc(fma) into v_fma_mixlo_f16, which rounds the exact
+  // fma result ONCE: a different fp16 value whenever the fp32 result is an fp16 tie (1 element in ~60 000; found by
+  // the full-chunk comparison with the oracle, tests/test_fullsize_gpu.py).  The empty asm pins the fp32 rounding.
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
-    o_points[3 * i + c] = __float2half_rn(bil_sample(points + 3 * fo + c, 3, 3L * W, b, H, W));
-    o_local[3 * i + c] = __float2half_rn(bil_sample(local_points + 3 * fo + c, 3, 3L * W, b, H, W));
+    float vp = bil_sample(points + 3 * fo + c, 3, 3L * W, b, H, W);
+    float vl = bil_sample(local_points + 3 * fo + c, 3, 3L * W, b, H, W);
+    asm volatile("" : "+v"(vp), "+v"(vl));
+    o_points[3 * i + c] = __float2half_rn(vp);
+    o_local[3 * i + c] = __float2half_rn(vl);
   }
   const long pn = fo + (long)b.yn * W + b.xn;
   o_conf[i] = __float2half_rn(conf[pn]);
@@ -248,7 +301,9 @@ __global__ __launch_bounds__(256) void gather_keypoints_kernel(
   if (images) {
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-      const float v = bil_sample(images + ((long)f * 3 + c) * H * W, 1, W, b, H, W) * 255.0f;
+      float vb = bil_sample(images + ((long)f * 3 + c) * H * W, 1, W, b, H, W);
+      asm volatile("" : "+v"(vb));     // the fp32 sample, then * 255 as its own rounding (keypoint_extraction.py:229)
+      const float v = vb * 255.0f;
       const int u = (int)v;  // .to(torch.uint8): truncation
       o_colors[3 * i + c] = __float2half_rn((float)(u & 255));
     }

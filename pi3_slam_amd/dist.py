@@ -67,24 +67,34 @@ def shard_chunks(n_chunks: int, rank: int, world: int) -> List[int]:
     return list(range(rank, n_chunks, world))
 
 
+PAD_KEYPOINT_TAIL, PAD_KEYPOINT_HEAD = -1.0, -2.0    # never equal to a pixel coordinate, nor to each other
+
+
 def pack_boundary(chunk: Dict[str, torch.Tensor], overlap: int, K: int, device="cpu") -> torch.Tensor:
     """Flat fp32 boundary block of one chunk: head (first ov views) and tail (last ov views) of keypoints (as fp16 bit
     patterns widened to fp32-exact integers), world points (fp32 values), validity, and the last camera pose.
-    Layout: [n_frames, head_kp(ov*K*2), head_pts(ov*K*3), head_mask(ov*K), tail_kp, tail_pts, tail_mask, pose(16)]."""
+    Layout: [n_frames, head_kp(ov*K*2), head_pts(ov*K*3), head_mask(ov*K), tail_kp, tail_pts, tail_mask, pose(16)].
+    K is the wave-wide keypoint count (the block size every rank must agree on before the all-gather); a chunk with
+    fewer keypoints fills its first K_local slots per view and pads the rest with keypoints that cannot match
+    (-1 in a tail block, -2 in a head block: a tail is only ever matched against a head), zero points, mask 0."""
     n = int(chunk["points"].shape[0])
     ov = min(overlap, n)
+    Kl = int(chunk["keypoints"].shape[1])
+    if Kl > K:
+        raise ValueError(f"chunk has {Kl} keypoints per view, the wave-wide block holds {K}")
 
-    def blk(sl):
-        out = torch.zeros(overlap * K * 6)
-        out[: ov * K * 2] = (chunk["keypoints"][sl].to(torch.float16).contiguous().view(torch.int16)
-                             .to(torch.float32).reshape(-1))
-        # fp16 file values are exact in fp32; refined ones stay fp32
-        out[overlap * K * 2: overlap * K * 2 + ov * K * 3] = chunk["points"][sl].to(torch.float32).reshape(-1)
-        out[overlap * K * 5: overlap * K * 5 + ov * K] = chunk["masks"][sl].reshape(-1).to(torch.float32)
-        return out
+    def blk(sl, pad_value):
+        kp = torch.full((overlap, K, 2), pad_value, dtype=torch.float16)
+        kp[:ov, :Kl] = chunk["keypoints"][sl].to(torch.float16)
+        pt = torch.zeros(overlap, K, 3)
+        pt[:ov, :Kl] = chunk["points"][sl].to(torch.float32)      # fp16 file values are exact in fp32; refined stay fp32
+        mk = torch.zeros(overlap, K, 1)
+        mk[:ov, :Kl] = chunk["masks"][sl].reshape(ov, Kl, 1).to(torch.float32)
+        return torch.cat([kp.view(torch.int16).to(torch.float32).reshape(-1), pt.reshape(-1), mk.reshape(-1)])
 
     # assembled on the host, one pinned asynchronous upload (alignment.upload): nothing here waits for the device
-    flat = torch.cat([torch.tensor([float(n)]), blk(slice(0, ov)), blk(slice(n - ov, n)),
+    flat = torch.cat([torch.tensor([float(n)]), blk(slice(0, ov), PAD_KEYPOINT_HEAD),
+                      blk(slice(n - ov, n), PAD_KEYPOINT_TAIL),
                       chunk["camera_poses"][n - 1].reshape(-1).to(torch.float32).cpu()])
     from .alignment import upload
     return upload(flat, device)

@@ -63,6 +63,9 @@ class Pi3SLAMOnline:
                  use_inverse_depth: bool = False, moge_model=None, moge_model_path: Optional[str] = None,
                  hip_graph: bool = True, output_dir: Optional[str] = None, num_loader_workers: int = 0,
                  bundle_adjust: bool = True):
+        if use_inverse_depth:
+            from .alignment import INVERSE_DEPTH_MESSAGE
+            raise NotImplementedError(INVERSE_DEPTH_MESSAGE)
         self.chunk_length, self.overlap = int(chunk_length), int(overlap)
         self.pixel_limit = 255000 // 2
         self.output_dir = output_dir or os.path.join("/tmp", f"pi3_online_{os.getpid()}")

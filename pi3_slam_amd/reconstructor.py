@@ -66,7 +66,10 @@ class OfflineReconstructor:
         self.overlap = int(overlap) if overlap is not None else (loaded_ov or 10)
         self.max_observations_per_track = max_observations_per_track
         self.save_per_chunk = save_per_chunk
-        self.use_inverse_depth = use_inverse_depth
+        if use_inverse_depth:      # accepted-and-ignored would silently change what the user asked for
+            from .alignment import INVERSE_DEPTH_MESSAGE
+            raise NotImplementedError(INVERSE_DEPTH_MESSAGE)
+        self.use_inverse_depth = False
         from .dist import resolve_device
         self.device = resolve_device(device)     # 'cuda' -> this rank's card (the one the process group is bound to)
         if torch.cuda.is_available():
@@ -105,7 +108,8 @@ class OfflineReconstructor:
     def _ba_args(self, data: Dict) -> Optional[Dict]:
         if not self.bundle_adjust or data.get("keypoints") is None:
             return None
-        return {"width": int(data.get("original_width", 406)), "height": int(data.get("original_height", 308)),
+        # offline_reconstructor.py:66-67: 1920x1080 when a chunk file does not carry its size
+        return {"width": int(data.get("original_width", 1920)), "height": int(data.get("original_height", 1080)),
                 "max_observations_per_track": self.max_observations_per_track}
 
     def _bundle_adjust_new_chunk(self, data: Dict, idx: int) -> None:

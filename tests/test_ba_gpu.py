@@ -73,6 +73,108 @@ def test_bundle_adjust_matches_oracle(dev, case):
     assert abs(out[0] - s_long["final_cost"]) <= 1e-4 * s_long["final_cost"] + 1e-9, (out[0], s_long["final_cost"])
 
 
+def _compare_with_schur_oracle(dev, pb, huber, iters, prior=None, cost_rtol=1e-9, atol_pose=1e-7, atol_pts=1e-6):
+    """pi3_bundle_adjust against oracle/ba_ref.bundle_adjust_schur on the same problem: same number of iterations and
+    accepted steps, costs to cost_rtol, parameters to atol.  Returns (device summary, oracle summary)."""
+    from oracle import ba_ref
+    from pi3_slam_amd import ops
+    N = len(pb["R"])
+    R, C, X, s = ba_ref.bundle_adjust_schur(pb["R"], pb["C"], pb["intr"], pb["X"], pb["uv"], pb["valid"], huber, iters, prior)
+    pts, rc, intr, uv, valid = _to_dev(pb, dev)
+    pr = pc = pf = None
+    if prior is not None:
+        pr = torch.from_numpy(prior["R"].reshape(N, 9)).to(dev)
+        pc = torch.from_numpy(prior["C"]).to(dev)
+        pf = torch.from_numpy(prior["flag"]).to(dev)
+    out = ops.bundle_adjust(pts, rc, intr, uv, valid, huber, iters, pr, pc, pf,
+                            prior["sqrt_info_rot"] if prior else 0.0, prior["sqrt_info_pos"] if prior else 0.0).cpu().numpy()
+    torch.cuda.synchronize()
+    assert abs(out[8] - s["initial_cost"]) <= cost_rtol * s["initial_cost"], (out[8], s["initial_cost"])
+    assert (int(out[5]), int(out[6])) == (s["iterations"], s["accepted_steps"]), (out, s)
+    assert abs(out[0] - s["final_cost"]) <= cost_rtol * s["final_cost"], (out[0], s["final_cost"])
+    rc = rc.cpu().numpy()
+    np.testing.assert_allclose(rc[:, :9].reshape(N, 3, 3), R, atol=atol_pose)
+    np.testing.assert_allclose(rc[:, 9:], C, atol=atol_pose)
+    np.testing.assert_allclose(pts.cpu().numpy(), X, atol=atol_pts)
+    return out, s
+
+
+@pytest.mark.parametrize("N,K", [(20, 12), (24, 12), (27, 10)])
+def test_multi_panel_cholesky_and_schur_slices_match_the_oracle(dev, N, K):
+    """6N = 120 / 144 / 162 unknowns = 3 / 3 / 4 panels of the blocked Cholesky (BA_NB = 48 columns; partial last panel
+    of 24 / none / 18), i.e. ba_chol_panel, ba_chol_update and the multi-panel loops of ba_chol_solve all execute
+    (with N <= 8 cameras the factorisation is one diagonal block), and the 32 source-frame slices of ba_schur_rows hold
+    0 or 1 frame each.  One LM iteration (the step itself) and six (the trust-region sequence), step for step against
+    the Schur-complement oracle; reference call: utils/chunk_reconstruction.py:188-219."""
+    pb = make_problem(N=N, K=K, seed=100 + N, noise_px=0.5, outlier_frac=0.03, perturb=0.5)
+    for iters in (1, 6):
+        out, s = _compare_with_schur_oracle(dev, pb, 2.0, iters)
+        assert out[9] == 0 and s["chol_failures"] == 0 and out[0] < out[8]
+
+
+def test_multi_panel_with_pose_priors_matches_the_oracle(dev):
+    """The prior-constrained form (utils/reconstruction_alignment.py:107-171: Huber 3.0, covariance 2 I / 25 I on the
+    overlap views) at 3 panels."""
+    N, K = 22, 10
+    pb = make_problem(N=N, K=K, seed=31, noise_px=0.4, perturb=0.4)
+    flag = np.zeros(N, np.uint8); flag[:5] = 1
+    prior = dict(R=pb["R_gt"].copy(), C=pb["C_gt"] + 0.03, flag=flag, sqrt_info_rot=0.5 ** 0.5, sqrt_info_pos=0.2)
+    _compare_with_schur_oracle(dev, pb, 3.0, 8, prior)
+
+
+@pytest.mark.parametrize("iters", [1, 10])
+def test_whole_chunk_matches_the_oracle(dev, iters):
+    """The shipped size: 100 cameras x 200 keypoints (600 unknowns = 12.5 panels, 20 000 tracks, ~1 M observations in
+    the reference's pattern: every earlier frame + the next two) on bench.synthetic_ba_problem, one LM iteration and
+    the per-chunk stage's ten, against the Schur-complement oracle.  Cost 1e-9; parameters 1e-7 after one step and
+    1e-6 after ten (round-off of 1 M-term sums taken in different orders, amplified along the weakly constrained
+    directions by ten solves)."""
+    from bench import synthetic_ba_problem
+    pb = synthetic_ba_problem(100, 200, seed=3, noise_px=0.5, perturb=1.0)
+    tol = dict(atol_pose=1e-7, atol_pts=1e-6) if iters == 1 else dict(atol_pose=1e-6, atol_pts=1e-5)
+    out, s = _compare_with_schur_oracle(dev, pb, 2.0, iters, **tol)
+    assert out[9] == 0 and s["chol_failures"] == 0 and out[0] < 0.2 * out[8], (out, s)
+
+
+def test_failed_factorisation_rejects_the_step_and_returns_the_inputs(dev):
+    """Forced Cholesky failure: one NaN pixel poisons camera 0's block, the diagonal pivot is not > 0, chol_fail is
+    raised, the step is rejected, the trust region shrinks (1e4 / 2 / 4 / 8 ...) until the loop gives up after 15
+    iterations - exactly as the oracle - and points / poses come back bit for bit (also from the multi-panel path)."""
+    from oracle import ba_ref
+    from pi3_slam_amd import ops
+    for N, K in ((5, 6), (20, 8)):
+        pb = make_problem(N=N, K=K, seed=3, noise_px=0.3, perturb=0.3)
+        pb["uv"] = pb["uv"].copy()
+        assert pb["valid"][1, 0, 2]
+        pb["uv"][1, 0, 2, 0] = np.nan
+        _, _, _, s = ba_ref.bundle_adjust_schur(pb["R"], pb["C"], pb["intr"], pb["X"], pb["uv"], pb["valid"], 2.0, 30)
+        pts, rc, intr, uv, valid = _to_dev(pb, dev)
+        p0, r0 = pts.clone(), rc.clone()
+        out = ops.bundle_adjust(pts, rc, intr, uv, valid, 2.0, 30).cpu().numpy()
+        assert out[9] == 1 and int(out[6]) == 0 == s["accepted_steps"] and int(out[5]) == s["iterations"] == 15
+        assert s["chol_failures"] == 15 and torch.equal(pts, p0) and torch.equal(rc, r0)
+
+
+def test_sanity_gate_keeps_the_input_when_the_geometry_is_inconsistent(dev):
+    """bundle_adjust_chunk must not take over a result that threw every track out or walked a camera away by more than
+    the scene extent (LM 'succeeds' on contradictory observations: round 2 saw poses move by 10^3 units on recipe-weight
+    chunks with success=True): the chunk stays as it was and the info says why."""
+    from pi3_slam_amd.bundle_adjust import bundle_adjust_chunk
+    N, K, W, H = 6, 30, 406, 308
+    g = torch.Generator().manual_seed(0)
+    poses = torch.eye(4).repeat(N, 1, 1)
+    poses[:, :3, 3] = torch.randn(N, 3, generator=g) * 0.1
+    chunk = dict(points=(torch.randn(N, K, 3, generator=g) + torch.tensor([0.0, 0.0, 4.0])).half(), camera_poses=poses,
+                 keypoints=(torch.rand(N, K, 2, generator=g) * torch.tensor([W - 1.0, H - 1.0])).half(),   # unrelated pixels
+                 masks=torch.ones(N, K, 1, dtype=torch.bool))
+    before = {k: v.clone() for k, v in chunk.items()}
+    info = bundle_adjust_chunk(chunk, W, H, 5, str(dev))
+    assert not info["success"] and "rejected" in info, info
+    for k in before:
+        assert torch.equal(chunk[k], before[k]), k
+    assert "track_estimated" not in chunk
+
+
 def test_bundle_adjust_is_deterministic_and_zero_iterations_is_identity(dev):
     from pi3_slam_amd import ops
     pb = make_problem(N=8, K=12, seed=6, noise_px=0.5, perturb=0.5)

@@ -63,3 +63,39 @@ def test_outlier_track_semantics():
     X = pb["X_gt"].copy()
     X[0] = pb["C_gt"][0] - pb["R_gt"][0].T @ np.array([0, 0, 2.0])  # behind camera 0
     assert not ba_ref.outlier_tracks(pb["R_gt"], pb["C_gt"], pb["intr"], X, pb["uv"], pb["valid"], 1e9, 0.25)[0]
+
+
+@pytest.mark.parametrize("case", ["noise", "priors", "larger"])
+def test_schur_form_takes_the_same_steps_as_the_dense_normal_equations(case):
+    """oracle/ba_ref.bundle_adjust_schur (per-track 3x3 elimination + reduced camera system: what DENSE_SCHUR and
+    csrc/ba.hip do, and the only form that scales to a 100-camera chunk) against the dense solve of the full normal
+    equations: the Schur complement is algebra, so iterates agree to round-off while the system is well conditioned."""
+    kw = dict(noise=dict(N=6, K=9, seed=4, noise_px=0.8, outlier_frac=0.05, perturb=0.6),
+              priors=dict(N=5, K=8, seed=9, noise_px=0.3, perturb=0.4),
+              larger=dict(N=12, K=10, seed=11, noise_px=0.5, perturb=0.5))[case]
+    pb = make_problem(**kw)
+    N = len(pb["R"])
+    prior = None
+    if case == "priors":
+        flag = np.zeros(N, np.uint8); flag[:3] = 1
+        prior = dict(R=pb["R_gt"], C=pb["C_gt"] + 0.05, flag=flag, sqrt_info_rot=0.5 ** 0.5, sqrt_info_pos=0.2)
+    args = (pb["R"], pb["C"], pb["intr"], pb["X"], pb["uv"], pb["valid"], 2.0, 6, prior)
+    Rd, Cd, Xd, sd = ba_ref.bundle_adjust(*args)
+    Rs, Cs, Xs, ss = ba_ref.bundle_adjust_schur(*args)
+    assert (sd["iterations"], sd["accepted_steps"]) == (ss["iterations"], ss["accepted_steps"]) and ss["chol_failures"] == 0
+    assert abs(sd["final_cost"] - ss["final_cost"]) <= 1e-9 * sd["final_cost"]
+    np.testing.assert_allclose(Rs, Rd, atol=1e-9)
+    np.testing.assert_allclose(Cs, Cd, atol=1e-9)
+    np.testing.assert_allclose(Xs, Xd, atol=1e-8)
+
+
+def test_schur_form_rejects_every_step_on_a_non_finite_observation():
+    """A NaN pixel poisons the normal equations: the factorisation fails, every step is rejected, the trust region
+    shrinks until the loop gives up and the inputs come back untouched (the device must do the same, test_ba_gpu.py)."""
+    pb = make_problem(N=5, K=6, seed=3, noise_px=0.3, perturb=0.3)
+    uv = pb["uv"].copy()
+    uv[1, 0, 2, 0] = np.nan
+    assert pb["valid"][1, 0, 2]
+    R, C, X, s = ba_ref.bundle_adjust_schur(pb["R"], pb["C"], pb["intr"], pb["X"], uv, pb["valid"], 2.0, 30)
+    assert s["accepted_steps"] == 0 and s["chol_failures"] == s["iterations"] and s["iterations"] < 30
+    assert np.array_equal(R, pb["R"]) and np.array_equal(C, pb["C"]) and np.array_equal(X, pb["X"])

@@ -61,7 +61,7 @@ def test_allgather_boundaries_world2():
 
 
 # ------------------------------------------------------------------------------------------------ wave alignment
-def _synthetic_chunks(n_chunks, cl, ov, K, bad_chunk=None):
+def _synthetic_chunks(n_chunks, cl, ov, K, bad_chunk=None, last_n=None, few_kp_chunk=None):
     """Chunk dicts (chunk-file layout) cut from one world: chunk c = S_c^-1 (world).  bad_chunk's keypoints are shifted
     so that it shares no track with its predecessor (its alignment must fail and restart the chain)."""
     import numpy as np
@@ -72,7 +72,7 @@ def _synthetic_chunks(n_chunks, cl, ov, K, bad_chunk=None):
     chunks, sims = [], []
     for c in range(n_chunks):
         start = c * (cl - ov)
-        n = min(cl, n_frames - start) if c < n_chunks - 1 else cl - 2      # short last chunk
+        n = min(cl, n_frames - start) if c < n_chunks - 1 else (last_n or cl - 2)      # short last chunk
         ang, s = 0.3 * c, 1.0 + 0.1 * c
         R = np.array([[np.cos(ang), -np.sin(ang), 0], [np.sin(ang), np.cos(ang), 0], [0, 0, 1.0]])
         t = np.array([0.5 * c, -0.3 * c, 0.1 * c])
@@ -82,8 +82,10 @@ def _synthetic_chunks(n_chunks, cl, ov, K, bad_chunk=None):
         k = np.tile(kp, (n, 1, 1))
         if c == bad_chunk:
             k[:ov] = (k[:ov].astype(np.float32) + 1000).astype(np.float16)     # only its head: the tail still pairs
+        if c == few_kp_chunk:       # a chunk with fewer keypoints per view than the rest of its wave
+            pts, k = pts[:, : K - 7], k[:, : K - 7]
         chunks.append(dict(points=torch.from_numpy(pts), keypoints=torch.from_numpy(k),
-                           masks=torch.ones(n, K, 1, dtype=torch.bool), camera_poses=torch.from_numpy(poses)))
+                           masks=torch.ones(n, pts.shape[1], 1, dtype=torch.bool), camera_poses=torch.from_numpy(poses)))
         M = np.eye(4); M[:3, :3] = s * R; M[:3, 3] = t
         sims.append(M)
     return chunks, sims
@@ -115,12 +117,13 @@ def _oracle_solver(ov, cl):
     return solve
 
 
-def _wave_worker(rank, world, port, n_chunks, cl, ov, K, bad, q):
+def _wave_worker(rank, world, port, n_chunks, cl, ov, K, bad, q, last_n=None, few_kp=None):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from pi3_slam_amd.dist import WaveAligner
-    chunks, _ = _synthetic_chunks(n_chunks, cl, ov, K, bad)
+    chunks, _ = _synthetic_chunks(n_chunks, cl, ov, K, bad, last_n, few_kp)
     # the product's wave driver (sizes all-gather, boundary all-gather, own solve, 136-byte all-gather, prefix product)
     # with the CPU oracle standing in for the HIP solver
     aligner = WaveAligner(rank, world, ov, cl, "cpu", solve=_oracle_solver(ov, cl))
@@ -172,3 +175,61 @@ def test_align_wave_world2_equals_sequential_composition(n_chunks, bad):
             np.testing.assert_allclose(G[c], sims[c], atol=2e-2)
         else:     # chunks from the rejected one on live in the rejected chunk's frame
             np.testing.assert_allclose(G[c], np.linalg.inv(sims[bad]) @ sims[c], atol=2e-2)
+
+
+def test_align_wave_world8_two_waves_restart_on_wave_boundary_and_ragged_keypoints():
+    """north_star's 8 ranks (gloo on the CPU): 13 chunks = a full wave of 8 + a ragged wave of 5; chunk 8 - the FIRST
+    chunk of the second wave, whose predecessor block is rank 0's `prev_tail` carried over from the previous wave - is
+    rejected, so the chain restarts there; the last chunk is short (4 of 10 frames, the 40-of-100 case of a
+    1000-frame sequence); chunk 10 has fewer keypoints per view than its wave (pack_boundary pads to
+    the wave-wide block).  Every rank must hold the same transforms, equal to the sequential composition."""
+    import numpy as np
+    world, n_chunks, cl, ov, K, bad, last_n, few = 8, 13, 10, 3, 30, 8, 4, 10
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_wave_worker, args=(r, world, port, n_chunks, cl, ov, K, bad, q, last_n, few))
+             for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in range(1, world):
+        assert np.array_equal(res[0][1], res[r][1]) and res[0][2] == res[r][2]
+    G, oks = res[0][1], res[0][2]
+    assert len(G) == n_chunks
+    from pi3_slam_amd.dist import pack_boundary, unpack_boundary
+    chunks, sims = _synthetic_chunks(n_chunks, cl, ov, K, bad, last_n, few)
+    solve = _oracle_solver(ov, cl)
+    blocks = [unpack_boundary(pack_boundary(ch, ov, K), ov, K) for ch in chunks]
+    Gseq = [np.eye(4)]
+    for c in range(1, n_chunks):
+        r = solve(blocks[c - 1], blocks[c])
+        Gseq.append(Gseq[-1] @ r[1:].numpy().reshape(4, 4) if r[0] > 0.5 else np.eye(4))
+    np.testing.assert_allclose(G, np.stack(Gseq), rtol=1e-12, atol=1e-12)
+    assert oks == [c != bad for c in range(n_chunks)]
+    for c in range(n_chunks):
+        want = sims[c] if c < bad else np.linalg.inv(sims[bad]) @ sims[c]
+        np.testing.assert_allclose(G[c], want, atol=3e-2)
+
+
+def test_pack_boundary_pads_a_chunk_with_fewer_keypoints():
+    """dist.py pack_boundary: the block is sized by the wave-wide K; a chunk with fewer keypoints must fill its own
+    slots and pad the rest with keypoints that can never pair (it used to raise inside a collective wave)."""
+    from pi3_slam_amd.dist import boundary_numel, pack_boundary, unpack_boundary
+    g = torch.Generator().manual_seed(0)
+    n, Kl, K, ov = 6, 5, 9, 3
+    ch = dict(points=torch.randn(n, Kl, 3, generator=g).half(), keypoints=(torch.rand(n, Kl, 2, generator=g) * 300).half(),
+              masks=torch.ones(n, Kl, 1, dtype=torch.bool), camera_poses=torch.randn(n, 4, 4, generator=g))
+    flat = pack_boundary(ch, ov, K)
+    assert flat.numel() == boundary_numel(ov, K)
+    b = unpack_boundary(flat, ov, K)
+    assert torch.equal(b["tail"]["keypoints"][:, :Kl], ch["keypoints"][-ov:])
+    assert torch.equal(b["head"]["points"][:, :Kl], ch["points"][:ov].float())
+    assert not b["tail"]["masks"][:, Kl:].any() and not b["head"]["masks"][:, Kl:].any()
+    pad_t, pad_h = b["tail"]["keypoints"][:, Kl:], b["head"]["keypoints"][:, Kl:]
+    assert (pad_t < 0).all() and (pad_h < 0).all() and not (pad_t == pad_h).any()
+    with pytest.raises(ValueError):
+        pack_boundary(ch, ov, Kl - 1)

@@ -1,0 +1,234 @@
+"""Oracle comparisons AT THE SIZES THAT SHIP (BASELINE.json configs[1]: 100 frames 308x406 -> S = 64 300 tokens; the
+nominal 378x504 tensor -> S = 97 700; EuRoC 280x448).  The small-shape tests elsewhere cover the arithmetic; these cover
+what only exists at full size: 126 query blocks per head in the XCD-aware order, the 300-row partial last block, the
+44-key tail tile, 252 row tiles of the 256x256 GEMM with a 44-row last tile, medians over 125 048 pixels, 100 LM solves.
+References: a row-blocked fp32 torch softmax / fp32 torch matmul ON THE DEVICE for the transformer kernels (the same op
+written out, pi3/models/layers/attention.py:336-341, layers/block.py:310-335) and oracle/post_ref on the CPU for the
+post-processing (offline_chunk_creator.py:114-159, utils/camera_estimation.py:12-70).  Gates are the small-shape gates."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev(built_lib):
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    from pi3_slam_amd import lib
+    lib.load(require_gpu=True)
+    return torch.device("cuda:0")
+
+
+def rel(a, b):
+    a, b = a.float(), b.float()
+    return ((a - b).abs().max() / (b.abs().max() + 1e-12)).item(), \
+        ((a - b).abs().mean() / (b.abs().mean() + 1e-12)).item()
+
+
+def attn_ref_rows(qkv, B, S, H, heads, block=4096):
+    """softmax(q k^T) v for the given heads, all rows, fp32, in row blocks of `block` queries (a [4096, S] score slab is
+    1.0-1.6 GB at S = 64 300-97 700).  q is pre-scaled and in the exp2 domain, as the kernel's contract says."""
+    x = qkv.view(B, S, 3, H, 64)
+    out = torch.empty(B, S, len(heads), 64, device=qkv.device, dtype=torch.float32)
+    for b in range(B):
+        for i, h in enumerate(heads):
+            q, k, v = (x[b, :, j, h].float() for j in range(3))
+            kt = k.t().contiguous()
+            for r0 in range(0, S, block):
+                s = (q[r0:r0 + block] @ kt) * math.log(2.0)
+                out[b, r0:r0 + block, i] = torch.softmax(s, dim=-1) @ v
+                del s
+    return out
+
+
+@pytest.mark.parametrize("S", [64300, 97700])
+def test_global_attention_full_size_all_rows(dev, S):
+    """One SDPA over the whole chunk (pi3.py:162-166): every row of every head against the fp32 softmax, with BOTH
+    softmax paths in the launch: LayerNorm-like q/k (bounded-score loop, no running max) and, in heads 0 and 9, waves
+    whose rows exceed the bound (online-max loop), plus a key that forces a late rescale."""
+    from pi3_slam_amd import ops
+    B, H = 1, 16
+    g = torch.Generator(device=dev).manual_seed(S)
+    qkv = torch.randn(S, 3 * H * 64, device=dev, generator=g)
+    qkv[:, :H * 64] *= ops.QSCALE * 2.0
+    qkv[:64, :64] *= 10.0                                        # head 0, first wave of the first block: over the bound
+    qkv[S - 300:S - 236, 9 * 64:10 * 64] *= 10.0                 # head 9, first wave of the PARTIAL last query block
+    qkv[S - 20, H * 64 + 64: H * 64 + 128] = qkv[4097, 64:128] * 30.0   # head 1: a spike in the 44-key tail tile
+    qkv = qkv.bfloat16()
+    out = torch.empty(S, H * 64, device=dev, dtype=torch.bfloat16)
+    ops.attention(qkv, out, B, S, H)
+    torch.cuda.synchronize()
+    assert torch.isfinite(out.float()).all()
+    worst = (0.0, 0.0)
+    for h0 in range(0, H, 4):
+        heads = list(range(h0, h0 + 4))
+        ref = attn_ref_rows(qkv, B, S, H, heads)[0]
+        got = out.view(S, H, 64)[:, h0:h0 + 4].float()
+        for i, h in enumerate(heads):
+            mx, mean = rel(got[:, i], ref[:, i])
+            worst = (max(worst[0], mx), max(worst[1], mean))
+            assert mx < 8e-3 and mean < 5e-3, (S, h, mx, mean)   # the gate of test_kernels_gpu.py:96-97
+        del ref
+    # with max |k|^2 supplied by the caller (what the fused qkv epilogue does in the engine): same result bit for bit
+    k = qkv.view(S, 3, H, 64)[:, 1].float()
+    k2 = (k * k).sum(-1).amax(0).contiguous()
+    out2 = torch.empty_like(out)
+    ops.attention(qkv, out2, B, S, H, k2max=k2)
+    assert torch.equal(out, out2)
+    print(f"global attention S={S}: worst max-rel {worst[0]:.2e}, worst mean-rel {worst[1]:.2e}")
+
+
+@pytest.mark.parametrize("T", [643, 645])
+def test_frame_attention_full_size_all_rows(dev, T):
+    """Frame-wise attention of a whole chunk (attention.py:102-107): 100 sequences of 643 (308x406) / 645 (280x448)
+    tokens, 16 heads, every row; max |k|^2 supplied as in the decoder blocks, one frame pushed over the bound."""
+    from pi3_slam_amd import ops
+    B, H = 100, 16
+    g = torch.Generator(device=dev).manual_seed(T)
+    qkv = torch.randn(B * T, 3 * H * 64, device=dev, generator=g)
+    qkv[:, :H * 64] *= ops.QSCALE * 2.0
+    qkv[37 * T:37 * T + 64, 3 * 64:4 * 64] *= 10.0              # frame 37, head 3: online-max loop
+    qkv = qkv.bfloat16()
+    k = qkv.view(B, T, 3, H, 64)[:, :, 1].float()
+    k2 = (k * k).sum(-1).amax(1).reshape(-1).contiguous()
+    for k2max in (k2, None):                                    # decoder form (bounded) and encoder form (no bound given)
+        out = torch.empty(B * T, H * 64, device=dev, dtype=torch.bfloat16)
+        ops.attention(qkv, out, B, T, H, k2max=k2max)
+        x = qkv.view(B, T, 3, H, 64).float()
+        q, kk, v = x[:, :, 0].transpose(1, 2), x[:, :, 1].transpose(1, 2), x[:, :, 2].transpose(1, 2)   # (B, H, T, 64)
+        ref = (torch.softmax((q @ kk.transpose(-1, -2)) * math.log(2.0), dim=-1) @ v).transpose(1, 2).reshape(B * T, H * 64)
+        mx, mean = rel(out, ref)
+        assert mx < 8e-3 and mean < 5e-3 and torch.isfinite(out.float()).all(), (T, mx, mean)
+
+
+BLOCK_SHAPES = [("qkv", 3072, 1024), ("proj", 1024, 1024), ("fc1", 4096, 1024), ("fc2", 1024, 4096)]
+
+
+@pytest.mark.parametrize("name,N,K", BLOCK_SHAPES)
+def test_gemm256_at_chunk_rows(dev, name, N, K):
+    """The four nn.Linear shapes of a decoder block at M = 64 300 rows (block.py:310-335), each with the epilogue the
+    model uses, against fp32 torch on the device: qkv bias + q scale fold (bf16 out), proj / fc2 bias + LayerScale +
+    in-place fp32 residual, fc1 bias + erf GELU (bf16 out)."""
+    from pi3_slam_amd import ops
+    M = 64300
+    g = torch.Generator(device=dev).manual_seed(N + K)
+    a = torch.randn(M, K, device=dev, generator=g).bfloat16()
+    w = (torch.randn(N, K, device=dev, generator=g) / math.sqrt(K)).bfloat16()
+    bias = torch.randn(N, device=dev, generator=g)
+    ref = torch.addmm(bias, a.float(), w.float().t())
+    if name == "qkv":
+        out = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+        ops.gemm(a, w, out, M=M, bias=bias, qscale=ops.QSCALE, qcols=1024)
+        ref[:, :1024] *= ops.QSCALE
+        assert rel(out, ref)[0] < 6e-3
+    elif name == "fc1":
+        out = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+        ops.gemm(a, w, out, M=M, bias=bias, act=ops.ACT_GELU)
+        assert rel(out, torch.nn.functional.gelu(ref))[0] < 6e-3
+    else:
+        gamma = torch.rand(N, device=dev, generator=g) + 0.5
+        x0 = torch.randn(M, N, device=dev, generator=g)
+        x = x0.clone()
+        ops.gemm(a, w, x, M=M, bias=bias, gamma=gamma, resid=x)
+        mx, mean = rel(x, x0 + gamma * ref)
+        assert mx < (2e-5 if K <= 1024 else 4e-5) and mean < 1e-5, (mx, mean)   # fp32 accumulation order only
+
+
+@pytest.mark.parametrize("attn_B,attn_S", [(1, 64300), (100, 643)])
+def test_fused_qkv_epilogue_at_chunk_rows(dev, attn_B, attn_S):
+    """pi3_gemm_qkv at (64 300, 3072, 1024) with the decoder's q/k LayerNorm(64) + RoPE-2D (22 x 29 patch grid + 5
+    special tokens per frame) + scale fold + max |k|^2, for the global and the frame-wise batch split, against the op
+    written out in fp32 (attention.py:323-334; RoPE: oracle/pi3_ref.rope2d = pos_embed.py:112-159)."""
+    from oracle import pi3_ref
+    from pi3_slam_amd import ops
+    H, T, K, F = 16, 643, 1024, 100
+    M = F * T
+    g = torch.Generator(device=dev).manual_seed(attn_S)
+    a = torch.randn(M, K, device=dev, generator=g).bfloat16()
+    w = (torch.randn(3 * H * 64, K, device=dev, generator=g) / math.sqrt(K)).bfloat16()
+    bias = torch.randn(3 * H * 64, device=dev, generator=g) * 0.1
+    pos = torch.zeros(T, 2, dtype=torch.int32)
+    for t in range(5, T):
+        pos[t, 0], pos[t, 1] = (t - 5) // 29 + 1, (t - 5) % 29 + 1
+    inv = 1.0 / (100.0 ** (torch.arange(0, 32, 2).float() / 32))
+    ang = torch.arange(30).float()[:, None] * inv[None]
+    cs = torch.stack([ang.cos(), ang.sin()], -1).contiguous().to(dev)
+    gq = torch.Generator().manual_seed(3)
+    qw, qb, kw, kb = [(torch.randn(64, generator=gq) * 0.2 + (1 if i % 2 == 0 else 0)) for i in range(4)]
+    qkv = torch.empty(M, 3 * H * 64, device=dev, dtype=torch.bfloat16)
+    k2 = torch.full((attn_B * H,), -1.0, device=dev)
+    ops.gemm_qkv(a, w, qkv, M=M, H=H, bias=bias, T=T, pos=pos.to(dev), cs=cs, eps=1e-5, k2max=k2, attn_B=attn_B,
+                 attn_S=attn_S, qw=qw.to(dev), qb=qb.to(dev), kw=kw.to(dev), kb=kb.to(dev))
+    torch.cuda.synchronize()
+    kk = qkv.view(attn_B, attn_S, 3, H, 64)[:, :, 1].float()
+    assert torch.allclose(k2, (kk * kk).sum(-1).amax(1).reshape(-1), rtol=1e-5)       # of the STORED k
+    plain = torch.empty_like(qkv)
+    ops.gemm(a, w, plain, M=M, bias=bias)                                               # same kernel, plain epilogue
+    assert torch.equal(qkv.view(M, 3, H, 64)[:, 2], plain.view(M, 3, H, 64)[:, 2])      # v: the plain projection
+    lin32 = torch.addmm(bias, a.float(), w.float().t())
+    assert rel(plain, lin32)[0] < 6e-3                                                  # and that one vs fp32 torch
+    del lin32
+    # LayerNorm + RoPE act on the bf16 Linear output (as under autocast): feed the reference the kernel's own bf16
+    # projection so that a bf16 rounding tie of the projection does not count against the epilogue
+    lin = plain.float().view(F, T, 3, H, 64)
+    got = qkv.float().view(F, T, 3, H, 64)
+    xpos = pos.long()[None].expand(10, T, 2)
+    worst = 0.0
+    for f0 in range(0, F, 10):                                                          # LN + RoPE reference on the CPU
+        x = lin[f0:f0 + 10].cpu()
+        q = torch.nn.functional.layer_norm(x[:, :, 0].transpose(1, 2), (64,), qw, qb, 1e-5)
+        k = torch.nn.functional.layer_norm(x[:, :, 1].transpose(1, 2), (64,), kw, kb, 1e-5)
+        q, k = pi3_ref.rope2d(q, xpos) * ops.QSCALE, pi3_ref.rope2d(k, xpos)
+        gq_, gk_ = got[f0:f0 + 10, :, 0].cpu(), got[f0:f0 + 10, :, 1].cpu()
+        e = max(rel(gq_, q.transpose(1, 2))[0], rel(gk_, k.transpose(1, 2))[0])
+        worst = max(worst, e)
+        assert e < 5e-3, (f0, e)
+    print(f"fused qkv epilogue at M={M}: worst max-rel {worst:.2e}")
+
+
+@pytest.mark.parametrize("H,W", [(308, 406), (280, 448)])
+def test_post_processing_full_chunk_vs_oracle(dev, H, W):
+    """masks / ratio median / per-frame focal-shift LM / keypoint gather + colours over a whole 100-frame chunk at the
+    two shipped map sizes, against oracle/post_ref on the CPU (pinned to the reference's own functions by
+    tests/golden/post_*.npz).  Bit-exact where the small fixtures are: masks, median, nearest samples, fp16 bilinear
+    samples, uint8 colours, keypoints; focal / shift to rtol 1e-5."""
+    from oracle import post_ref
+    from oracle.gen_golden_post import synthetic_chunk
+    from pi3_slam_amd import ops
+    from pi3_slam_amd.chunk_creator import _uv_tables
+    N, KP = 100, 200
+    d = synthetic_chunk(f"full_{H}x{W}", N, H, W)
+    lp, conf, pts, imgs = d["local_points"], d["conf"], d["points"], d["images"]
+    masks_ref = post_ref.compute_masks(conf, lp)
+    lpd, confd, ptsd = lp.to(dev), conf.to(dev), pts.to(dev)
+    masks = ops.compute_masks(confd, lpd)
+    assert torch.equal(masks.bool().cpu(), masks_ref), float((masks.bool().cpu() != masks_ref).float().mean())
+    assert 0.05 < float(masks_ref.float().mean()) < 0.95                    # the comparison is not vacuous
+    # metric scale: lower median of moge / pi3 depth over frame 0's mask (offline_chunk_creator.py:121-127)
+    med = ops.masked_ratio_median(d["moge_depth"].to(dev), lpd[0][..., 2], 3, masks[0].contiguous(), H * W).cpu()
+    ref_scale = post_ref.scale_factor(d["moge_depth"], lp[0][..., 2], masks_ref[0])
+    assert med[0].item() == ref_scale.item() and int(med[1]) == int(masks_ref[0].sum())
+    # intrinsics: 100 LM solves (utils/camera_estimation.py:12-70)
+    uvx, uvy = _uv_tables(H, W, dev)
+    r = ops.focal_shift(lpd, confd, uvx, uvy)
+    ref = post_ref.estimate_camera_parameters(lp, conf)
+    np.testing.assert_allclose(r["focal"].cpu().numpy(), ref["focal"][0].numpy(), rtol=1e-5)
+    np.testing.assert_allclose(r["shift"].cpu().numpy(), ref["shift"][0].numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(r["intrinsics"].cpu().numpy(), ref["intrinsics"].numpy(), rtol=1e-5)
+    # keypoints: the per-frame random subset of the grid, gather + fp16 pack + colours
+    kp = post_ref.grid_keypoints(N, H, W, KP, torch.Generator().manual_seed(11))
+    assert kp.shape == (N, KP, 2)
+    out = ops.gather_keypoints(ptsd, lpd, confd, masks, imgs.to(dev), kp.to(dev))
+    exp = post_ref.interpolate_at_keypoints(pts, lp, conf, masks_ref, kp, H, W)
+    assert torch.equal(out["masks"].bool().cpu().reshape(N, KP), exp["masks"].reshape(N, KP))
+    assert torch.equal(out["conf"].cpu().reshape(N, KP), exp["conf"].to(torch.float16).reshape(N, KP))
+    assert torch.equal(out["keypoints"].cpu(), kp.to(torch.float16))
+    for k in ("points", "local_points"):
+        a = out[k].cpu().view(torch.int16)
+        b = exp[k].to(torch.float16).view(torch.int16)
+        assert torch.equal(a, b), (k, float((a != b).float().mean()))
+    col = post_ref.keypoint_colors(imgs, kp)
+    assert torch.equal(out["colors"].cpu().float(), col.float())

@@ -142,6 +142,51 @@ def test_overlapped_stages_write_the_same_chunk_files(tmp_path, built_lib):
         assert ca["_metrics"]["metric_scale"] == cb["_metrics"]["metric_scale"]
 
 
+def test_graphed_moge_depth_belongs_to_its_own_chunk(built_lib):
+    """hip_graph + MoGe + overlapped stages (Pi3SLAMOnline's default): the MoGe graph returns ONE static buffer and
+    chunk k+1's replay is queued while chunk k's forward still runs, so chunk k must read a private copy.  A stand-in
+    MoGe whose `infer_graphed` has exactly that static-buffer contract and whose depth encodes the chunk's first frame
+    makes a mix-up visible as a wrong metric scale (offline_chunk_creator.py:184-192: the scale of a chunk comes from
+    ITS first frame)."""
+    from pi3_slam_amd.chunk_creator import OfflineChunkCreator, OfflineCreatorConfig
+    from pi3_slam_amd.engine import Pi3Engine
+    from pi3_slam_amd.weights import Pi3Config
+
+    class StaticDepth:
+        def __init__(self):
+            self.static = None
+
+        def infer(self, img):
+            return {"depth": (1.0 + 4.0 * img.mean()).expand(img.shape[-2:]).contiguous()}
+
+        def infer_graphed(self, img):
+            if self.static is None:
+                self.static = torch.empty(img.shape[-2:], device=img.device)
+            self.static.copy_((1.0 + 4.0 * img.mean()).expand(img.shape[-2:]))
+            return {"depth": self.static}
+
+    small = Pi3Config(dim=128, enc_depth=1, dec_depth=2, head_depth=1, cam_dim=128, pos_grid=5)
+    engine = Pi3Engine(small, "cuda:0")
+    g = torch.Generator().manual_seed(5)
+    base = torch.rand(1, 6, 3, 56, 70, generator=g)
+    items = [{"frames": (base * (0.15 + 0.2 * c)).clamp(0, 1), "paths": [[f"c{c}_{i}.png"] for i in range(6)],
+              "meta": {"chunk_index": c}} for c in range(4)]                  # distinct first-frame brightness per chunk
+    scales = {}
+    for mode, graph, overlap in (("serial", False, False), ("graph_overlap", True, True)):
+        cfg = OfflineCreatorConfig(model_path="recipe", output_dir="/tmp/pi3_t_graphmoge", chunk_length=6, overlap=2,
+                                   do_metric_depth=True, keypoint_type="grid", max_num_keypoints=50,
+                                   num_loader_workers=0, hip_graph=graph, overlap_stages=overlap)
+        cr = OfflineChunkCreator(cfg, model=engine, moge_model=StaticDepth())
+        cr.target_size = (56, 70)
+        # recipe weights give an (almost) empty validity mask, hence no scale at all: take every pixel, so that the
+        # median really is a function of the chunk's own depth map
+        cr._compute_masks = lambda pi3: torch.ones(pi3["conf"].shape[:4], dtype=torch.bool, device=pi3["conf"].device)
+        scales[mode] = [r["_metrics"]["metric_scale"] for _, r in cr.process_chunks(items)]
+    assert all(s is not None for s in scales["serial"]), scales        # otherwise the test says nothing
+    assert len(set(scales["serial"])) == 4, scales
+    assert scales["graph_overlap"] == scales["serial"], scales
+
+
 def test_metric_scale_fallback_is_reported(built_lib, capsys):
     """An unusable MoGe depth (no valid pixel under the mask) must not rescale the chunk and must say so: the reference
     would raise in torch.median of an empty tensor (offline_chunk_creator.py:121-127)."""

@@ -65,22 +65,55 @@ for _n in VARIANT_CONFIGS:
     CASES[_n] = (84, 112, 0)
 
 
+def _backbone(backbone: str, width: int):
+    import copy
+    cfg = copy.deepcopy(SYNTHETIC_CONFIG)
+    cfg["encoder"] = dict(backbone=backbone, intermediate_layers=4, dim_out=384)   # 1x1 projections width -> 384
+    cfg["scale_head"] = dict(dims=[width, 128, 1])                                   # the class token feeds the scale head
+    return cfg
+
+
+# the other DINOv2 backbones MoGeModel can be built on (moge/model/dinov2/hub/backbones.py): the reference's online
+# worker loads "Ruicheng/moge-2-vitl-normal" (slam/online_reconstructor.py:78); the *_reg forms add 4 register tokens and
+# interpolate the position embedding antialiased with offset 0.0
+BACKBONE_CONFIGS = {
+    "moge_vitl": _backbone("dinov2_vitl14", 1024),
+    "moge_vitb_reg": _backbone("dinov2_vitb14_reg", 768),
+}
+for _n in BACKBONE_CONFIGS:
+    CASES[_n] = (84, 112, 0)
+
+# every fixture below is made pinhole-consistent (see pinhole_overrides): the variants and the backbones as well, so
+# that shift -> final mask -> depth are gated on them like on moge_pinhole_*
+PINHOLE_CASES = {"moge_pinhole_small", "moge_pinhole_chunk", *VARIANT_CONFIGS, *BACKBONE_CONFIGS}
+
+
 def case_config(name: str):
-    return VARIANT_CONFIGS.get(name, SYNTHETIC_CONFIG)
+    return VARIANT_CONFIGS.get(name) or BACKBONE_CONFIGS.get(name) or SYNTHETIC_CONFIG
 
 
 PINHOLE = dict(A=6.0, f0=0.9, b=0.5, c=-0.4, d=0.3, noise=0.25)
 
 
-def pinhole_overrides(sd):
-    """Edit a recipe state dict (SYNTHETIC_CONFIG) in place so that the predicted point map is what a pinhole camera
-    sees, plus a little network-dependent structure: with remap_output='exp' the map is (x z, y z, z), z = exp(z_raw),
-    so xy_raw = uv / f0 makes it EXACTLY pinhole (focal f0, shift 0) for any z_raw.  The UV planes enter the neck's
-    finest level through a 1x1 conv (v2.py:141-147); channels 0 / 1 are turned into clean carriers of A.u / A.v
-    (every other producer of those two channels on the finest level is zeroed), the points head reads xy_raw = uv / f0
-    and z_raw = b u + c v + d from them, and the remaining 30 random channels contribute `noise` x their recipe weight.
+def _last_conv(sd, prefix: str) -> str:
+    """Name of the last convolution of a Resampler (modules.py:139-176): the highest-numbered sub-module with a weight
+    (index 1 for conv_transpose / nearest / bilinear, 2 for pixel_shuffle)."""
+    idx = sorted({int(k[len(prefix) + 1:].split(".")[0]) for k in sd if k.startswith(prefix + ".") and k.endswith(".weight")})
+    return f"{prefix}.{idx[-1]}"
+
+
+def pinhole_overrides(sd, cfg=None):
+    """Edit a recipe state dict in place so that the predicted point map is what a pinhole camera sees, plus a little
+    network-dependent structure: with remap_output='exp' the map is (x z, y z, z), z = exp(z_raw), so xy_raw = uv / f0
+    makes it EXACTLY pinhole (focal f0, shift 0) for any z_raw.  The UV planes enter the neck's finest level through a
+    1x1 conv (v2.py:141-147); channels 0 / 1 are turned into clean carriers of A.u / A.v (every other producer of those
+    two channels on the finest level is zeroed: the last conv of the resampler feeding the level and the last conv of
+    each residual branch), the points head reads xy_raw = uv / f0 and z_raw = b u + c v + d from them, and the remaining
+    random channels contribute `noise` x their recipe weight.  Works for every ConvStack layout of the reference
+    (any resampler type, any number of res blocks, identity input / output blocks pass the carriers through unchanged).
     Random recipe weights alone give a map that no camera could have produced: the shift solve is then ill-conditioned
     and the focal comes out negative (round-1 fixtures), which is not the regime the pipeline runs in."""
+    cfg = cfg or SYNTHETIC_CONFIG
     P = PINHOLE
     A = P["A"]
     import torch as _t
@@ -90,18 +123,30 @@ def pinhole_overrides(sd):
         if bias:
             sd[name + ".bias"][0:2] = 0.0
 
+    def passthrough(name):          # a 1x1 conv [C_out, C_in, 1, 1] (or an identity: nothing to do)
+        if name + ".weight" in sd:
+            rows01(name)
+            sd[name + ".weight"][0, 0, 0, 0] = 1.0
+            sd[name + ".weight"][1, 1, 0, 0] = 1.0
+
     for stack in ("neck", "points_head"):
-        rows01(f"{stack}.resamplers.3.1")                 # 3x3 conv after the last transposed conv
-        rows01(f"{stack}.res_blocks.4.0.layers.5")         # second conv of the finest res block (residual branch)
-    w = sd["neck.input_blocks.4.weight"]                   # [32, 2, 1, 1] on the UV planes
+        L = len(cfg[stack]["dim_res_blocks"]) - 1
+        rows01(_last_conv(sd, f"{stack}.resamplers.{L - 1}"))
+        j = 0
+        while f"{stack}.res_blocks.{L}.{j}.layers.5.weight" in sd:     # second conv of every finest res block
+            rows01(f"{stack}.res_blocks.{L}.{j}.layers.5")
+            j += 1
+        assert j >= 1
+    L = len(cfg["neck"]["dim_res_blocks"]) - 1
+    w = sd[f"neck.input_blocks.{L}.weight"]                # [C, 2, 1, 1] on the UV planes
+    assert w.shape[1] == 2
     w[0:2] = 0.0
     w[0, 0, 0, 0], w[1, 1, 0, 0] = A, A
-    sd["neck.input_blocks.4.bias"][0:2] = 0.0
-    for name in ("neck.output_blocks.4", "points_head.input_blocks.4"):   # [32, 32, 1, 1] pass-through of ch 0, 1
-        rows01(name)
-        sd[name + ".weight"][0, 0, 0, 0] = 1.0
-        sd[name + ".weight"][1, 1, 0, 0] = 1.0
-    wo, bo = sd["points_head.output_blocks.4.weight"], sd["points_head.output_blocks.4.bias"]   # [3, 32, 1, 1]
+    sd[f"neck.input_blocks.{L}.bias"][0:2] = 0.0
+    passthrough(f"neck.output_blocks.{L}")
+    Lp = len(cfg["points_head"]["dim_res_blocks"]) - 1
+    passthrough(f"points_head.input_blocks.{Lp}")
+    wo, bo = sd[f"points_head.output_blocks.{Lp}.weight"], sd[f"points_head.output_blocks.{Lp}.bias"]   # [3, C, 1, 1]
     wo *= P["noise"]
     wo[:, 0:2] = 0.0
     wo[0, 0, 0, 0] = 1.0 / (A * P["f0"])
@@ -112,8 +157,9 @@ def pinhole_overrides(sd):
 
 
 def case_state_dict(name: str):
-    sd = recipe_state_dict_cpu(case_config(name))
-    return pinhole_overrides(sd) if "pinhole" in name else sd
+    cfg = case_config(name)
+    sd = recipe_state_dict_cpu(cfg)
+    return pinhole_overrides(sd, cfg) if name in PINHOLE_CASES else sd
 
 
 def moge_image(name: str, H: int, W: int) -> torch.Tensor:

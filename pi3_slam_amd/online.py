@@ -115,7 +115,7 @@ class Pi3SLAMOnline:
     def _ba_args(self, chunk: Dict) -> Optional[Dict]:
         if not self.bundle_adjust or chunk.get("keypoints") is None:
             return None
-        return {"width": int(chunk.get("original_width", 406)), "height": int(chunk.get("original_height", 308)),
+        return {"width": int(chunk.get("original_width", 1920)), "height": int(chunk.get("original_height", 1080)),
                 "max_observations_per_track": self.max_observations_per_track}
 
     def _refine_new_chunk(self, chunk: Dict) -> None:
@@ -211,6 +211,7 @@ class Pi3SLAMOnline:
                 assert meta["chunk_index"] == c
             if chunk is not None:
                 self._refine_new_chunk(chunk)
+                chunk.pop("_observations", None)      # chunk-parallel flow: no prior-constrained adjustment follows
             with torch.cuda.stream(self._align_stream):
                 Gs, oks = aligner.step(chunk, w0, n)
                 if chunk is not None:

@@ -136,6 +136,8 @@ class OfflineReconstructor:
             self._run_distributed(rank, world)
             return
         chunk_files = self._load_chunks()
+        self.refinement_stages = (["per_chunk_bundle_adjust", "closed_form_sim3", "prior_constrained_bundle_adjust"]
+                                  if self.bundle_adjust else ["closed_form_sim3"])
         print(f"🔄 Reconstructing {len(chunk_files)} chunks from {self.chunk_dir}")
         for idx, path in enumerate(chunk_files):
             print(f"\n📦 Loading {os.path.basename(path)} ({idx + 1}/{len(chunk_files)})")
@@ -184,8 +186,13 @@ class OfflineReconstructor:
              the blocks stay on the device under nccl = RCCL over xGMI);
           3. rank r solves only its own T_{c-1<-c}; a 136-byte all-gather distributes the [accepted, T] records;
           4. every rank forms G_c = G_{c-1} . T_c by the prefix product (dist.align_wave) and applies G_c to its chunk.
-        Rank 0 collects the transformed chunks for the trajectory / point-cloud files.  Equal to the sequential run:
-        both solve on chunk-frame fp16 values and compose (alignment.align_and_refine_reconstructions).
+        Rank 0 collects the transformed chunks for the trajectory / point-cloud files.
+        With bundle_adjust=False this equals the sequential run: both solve on chunk-frame fp16 values and compose
+        (alignment.align_and_refine_reconstructions).  With bundle_adjust=True it does NOT: the per-chunk refinement
+        (chunk_reconstruction.py:188-219) runs on every rank, but the prior-constrained refinement after each alignment
+        (reconstruction_alignment.py:107-171) needs the REFINED predecessor - a strictly sequential chain
+        (offline_reconstructor.py:130-133) - and is skipped; self.refinement_stages says which stages ran and the run
+        prints it.  tests/test_pipeline_gpu.py bounds the trajectory difference on consistent data.
         `solve` (tests): replaces the device solver, see dist.default_solver."""
         import torch.distributed as dist
 
@@ -195,12 +202,18 @@ class OfflineReconstructor:
         n_chunks = len(files)
         aligner = WaveAligner(rank, world, self.overlap, self.chunk_length, self.device, solve)
         print(f"🔄 Reconstructing {n_chunks} chunks from {self.chunk_dir} on {world} ranks (rank {rank})")
+        self.refinement_stages = (["per_chunk_bundle_adjust"] if self.bundle_adjust else []) + ["closed_form_sim3"]
+        if self.bundle_adjust and rank == 0:
+            print("   ℹ️  chunk-parallel run: per-chunk bundle adjustment + closed-form Sim(3) chain; the prior-constrained "
+                  "bundle adjustment after each alignment is sequential by construction and is NOT run "
+                  "(single-process run, or --no-bundle-adjust, for identical trajectories)")
         mine: List[Dict] = []
         for w0 in range(0, n_chunks, world):
             c = w0 + rank
             data = torch.load(files[c], map_location="cpu", weights_only=False) if c < n_chunks else None
             if data is not None:    # the per-chunk refinement is independent per chunk; the prior-constrained one after
                 self._bundle_adjust_new_chunk(data, c)   # each alignment needs the refined predecessor: sequential only
+                data.pop("_observations", None)          # no later adjustment will read them (device memory)
             Gs, oks = aligner.step(data, w0, n_chunks)
             for r, ok in enumerate(oks):
                 if not ok and rank == 0:

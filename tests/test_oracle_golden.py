@@ -90,7 +90,8 @@ def test_umeyama_known_answers():
 
 
 @pytest.mark.parametrize("name", ["moge_small", "moge_chunk", "moge_pinhole_small", "moge_pinhole_chunk",
-                                  "moge_var_pixelshuffle", "moge_var_interp", "moge_var_elu"])
+                                  "moge_var_pixelshuffle", "moge_var_interp", "moge_var_elu", "moge_vitl",
+                                  "moge_vitb_reg"])
 def test_moge_oracle_matches_reference_vectors(name):
     """MoGe-2 restatement vs the real MoGeModel class (synthetic model_config + recipe weights; the 'pinhole' cases
     edit a few 1x1 convolutions so the predicted map is camera-consistent: focal > 0, well-conditioned shift)."""

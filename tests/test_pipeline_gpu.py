@@ -304,6 +304,94 @@ def test_two_rank_pipeline_matches_single_process(tmp_path, built_lib):
     assert np.abs(o1[:, 1:4] - t1[:, 1:4]).max() / scale < 1e-4      # and the online flow equals the offline one
 
 
+def test_reconstruct_with_bundle_adjust_under_torchrun_is_bounded(tmp_path, built_lib):
+    """What `reconstruct` does under torch.distributed.run when bundle adjustment is on (the default), stated and
+    bounded: the reference's flow is strictly sequential (slam/offline_reconstructor.py:130-133: align chunk c to the
+    already refined chunk c-1, then the prior-constrained BA of utils/reconstruction_alignment.py:107-171); the
+    chunk-parallel flow runs the per-chunk BA on every rank and the closed-form Sim(3) chain, NOT the prior-constrained
+    BA, and says so (refinement_stages, a printed note).  On geometrically consistent chunks (five overlapping cuts of
+    one synthetic scene) both flows recover the ground-truth trajectory and differ by < 2 cm on a 1.5 m path."""
+    import subprocess
+    import sys
+    from ba_problem import make_problem
+    N, K, W, H = 12, 40, 406, 308
+    pb = make_problem(N=N, K=K, seed=2)
+    poses = np.tile(np.eye(4, dtype=np.float32), (N, 1, 1))
+    poses[:, :3, :3] = pb["R_gt"].transpose(0, 2, 1)
+    poses[:, :3, 3] = pb["C_gt"]
+    K3 = np.zeros((N, 3, 3), np.float32)
+    K3[:, 0, 0], K3[:, 1, 1], K3[:, 0, 2], K3[:, 1, 2], K3[:, 2, 2] = pb["intr"][:, 0], pb["intr"][:, 1], pb["intr"][:, 2], pb["intr"][:, 3], 1
+    idx = np.arange(N)
+    full = dict(points=torch.from_numpy(pb["X_gt"].reshape(N, K, 3)).half(), camera_poses=torch.from_numpy(poses),
+                intrinsics=torch.from_numpy(K3), keypoints=torch.from_numpy(pb["uv"][idx, idx]).half(),
+                masks=torch.ones(N, K, 1, dtype=torch.bool), colors=torch.full((N, K, 3), 99.0).half())
+    cdir = tmp_path / "chunks_root"
+    os.makedirs(cdir / "chunks")
+    cl, ov = 4, 2
+    starts = list(range(0, N - ov, cl - ov))                    # 0, 2, 4, 6, 8 -> five chunks of four views
+    for c, s0 in enumerate(starts):
+        sl = slice(s0, s0 + cl)
+        d = {k: v[sl].clone() for k, v in full.items()}
+        # every chunk in its own frame: a similarity of the scene, as chunks of a real run are
+        ang, sc, t = 0.2 * c, 1.0 + 0.05 * c, torch.tensor([0.3 * c, -0.1 * c, 0.05 * c])
+        R = torch.tensor([[np.cos(ang), -np.sin(ang), 0.0], [np.sin(ang), np.cos(ang), 0.0], [0.0, 0.0, 1.0]], dtype=torch.float32)
+        d["points"] = (((d["points"].float() - t) @ R) / sc).half()
+        P = d["camera_poses"].clone()
+        P[:, :3, :3] = R.T @ P[:, :3, :3]
+        P[:, :3, 3] = ((d["camera_poses"][:, :3, 3] - t) @ R) / sc
+        d["camera_poses"] = P
+        d.update(image_paths=[[f"img_{i:03d}.png"] for i in range(s0, s0 + cl)], original_width=W, original_height=H,
+                 chunk_index=c)
+        torch.save(d, cdir / "chunks" / f"chunk_{c:06d}.pt")
+    json.dump({"chunk_length": cl, "overlap": ov, "target_size": [H, W]}, open(cdir / "chunk_metadata.json", "w"))
+    worker = os.path.join(os.path.dirname(__file__), "dist_recon_worker.py")
+    env = dict(os.environ, PI3_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r1 = subprocess.run([sys.executable, worker, str(cdir), str(tmp_path / "seq")], env=env, capture_output=True,
+                        text=True, timeout=300)
+    assert r1.returncode == 0, r1.stdout[-2000:] + r1.stderr[-2000:]
+    r2 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                         "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), worker, str(cdir),
+                         str(tmp_path / "par")], env=env, capture_output=True, text=True, timeout=300)
+    assert r2.returncode == 0, r2.stdout[-2000:] + r2.stderr[-2000:]
+    s1, s2 = json.load(open(tmp_path / "seq" / "stages.json")), json.load(open(tmp_path / "par" / "stages.json"))
+    assert s1["stages"] == ["per_chunk_bundle_adjust", "closed_form_sim3", "prior_constrained_bundle_adjust"]
+    assert s2["stages"] == ["per_chunk_bundle_adjust", "closed_form_sim3"] and "NOT run" in r2.stdout
+    assert all(s1["ba"]) and all(s2["ba"])
+    t1 = np.loadtxt(tmp_path / "seq" / "trajectory_tum.txt")
+    t2 = np.loadtxt(tmp_path / "par" / "trajectory_tum.txt")
+    assert t1.shape == t2.shape == (N, 8)
+    # both live in chunk 0's frame = the scene frame (chunk 0 was cut with the identity similarity)
+    assert np.abs(t1[:, 1:4] - pb["C_gt"]).max() < 2e-2 and np.abs(t2[:, 1:4] - pb["C_gt"]).max() < 2e-2
+    assert np.abs(t1[:, 1:4] - t2[:, 1:4]).max() < 2e-2
+
+
+def test_bench_two_ranks_rehearsal(tmp_path, built_lib):
+    """`bench.py --gpus 2` exactly as the driver launches it (torch.distributed.run, one rank per process), with gloo
+    standing in for RCCL because both ranks share this box's one GPU: the N > 1 branch (one chunk per rank per step,
+    boundary all-gather, own solve, 136-byte all-gather, prefix product, max-over-ranks timing) runs end to end and
+    prints ONE JSON line with the whole-job aggregate."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PI3_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(root, "bench.py"),
+                        "--gpus", "2", "--steps", "2", "--warmup", "1"], env=env, capture_output=True, text=True,
+                       timeout=600, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["steps"] == 2 and rec["scaling"] == "weak" and rec["unit"] == "frames/s"
+    assert rec["value"] > 0 and abs(rec["value"] - 2 * 100 * 2 / (rec["ms_per_step"] * 2 / 1e3)) < 1e-6 * rec["value"]
+    assert rec["roofline"]["bound"] == "mfma" and 0 < rec["roofline"]["frac"] < 1
+    assert "cpu_baseline" not in rec            # rank 0 at N = 1 only
+
+
 def test_rccl_branch_with_a_one_rank_group(tmp_path, built_lib):
     """The nccl (= RCCL) branch of the chunk-parallel code on the hardware that is available: ONE rank on this box's GPU
     (two ranks cannot share a card under RCCL).  Device-resident boundary blocks, all-gathers of device tensors,

@@ -49,6 +49,8 @@ struct Attn64Params {
   bf16_t* o; long o_tok_stride, o_batch_stride;
   int S, H, B, nqb;
   const float* k2max;   // [B][H] max over keys of |k|^2, or null (always online max)
+  int prio;             // 1: waves NW/2 .. NW-1 (the later-dispatched wave of every SIMD) run at s_setprio 1 (A/B knob)
+  int tailopt;          // 1: short-sequence waves skip query blocks / key halves that do not exist (A/B knob, default 1)
   unsigned long long* dbg;   // -DPI3_ATTN_STAMPS builds only: s_memtime stamps of workgroup 0
 };
 #ifndef A64_ABL   // development builds only (-DA64_ABL=n, a separate .so): timing ablations with WRONG results.
@@ -99,14 +101,15 @@ __device__ __forceinline__ void a64_glds16(const void* gsrc, const void* lds_dst
 // lacc (D_b[i][j] = sum_k B_b[k][j], and lane 4b+j holds both column j of B_b and column j of D_b).  16 two-pass MFMAs
 // replace 68 v_add_f32 per tile, and l sums exactly the bf16 values that P.V multiplies.
 typedef short s16x4 __attribute__((ext_vector_type(4)));
-template <bool FIRST, bool NOMAX, bool MSUM>
+// NKT = 1: only the first 32 keys of the tile exist (a short last tile): sc[1] / pf[1] are not touched.
+template <bool FIRST, bool NOMAX, bool MSUM, int NKT = 2>
 __device__ __forceinline__ void a64_softmax(f32x16 (&sc)[2], float& m, f32x16 (&o)[2], float& l, f32x4& lacc,
                                             bf16x8 (&pf)[2][2]) {
   if constexpr (NOMAX) {
     float ps0 = 0.f, ps1 = 0.f;
     const s16x4 ones = {0x3f80, 0x3f80, 0x3f80, 0x3f80};
 #pragma unroll
-    for (int kt = 0; kt < 2; ++kt)
+    for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
         u32x4 pw;
@@ -134,8 +137,10 @@ __device__ __forceinline__ void a64_softmax(f32x16 (&sc)[2], float& m, f32x16 (&
   float tmax = sc[0][0];
 #pragma unroll
   for (int i = 1; i < 16; ++i) tmax = fmaxf(tmax, sc[0][i]);
+  if constexpr (NKT == 2) {
 #pragma unroll
-  for (int i = 0; i < 16; ++i) tmax = fmaxf(tmax, sc[1][i]);
+    for (int i = 0; i < 16; ++i) tmax = fmaxf(tmax, sc[1][i]);
+  }
   tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
   if (FIRST) {
     m = tmax;
@@ -152,7 +157,7 @@ __device__ __forceinline__ void a64_softmax(f32x16 (&sc)[2], float& m, f32x16 (&
   }
   float psum = 0.f;
 #pragma unroll
-  for (int kt = 0; kt < 2; ++kt)
+  for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2) {
       u32x4 pw;
@@ -275,17 +280,21 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd64_kernel(Attn64Params p) 
   const int vin_l = (vcol_l & 7) * 2;
   const int vswz = ((vrow_l >> 1) & 1) << 2;
 
-#define A64_MASK(T, SC)                                                                                          \
+#define A64_MASK(T, SC, NKT)                                                                                     \
   {                                                                                                               \
     const int kb = (T) * A64_KT + 4 * h;                                                                          \
-    _Pragma("unroll") for (int kt = 0; kt < 2; ++kt)                                                              \
+    _Pragma("unroll") for (int kt = 0; kt < (NKT); ++kt)                                                          \
     _Pragma("unroll") for (int i = 0; i < 16; ++i) {                                                              \
       const int key = kb + 32 * kt + (i & 3) + 8 * (i >> 2);                                                      \
       if (key >= S) SC[kt][i] = -INFINITY;                                                                        \
     }                                                                                                             \
   }
 
-#define A64_TILE(T, BUF, FIRST, LAST, CLAMPNEXT, NOMAX)                                                               \
+// NB = query blocks this wave owns (2; a wave at the end of a short sequence owns 1 or 0: it still stages K/V and
+// keeps the barriers, but issues no MFMA / softmax work for rows that do not exist - on 643-token frames the third
+// workgroup's waves own 2, 2, 1 (3 rows) and 0 blocks).  NKT = 32-key halves of this tile (2; 1 for a last tile with
+// <= 32 keys: 643 = 10 x 64 + 3).
+#define A64_TILE(T, BUF, FIRST, LAST, CLAMPNEXT, NOMAX, NB, NKT)                                                  \
   {                                                                                                               \
     const int buf = (BUF);                                                                                        \
     A64_STAMP(T, 0)                                                                                               \
@@ -295,31 +304,35 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd64_kernel(Attn64Params p) 
     const char* kl = lds + buf * 8192 + krow_off;                                                                 \
     const char* vl = lds + 16384 + buf * 8192;                                                                    \
     const bool masktail = (LAST) && (S & (A64_KT - 1));                                                           \
-    {                                                                                                             \
+    if ((NB) > 0) {                                                                                               \
       {                                                                                                           \
         const int off = (h ^ kswz) << 4;                                                                          \
         const bf16x8 a0 = *(const bf16x8*)(kl + off);                                                             \
-        const bf16x8 a1 = *(const bf16x8*)(kl + 32 * 128 + off);                                                  \
         scA[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, qfA[0], (f32x16)(0.f), 0, 0, 0);                     \
-        scB[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, qfB[0], (f32x16)(0.f), 0, 0, 0);                     \
-        scA[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, qfA[0], (f32x16)(0.f), 0, 0, 0);                     \
-        scB[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, qfB[0], (f32x16)(0.f), 0, 0, 0);                     \
+        if ((NB) == 2) scB[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, qfB[0], (f32x16)(0.f), 0, 0, 0);      \
+        if ((NKT) == 2) {                                                                                         \
+          const bf16x8 a1 = *(const bf16x8*)(kl + 32 * 128 + off);                                                \
+          scA[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, qfA[0], (f32x16)(0.f), 0, 0, 0);                   \
+          if ((NB) == 2) scB[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, qfB[0], (f32x16)(0.f), 0, 0, 0);    \
+        }                                                                                                         \
       }                                                                                                           \
       if (A64_ABL != 4)                                                                                           \
       _Pragma("unroll") for (int s = 1; s < 4; ++s) {                                                             \
         const int off = A64_ABL == 7 ? ((h ^ kswz) << 4) : (((2 * s + h) ^ kswz) << 4);                           \
         const bf16x8 a0 = *(const bf16x8*)(kl + off);                                                             \
-        const bf16x8 a1 = *(const bf16x8*)(kl + 32 * 128 + off);                                                  \
         scA[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, qfA[s], scA[0], 0, 0, 0);                            \
-        scB[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, qfB[s], scB[0], 0, 0, 0);                            \
-        scA[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, qfA[s], scA[1], 0, 0, 0);                            \
-        scB[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, qfB[s], scB[1], 0, 0, 0);                            \
+        if ((NB) == 2) scB[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, qfB[s], scB[0], 0, 0, 0);             \
+        if ((NKT) == 2) {                                                                                         \
+          const bf16x8 a1 = *(const bf16x8*)(kl + 32 * 128 + off);                                                \
+          scA[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, qfA[s], scA[1], 0, 0, 0);                          \
+          if ((NB) == 2) scB[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, qfB[s], scB[1], 0, 0, 0);           \
+        }                                                                                                         \
       }                                                                                                           \
-      if (masktail) { A64_MASK(T, scA) A64_MASK(T, scB) }                                                         \
+      if (masktail) { A64_MASK(T, scA, NKT) if ((NB) == 2) { A64_MASK(T, scB, NKT) } }                            \
       A64_STAMP(T, 1)                                                                                             \
-      a64_softmax<FIRST, NOMAX, MSUM>(scA, mA, oA, lA, laccA, pfA);                                                                   \
-      a64_softmax<FIRST, NOMAX, MSUM>(scB, mB, oB, lB, laccB, pfB);                                                                   \
-      _Pragma("unroll") for (int kt = 0; kt < 2; ++kt)                                                            \
+      a64_softmax<FIRST, NOMAX, MSUM, NKT>(scA, mA, oA, lA, laccA, pfA);                                          \
+      if ((NB) == 2) a64_softmax<FIRST, NOMAX, MSUM, NKT>(scB, mB, oB, lB, laccB, pfB);                           \
+      _Pragma("unroll") for (int kt = 0; kt < (NKT); ++kt)                                                        \
       _Pragma("unroll") for (int s2 = 0; s2 < 2; ++s2) {                                                          \
         const int row0 = 32 * kt + 16 * s2 + vrow_l;                                                              \
         _Pragma("unroll") for (int dt = 0; dt < 2; ++dt) {                                                        \
@@ -332,7 +345,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd64_kernel(Attn64Params p) 
               (__attribute__((address_space(3))) bf16x4*)LDS_PTR(a + 8 * 128));                                   \
           const bf16x8 vf = a64_cat4(lo, hi);                                                                     \
           oA[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pfA[kt][s2], oA[dt], 0, 0, 0);                     \
-          oB[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pfB[kt][s2], oB[dt], 0, 0, 0);                     \
+          if ((NB) == 2) oB[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pfB[kt][s2], oB[dt], 0, 0, 0);      \
         }                                                                                                         \
       }                                                                                                           \
     }                                                                                                             \
@@ -346,13 +359,32 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd64_kernel(Attn64Params p) 
     }                                                                                                             \
   }
 
+// the whole key sweep for a wave that owns NB query blocks; the last tile takes the 32-key form when it holds <= 32 keys
+#define A64_SWEEP(NOMAX, NB)                                                                                      \
+  {                                                                                                               \
+    if (nt == 1) {                                                                                                \
+      if (half_last) { A64_TILE(0, 0, true, true, false, NOMAX, NB, 1) }                                          \
+      else { A64_TILE(0, 0, true, true, false, NOMAX, NB, 2) }                                                    \
+    } else {                                                                                                      \
+      A64_TILE(0, 0, true, false, (tail && nt == 2), NOMAX, NB, 2)                                                \
+      for (int t = 1; t < nt - 1; ++t) A64_TILE(t, (t & 1), false, false, (tail && t == nt - 2), NOMAX, NB, 2)    \
+      if (half_last) { A64_TILE(nt - 1, ((nt - 1) & 1), false, true, false, NOMAX, NB, 1) }                       \
+      else { A64_TILE(nt - 1, ((nt - 1) & 1), false, true, false, NOMAX, NB, 2) }                                 \
+    }                                                                                                             \
+  }
+
   const bool tail = (S & (A64_KT - 1)) != 0;
 #ifdef PI3_ATTN_STAMPS
   if (p.dbg && blockIdx.x == 8 && tid == 0) { p.dbg[1000] = a64_stamp(); p.dbg[1001] = a64_realtime(); }
 #endif
+  // the last tile holds S - 64 (nt - 1) keys: when that is <= 32 its second 32-key half is skipped (frame-wise
+  // sequences: 643 = 10 x 64 + 3); long sequences keep one code path (their last tile is one of a thousand)
+  const bool half_last = (NW == 4) && p.tailopt && (S - (nt - 1) * A64_KT <= 32);
+  // query blocks this wave owns (see A64_TILE); long sequences (NW == 8) keep the single two-block path
+  const int nb = (NW == 4 && p.tailopt) ? (q0 >= S ? 0 : (q0 + 32 >= S ? 1 : 2)) : 2;
   // bounded-score test (see header): wave-uniform
   bool fast = false;
-  if (p.k2max) {
+  if (p.k2max && nb > 0) {
     const float k2 = p.k2max[b * p.H + head];
     float qa = 0.f, qb = 0.f;
 #pragma unroll
@@ -367,22 +399,15 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd64_kernel(Attn64Params p) 
     qb += __shfl_xor(qb, 32, 64);
     fast = __all(fmaxf(qa, qb) * k2 <= A64_BOUND2);
   }
-  if (fast) {
-    if (nt == 1) {
-      A64_TILE(0, 0, true, true, false, true)
-    } else {
-      A64_TILE(0, 0, true, false, (tail && nt == 2), true)
-      for (int t = 1; t < nt - 1; ++t) A64_TILE(t, (t & 1), false, false, (tail && t == nt - 2), true)
-      A64_TILE(nt - 1, ((nt - 1) & 1), false, true, false, true)
-    }
+  // static priority for the second-dispatched half (MI355X_MICROARCH.md, two waves per SIMD, item 4): the younger
+  // wave of a SIMD loses every VALU arbitration at equal priority
+  if (p.prio && wave >= NW / 2) __builtin_amdgcn_s_setprio(1);
+  if (nb == 2) {
+    if (fast) A64_SWEEP(true, 2) else A64_SWEEP(false, 2)
+  } else if (nb == 1) {
+    if (fast) A64_SWEEP(true, 1) else A64_SWEEP(false, 1)
   } else {
-    if (nt == 1) {
-      A64_TILE(0, 0, true, true, false, false)
-    } else {
-      A64_TILE(0, 0, true, false, (tail && nt == 2), false)
-      for (int t = 1; t < nt - 1; ++t) A64_TILE(t, (t & 1), false, false, (tail && t == nt - 2), false)
-      A64_TILE(nt - 1, ((nt - 1) & 1), false, true, false, false)
-    }
+    A64_SWEEP(true, 0)
   }
 
 #ifdef PI3_ATTN_STAMPS
@@ -496,6 +521,18 @@ int pi3_attention64_launch(const void* q, const void* k, const void* v, long tok
   }
   p.k2max = nullptr;
   p.dbg = nullptr;
+  static int prio = -1;   // PI3_ATTN_PRIO: 1 = static s_setprio 1 for the second half of a workgroup's waves (A/B knob)
+  if (prio < 0) {
+    const char* e = getenv("PI3_ATTN_PRIO");
+    prio = e ? atoi(e) : 0;
+  }
+  p.prio = prio;
+  static int tailopt = -1;   // PI3_ATTN_TAILOPT: 0 = every wave runs two query blocks and full key tiles (A/B knob)
+  if (tailopt < 0) {
+    const char* e = getenv("PI3_ATTN_TAILOPT");
+    tailopt = e ? atoi(e) : 1;
+  }
+  p.tailopt = tailopt;
 #ifdef PI3_ATTN_STAMPS
   static unsigned long long* dbgbuf = nullptr;
   if (!dbgbuf) hipMalloc((void**)&dbgbuf, 2048 * 8);

@@ -37,6 +37,7 @@ struct Attn64Params {
   bf16_t* o; long o_tok_stride, o_batch_stride;
   int S, H, B, nqb;
   const float* k2max;
+  int prio, tailopt;    // (attn64.hip's knobs; unused by this kernel - the struct must match attn64.hip's field for field)
   unsigned long long* dbg;
 };
 #ifndef P64_ABL   // development builds only (-DP64_ABL=1: no exp; timing ablation with WRONG results, never in the product .so)

@@ -5,6 +5,7 @@
 #include "common.h"
 #include <hip/hip_fp16.h>
 #include <float.h>
+#include <string.h>
 
 // ---------------------------------------------------------------------------------------------------------------
 // masks = sigmoid(conf) > thr  &  ~depth_edge(z, rtol)         (offline_chunk_creator.py:114-119)
@@ -15,63 +16,83 @@
 // Phase 1 stages the z channel of the strip and its two halo rows in LDS from the interleaved (x, y, z) rows with
 // 16-byte loads: a float4 at strip offset s = 3 pix + r holds the z of pixel pix at lane element (2 - r) mod 3 (and a
 // second one, of pix + 1, when r == 2), and a thread's next float4 is 1024 floats on = 341 pixels + 1 float, so the
-// walk needs no division at all (round 2 read one float per instruction and did `% 3` and `/ 3` per element: 1.1 TB/s).
+// walk needs no division (round 2 read one float per instruction and did `% 3` and `/ 3` per element: 1.1 TB/s).
 // An aligned 16-byte load that holds one valid float cannot cross a page, so the ragged first / last float4 are safe.
+// The LDS image has one extra column on either side holding a copy of the row's first / last pixel, and rows are
+// addressed with a clamp: max_pool2d's implicit -inf padding means "ignore what is outside", and a replicated edge
+// value is a value the window contains anyway - so phase 2 has NO bounds tests (they were 36 of ~100 instructions per
+// pixel; the kernel is VALU-bound, not memory-bound: 9 window reads, NaN tracking, an IEEE division, a sigmoid).
 // Phase 2 walks the strip as ONE contiguous pixel range (full rows of a [F][H][W] array are contiguous): four
 // consecutive pixels per thread, float4 confidence load, uchar4 mask store, one row/column split per group.
 #define MK_ROWS 14
 #define MK_MAXW 1024
 
-__device__ __forceinline__ uint8_t mask_pixel(const float* zs, int ylo, int y, int x, int H, int W, float c, float thr,
-                                              float rtol) {
-  const float z = zs[(y - ylo) * W + x];
-  float mx = z, mn = z;
-  bool anynan = isnan(z);  // max_pool2d propagates NaN (a NaN in the window wins), fmaxf would drop it
-#pragma unroll
-  for (int dy = -1; dy <= 1; ++dy)
-#pragma unroll
-    for (int dx = -1; dx <= 1; ++dx) {
-      const int yy = y + dy, xx = x + dx;
-      if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
-        const float v = zs[(yy - ylo) * W + xx];
-        mx = fmaxf(mx, v);
-        mn = fminf(mn, v);
-        anynan = anynan || isnan(v);
-      }
-    }
+// zr0 / zr1 / zr2: LDS rows above / at / below the pixel (clamped), already offset so that index x is the pixel's left
+// neighbour (the image is stored from column 1).
+// estar: the largest e >= 0 with fl(1 / fl(1 + e)) > thr (found on the host, see pi3_compute_masks): sigmoid(c) > thr
+// <=> expf(-c) <= estar, decision for decision (the outer 1 / (1 + e) is monotone in e and correctly rounded on both
+// sides), without the add and the IEEE division per pixel.
+__device__ __forceinline__ uint8_t mask_pixel(const float* zr0, const float* zr1, const float* zr2, int x, float c,
+                                              float estar, float rtol) {
+  const float a0 = zr0[x], a1 = zr0[x + 1], a2 = zr0[x + 2];
+  const float b0 = zr1[x], z = zr1[x + 1], b2 = zr1[x + 2];
+  const float c0 = zr2[x], c1 = zr2[x + 1], c2 = zr2[x + 2];
+  // max_pool2d propagates NaN (a NaN in the window wins), fmaxf would drop it
+  const bool anynan = isnan(a0) | isnan(a1) | isnan(a2) | isnan(b0) | isnan(z) | isnan(b2) | isnan(c0) | isnan(c1) | isnan(c2);
+  const float mx = fmaxf(fmaxf(fmaxf(a0, a1), fmaxf(a2, b0)), fmaxf(fmaxf(z, b2), fmaxf(fmaxf(c0, c1), c2)));
+  const float mn = fminf(fminf(fminf(a0, a1), fminf(a2, b0)), fminf(fminf(z, b2), fminf(fminf(c0, c1), c2)));
   float ratio = anynan ? __uint_as_float(0x7fc00000u) : (mx + (-mn)) / z;
   if (isnan(ratio)) ratio = 0.f;
   else if (isinf(ratio)) ratio = ratio > 0.f ? FLT_MAX : -FLT_MAX;
   const bool edge = ratio > rtol;
-  const float sg = 1.0f / (1.0f + expf(-c));
-  return (sg > thr && !edge) ? 1 : 0;
+  return (expf(-c) <= estar && !edge) ? 1 : 0;
 }
 
 __global__ __launch_bounds__(256) void masks_kernel(const float* __restrict__ conf, const float* __restrict__ lp,
                                                     int F, int H, int W, float thr, float rtol,
-                                                    uint8_t* __restrict__ out) {
-  extern __shared__ __attribute__((aligned(16))) float zs[];          // (MK_ROWS + 2) * W floats
+                                                    uint8_t* __restrict__ out) {   // thr: the e-threshold (estar)
+  extern __shared__ __attribute__((aligned(16))) float zs[];          // (MK_ROWS + 2) rows of W + 2 floats
   const int strips = (H + MK_ROWS - 1) / MK_ROWS;
   const int f = blockIdx.x / strips, y0 = (blockIdx.x % strips) * MK_ROWS;
   const int tid = threadIdx.x;
   const int ylo = max(y0 - 1, 0), yhi = min(y0 + MK_ROWS + 1, H);       // staged rows [ylo, yhi)
+  const int P = W + 2, nst = yhi - ylo;
   {
     const float* first = lp + ((long)f * H + ylo) * W * 3;
     const uintptr_t addr = (uintptr_t)first, aligned = addr & ~(uintptr_t)15;
     const int lead = (int)((addr - aligned) >> 2);                      // floats in front of the strip in float4 0
     const float4* src = (const float4*)aligned;
-    const int npix = (yhi - ylo) * W;
+    const int npix = nst * W;
     const int nq = (lead + 3 * npix + 3) >> 2;
     const int s3 = 4 * tid - lead + 3;                                  // strip offset of element 0, biased by +3 (>= 0)
     int pix = s3 / 3 - 1, r = s3 - 3 * (s3 / 3);
+    // (row, x) of pixel `pix`, kept incrementally; pix = -1 (only possible for the very first float4) maps to (0, -1)
+    int row = pix < 0 ? 0 : pix / W, x = pix < 0 ? -1 : pix - row * W;
+    const bool wide = W >= 342;                                         // one conditional subtraction per step is enough
     for (int q = tid; q < nq; q += 256) {
       const float4 v = src[q];
       const float za = r == 0 ? v.z : (r == 1 ? v.y : v.x);
-      if (pix >= 0 && pix < npix) zs[pix] = za;
-      if (r == 2 && pix + 1 < npix) zs[pix + 1] = v.w;
+      if (pix >= 0 && pix < npix) zs[row * P + 1 + x] = za;
+      if (r == 2 && pix + 1 < npix) {
+        const bool wrap = x + 1 >= W;
+        zs[(wrap ? row + 1 : row) * P + 1 + (wrap ? 0 : x + 1)] = v.w;
+      }
       pix += 341;                                                       // 256 threads x 4 floats = 1024 = 3 * 341 + 1
-      if (++r == 3) { r = 0; ++pix; }
+      x += 341;
+      if (++r == 3) { r = 0; ++pix; ++x; }
+      if (wide) {
+        if (x >= W) { x -= W; ++row; }
+      } else {
+        row = pix / W;
+        x = pix - row * W;
+      }
     }
+  }
+  __syncthreads();
+  if (tid < 2 * nst) {                                                  // replicated edge columns
+    const int rr = tid >> 1;
+    if (tid & 1) zs[rr * P + W + 1] = zs[rr * P + W];
+    else zs[rr * P] = zs[rr * P + 1];
   }
   __syncthreads();
   const int rows = min(MK_ROWS, H - y0);
@@ -80,27 +101,41 @@ __global__ __launch_bounds__(256) void masks_kernel(const float* __restrict__ co
   const bool vec_ok = (((uintptr_t)conf & 15) == 0) && (((uintptr_t)out & 3) == 0);
   const int lead2 = (int)(p0 & 3);
   const int ngroups = (lead2 + npx + 3) >> 2;
+  const int yoff = y0 - ylo;                                            // staged row of the strip's first row (0 or 1)
   for (int g = tid; g < ngroups; g += 256) {
     const int e0 = 4 * g - lead2;                                       // strip-linear index of the group's first pixel
     const int eb = max(e0, 0);
     int ry = eb / W, x = eb - ry * W;
-    if (vec_ok && e0 >= 0 && e0 + 4 <= npx) {
+    const int n = min(e0 + 4, npx) - eb;                                // pixels of this group inside the strip (1..4)
+    const bool full = vec_ok && e0 >= 0 && n == 4;
+    float cc[4];
+    if (full) {
       const float4 c = *(const float4*)(conf + p0 + e0);
-      const float cc[4] = {c.x, c.y, c.z, c.w};
-      uchar4 m;
-      uint8_t mm[4];
+      cc[0] = c.x; cc[1] = c.y; cc[2] = c.z; cc[3] = c.w;
+    } else {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        mm[i] = mask_pixel(zs, ylo, y0 + ry, x, H, W, cc[i], thr, rtol);
+      for (int i = 0; i < 4; ++i) cc[i] = i < n ? conf[p0 + eb + i] : 0.f;
+    }
+    uint8_t mm[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (i < n) {
+        const int yc = yoff + ry;
+        const float* zr1 = zs + yc * P;
+        const float* zr0 = zs + max(yc - 1, 0) * P;
+        const float* zr2 = zs + min(yc + 1, nst - 1) * P;
+        mm[i] = mask_pixel(zr0, zr1, zr2, x, cc[i], thr, rtol);
         if (++x >= W) { x = 0; ++ry; }
       }
+    }
+    if (full) {
+      uchar4 m;
       m.x = mm[0]; m.y = mm[1]; m.z = mm[2]; m.w = mm[3];
       *(uchar4*)(out + p0 + e0) = m;
     } else {
-      for (int e = eb; e < min(e0 + 4, npx); ++e) {
-        out[p0 + e] = mask_pixel(zs, ylo, y0 + ry, x, H, W, conf[p0 + e], thr, rtol);
-        if (++x >= W) { x = 0; ++ry; }
-      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (i < n) out[p0 + eb + i] = mm[i];
     }
   }
 }
@@ -112,9 +147,31 @@ extern "C" int pi3_compute_masks(const float* conf, const float* local_points, i
     pi3_set_error("pi3_compute_masks: bad arguments (W <= %d, 4-byte aligned maps)", MK_MAXW);
     return PI3_ERR_ARG;
   }
+  // sigmoid(c) > conf_thr, i.e. fl(1 / fl(1 + e)) > conf_thr with e = expf(-c): the set of such e is an interval
+  // [0, estar]; bisect estar over the bit patterns of the non-negative floats (they order like the values) with the
+  // same two correctly rounded fp32 operations the kernel used to do per pixel
+  float estar = -1.0f;
+  {
+    auto pass = [&](uint32_t bits) {
+      float e;
+      memcpy(&e, &bits, 4);
+      volatile float d = 1.0f + e;
+      volatile float sg = 1.0f / d;
+      return sg > conf_thr;
+    };
+    if (pass(0u)) {
+      uint32_t lo = 0u, hi = 0x7f800000u;          // pass(lo) holds; +inf fails unless conf_thr < 0
+      if (pass(hi)) lo = hi;
+      while (hi - lo > 1u) {
+        const uint32_t mid = lo + (hi - lo) / 2u;
+        if (pass(mid)) lo = mid; else hi = mid;
+      }
+      memcpy(&estar, &lo, 4);
+    }
+  }
   const long nwg = (long)F * ((H + MK_ROWS - 1) / MK_ROWS);
-  hipLaunchKernelGGL(masks_kernel, dim3((unsigned)nwg), dim3(256), (size_t)(MK_ROWS + 2) * W * sizeof(float),
-                     (hipStream_t)stream, conf, local_points, F, H, W, conf_thr, rtol, masks);
+  hipLaunchKernelGGL(masks_kernel, dim3((unsigned)nwg), dim3(256), (size_t)(MK_ROWS + 2) * (W + 2) * sizeof(float),
+                     (hipStream_t)stream, conf, local_points, F, H, W, estar, rtol, masks);
   return pi3_check_launch("compute_masks");
 }
 

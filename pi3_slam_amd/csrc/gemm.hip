@@ -259,6 +259,10 @@ extern "C" int pi3_gemm_qkv(const void* A, long lda, const void* W, long ldw, in
   p.qk_mode = 1; p.qk_H = H; p.qk_T = T; p.qk_pos = pos; p.qk_cs = cs;
   p.qk_qw = qw; p.qk_qb = qb; p.qk_kw = kw; p.qk_kb = kb; p.qk_eps = eps; p.qk_qscale = qscale;
   p.qk_k2max = k2max; p.qk_attnS = attn_S > 0 ? attn_S : M;
+  if (!qw && !pos) {       // no LayerNorm, no RoPE (encoder blocks): the q scale rides in the plain epilogue, as in pi3_gemm
+    p.qscale = qscale;
+    p.qcols = H * 64;
+  }
   static int fuse = -1;   // PI3_QKV_FUSE: 0 = always the two-pass form (A/B knob; both forms are correct)
   if (fuse < 0) {
     const char* e = getenv("PI3_QKV_FUSE");
@@ -273,8 +277,10 @@ extern "C" int pi3_gemm_qkv(const void* A, long lda, const void* W, long ldw, in
   int rc = pi3_gemm256_try(p, 0, 0, s);
   if (rc > 0) rc = launch_gemm<true, true, 0>(p, s);
   if (rc != 0) return rc;
-  rc = pi3_qknorm_rope_launch(qkv, M, H, T, pos, cs, qw, qb, kw, kb, eps, qscale, pos != nullptr, s);
-  if (rc != 0) return rc;
+  if (qw || pos) {     // (without LayerNorm and RoPE the projection above has already folded the scale into q)
+    rc = pi3_qknorm_rope_launch(qkv, M, H, T, pos, cs, qw, qb, kw, kb, eps, qscale, pos != nullptr, s);
+    if (rc != 0) return rc;
+  }
   if (k2max)
     return pi3_attention_knorm_launch((const char*)qkv + (size_t)H * 64 * 2, ldo, (long)attn_S * ldo, attn_B, attn_S, H,
                                       k2max, s);

@@ -129,7 +129,7 @@ __device__ __forceinline__ void g2_epilogue_lds(const GemmParams& p, f32x4 (&acc
       const int mi = pass * MI_PER_PASS + mq;
       char* rowp = wl + (mq * 16 + frow) * PITCH;
       if constexpr (QK) {
-        if (qk_part < 2) {
+        if (qk_part < 2 && (qk_ln || p.qk_pos)) {      // q / k head with LayerNorm and / or RoPE
           f32x4 x[4];
 #pragma unroll
           for (int ni = 0; ni < 4; ++ni) {
@@ -214,6 +214,7 @@ __device__ __forceinline__ void g2_epilogue_lds(const GemmParams& p, f32x4 (&acc
           continue;
         }
       }
+      float ksq_plain = 0.f;     // QK, a k head without LayerNorm / RoPE (encoder blocks): only max |k|^2 is wanted
 #pragma unroll
       for (int ni = 0; ni < 4; ++ni) {
         f32x4 v = acc[ni][mi] + bias4[ni];
@@ -231,8 +232,27 @@ __device__ __forceinline__ void g2_epilogue_lds(const GemmParams& p, f32x4 (&acc
           o[0] = pack_bf16x2(v[0], v[1]);
           o[1] = pack_bf16x2(v[2], v[3]);
           *(u32x2*)(rowp + (ni * 16 + nq) * 2) = o;
+          if constexpr (QK) {
+            if (qk_part == 1 && p.qk_k2max) {
+#pragma unroll
+              for (int e = 0; e < 2; ++e) {
+                const float lo = __uint_as_float(o[e] << 16), hi = __uint_as_float(o[e] & 0xffff0000u);
+                ksq_plain += lo * lo + hi * hi;
+              }
+            }
+          }
         } else {
           *(f32x4*)(rowp + (ni * 16 + nq) * 4) = v;
+        }
+      }
+      if constexpr (QK) {
+        if (qk_part == 1 && p.qk_k2max) {
+          ksq_plain = g2_sum_rows4(ksq_plain);
+          const int m = m_base + pass * ROWS_PER_PASS + mq * 16 + frow;
+          if (m < p.M) {
+            if (m < qk_split) k2 = fmaxf(k2, ksq_plain);
+            else k2n = fmaxf(k2n, ksq_plain);
+          }
         }
       }
     }

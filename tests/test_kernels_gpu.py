@@ -263,6 +263,28 @@ def test_fused_qkv_epilogue_matches_fp32_reference_and_two_pass_form(dev, use_no
     assert rel(got[:, :, 0], q.transpose(1, 2) * ops.QSCALE)[0] < 5e-3 and rel(got[:, :, 1], k.transpose(1, 2))[0] < 5e-3
 
 
+def test_qkv_epilogue_without_norm_and_rope_is_the_plain_projection_plus_k2max(dev):
+    """Encoder blocks (no q/k LayerNorm, no RoPE: pi3/models/dinov2/layers/block.py:88-113) go through pi3_gemm_qkv for
+    max |k|^2 alone: the packed qkv must equal pi3_gemm's (bias + scale fold on the q columns) bit for bit, on the
+    256x256 kernel (M >= 1024) and on the two-pass fallback (M < 1024)."""
+    from pi3_slam_amd import ops
+    torch.manual_seed(11)
+    H, K = 4, 256
+    for attn_B, attn_S in ((2, 1353), (3, 300)):
+        M = attn_B * attn_S
+        a = torch.randn(M, K, device=dev).bfloat16()
+        w = (torch.randn(3 * H * 64, K, device=dev) / K ** 0.5).bfloat16()
+        bias = torch.randn(3 * H * 64, device=dev) * 0.1
+        qkv = torch.empty(M, 3 * H * 64, device=dev, dtype=torch.bfloat16)
+        k2 = torch.full((attn_B * H,), -1.0, device=dev)
+        ops.gemm_qkv(a, w, qkv, M=M, H=H, bias=bias, T=41, k2max=k2, attn_B=attn_B, attn_S=attn_S)
+        plain = torch.empty_like(qkv)
+        ops.gemm(a, w, plain, M=M, bias=bias, qscale=ops.QSCALE, qcols=H * 64)
+        assert torch.equal(qkv, plain)
+        kk = qkv.view(attn_B, attn_S, 3, H, 64)[:, :, 1].float()
+        assert torch.allclose(k2, (kk * kk).sum(-1).amax(1).reshape(-1), rtol=1e-5)
+
+
 def test_recipe_fill_bit_identical_to_numpy(dev):
     from pi3_slam_amd import ops
     from pi3_slam_amd.recipe import fnv1a64, recipe_tensor

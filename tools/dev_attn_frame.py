@@ -46,4 +46,4 @@ for rnd in range(5):
         res[k].append(ev_time(fn, 10 if "frame" in k else 3))
 for k, (fn, fl) in cases.items():
     v = sorted(res[k])
-    print(f"PRIO={os.environ.get('PI3_ATTN_PRIO','0')} TAILOPT={os.environ.get('PI3_ATTN_TAILOPT','1')} {k:24s}: median {v[len(v)//2]:.4f} ms  min {v[0]:.4f} ms  {fl / v[len(v)//2] / 1e9:.0f} TF/s")
+    print(f"PRIO={os.environ.get('PI3_ATTN_PRIO','0')} TAILOPT={os.environ.get('PI3_ATTN_TAILOPT','1')} CARRY={os.environ.get('PI3_ATTN_CARRY','1')} {k:24s}: median {v[len(v)//2]:.4f} ms  min {v[0]:.4f} ms  {fl / v[len(v)//2] / 1e9:.0f} TF/s")

@@ -22,8 +22,8 @@
 // addressed with a clamp: max_pool2d's implicit -inf padding means "ignore what is outside", and a replicated edge
 // value is a value the window contains anyway - so phase 2 has NO bounds tests (they were 36 of ~100 instructions per
 // pixel; the kernel is VALU-bound, not memory-bound: 9 window reads, NaN tracking, an IEEE division, a sigmoid).
-// Phase 2 walks the strip as ONE contiguous pixel range (full rows of a [F][H][W] array are contiguous): four
-// consecutive pixels per thread, float4 confidence load, uchar4 mask store, one row/column split per group.
+// Phase 2 walks the strip as ONE contiguous pixel range (full rows of a [F][H][W] array are contiguous), consecutive
+// lanes on consecutive pixels.
 #define MK_ROWS 14
 #define MK_MAXW 1024
 
@@ -98,44 +98,24 @@ __global__ __launch_bounds__(256) void masks_kernel(const float* __restrict__ co
   const int rows = min(MK_ROWS, H - y0);
   const int npx = rows * W;
   const long p0 = ((long)f * H + y0) * W;                               // first pixel of the strip, frame-linear
-  const bool vec_ok = (((uintptr_t)conf & 15) == 0) && (((uintptr_t)out & 3) == 0);
-  const int lead2 = (int)(p0 & 3);
-  const int ngroups = (lead2 + npx + 3) >> 2;
   const int yoff = y0 - ylo;                                            // staged row of the strip's first row (0 or 1)
-  for (int g = tid; g < ngroups; g += 256) {
-    const int e0 = 4 * g - lead2;                                       // strip-linear index of the group's first pixel
-    const int eb = max(e0, 0);
-    int ry = eb / W, x = eb - ry * W;
-    const int n = min(e0 + 4, npx) - eb;                                // pixels of this group inside the strip (1..4)
-    const bool full = vec_ok && e0 >= 0 && n == 4;
-    float cc[4];
-    if (full) {
-      const float4 c = *(const float4*)(conf + p0 + e0);
-      cc[0] = c.x; cc[1] = c.y; cc[2] = c.z; cc[3] = c.w;
+  // consecutive lanes take consecutive pixels: the nine window reads of a wave then walk consecutive LDS words (no bank
+  // conflict; four pixels per lane made every read 4-way conflicted), confidence loads and mask stores are coalesced
+  int ry = tid / W, x = tid - ry * W;
+  const bool wide = W >= 256;
+  for (int e = tid; e < npx; e += 256) {
+    const int yc = yoff + ry;
+    const float* zr1 = zs + yc * P;
+    const float* zr0 = zs + max(yc - 1, 0) * P;
+    const float* zr2 = zs + min(yc + 1, nst - 1) * P;
+    out[p0 + e] = mask_pixel(zr0, zr1, zr2, x, conf[p0 + e], thr, rtol);
+    x += 256;
+    if (wide) {
+      if (x >= W) { x -= W; ++ry; }
     } else {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) cc[i] = i < n ? conf[p0 + eb + i] : 0.f;
-    }
-    uint8_t mm[4] = {0, 0, 0, 0};
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      if (i < n) {
-        const int yc = yoff + ry;
-        const float* zr1 = zs + yc * P;
-        const float* zr0 = zs + max(yc - 1, 0) * P;
-        const float* zr2 = zs + min(yc + 1, nst - 1) * P;
-        mm[i] = mask_pixel(zr0, zr1, zr2, x, cc[i], thr, rtol);
-        if (++x >= W) { x = 0; ++ry; }
-      }
-    }
-    if (full) {
-      uchar4 m;
-      m.x = mm[0]; m.y = mm[1]; m.z = mm[2]; m.w = mm[3];
-      *(uchar4*)(out + p0 + e0) = m;
-    } else {
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-        if (i < n) out[p0 + eb + i] = mm[i];
+      const int e2 = e + 256;
+      ry = e2 / W;
+      x = e2 - ry * W;
     }
   }
 }

@@ -281,3 +281,31 @@ class WaveAligner:
                              self.comm_dev, self.compose)
         self.G_last, self.prev_tail = Gs[-1], blocks[len(Gs) - 1]
         return Gs, oks
+
+
+# ------------------------------------------------------------------------------------------- sequential refinement chain
+CHAIN_KEYS = ("points", "keypoints", "masks", "camera_poses", "_chunk_frame", "_sim3_global", "track_estimated")
+
+
+def chain_payload(chunk: Optional[Dict]) -> Optional[Dict]:
+    """What the alignment of chunk c + 1 reads from chunk c (alignment.align_and_refine_reconstructions,
+    bundle_adjust.overlap_priors): host tensors only, ~0.5 MB at 100 views x 200 keypoints."""
+    if chunk is None:
+        return None
+    out = {}
+    for k in CHAIN_KEYS:
+        if k in chunk and chunk[k] is not None:
+            v = chunk[k]
+            out[k] = {kk: vv.cpu() for kk, vv in v.items()} if isinstance(v, dict) else (v.cpu() if torch.is_tensor(v) else v)
+    return out
+
+
+def chain_step(payload: Optional[Dict], src: int) -> Optional[Dict]:
+    """Hand the refined chunk c from its owner to every rank (the owner of chunk c + 1 needs it; a broadcast keeps the
+    collective order identical on all ranks).  Used when bundle adjustment is on: the reference's refinement is a strictly
+    sequential chain (align chunk c + 1 to the ALREADY REFINED chunk c, then adjust it with pose priors from c:
+    slam/offline_reconstructor.py:130-133, utils/reconstruction_alignment.py:107-171), so the ranks take turns for it -
+    stage 2 is 2-3 orders of magnitude cheaper than chunk creation, which stays chunk-parallel."""
+    box = [payload]
+    dist.broadcast_object_list(box, src=src)
+    return box[0]

@@ -82,7 +82,7 @@ class Pi3SLAMOnline:
         self.model = self._creator.model
         self.max_observations_per_track = max_observations_per_track
         # the two pytheia refinement stages of the reference (ChunkPTRecon BA, prior-constrained BA after alignment) on
-        # the device (bundle_adjust.py); the chunk-parallel branch runs the per-chunk stage only
+        # the device (bundle_adjust.py); the chunk-parallel branch runs them as a sequential chain over the ranks
         self.bundle_adjust = bool(bundle_adjust)
         self.chunk_reconstructions: List[Dict] = []     # aligned chunk dicts (the reference keeps pytheia objects)
         self.alignment_infos: List[Optional[Dict]] = []
@@ -195,9 +195,10 @@ class Pi3SLAMOnline:
         in chunk order."""
         import torch.distributed as dist
 
-        from .dist import WaveAligner, gather_objects
+        from .dist import WaveAligner, chain_payload, chain_step, gather_objects
         rank, world, n = self.rank, self.world, len(ds)
         aligner = WaveAligner(rank, world, self.overlap, self.chunk_length, str(self.device))
+        prev_payload: Optional[Dict] = None        # bundle adjustment on: the refined predecessor (dist.chain_step)
         mine = list(range(rank, n, world))
         stream = self._creator.process_chunks(self._items(ds, mine))
         drain = InOrderDrain()
@@ -211,11 +212,29 @@ class Pi3SLAMOnline:
                 assert meta["chunk_index"] == c
             if chunk is not None:
                 self._refine_new_chunk(chunk)
-                chunk.pop("_observations", None)      # chunk-parallel flow: no prior-constrained adjustment follows
-            with torch.cuda.stream(self._align_stream):
-                Gs, oks = aligner.step(chunk, w0, n)
-                if chunk is not None:
-                    transform_chunk(chunk, Gs[rank], device=str(self.device), absolute=True)
+            if self.bundle_adjust:
+                # the reference's refinement is a sequential chain (align to the REFINED predecessor, then adjust with
+                # its poses as priors): the ranks of a wave take turns, the refined chunk travels on; the next wave's
+                # forward is already queued on this rank's compute stream and runs meanwhile
+                my_ok, my_G = True, torch.eye(4, dtype=torch.float64)
+                for r in range(min(world, n - w0)):
+                    pay = None
+                    if r == rank:
+                        if w0 + r > 0:
+                            with torch.cuda.stream(self._align_stream):
+                                my_ok, info = align_and_refine_reconstructions(
+                                    prev_payload, chunk, self._matches, device=str(self.device),
+                                    bundle_adjust=self._ba_args(chunk))
+                            if my_ok:
+                                my_G = info["sim3_summary"]["global_matrix"]
+                        pay = chain_payload(chunk)
+                    prev_payload = chain_step(pay, r)
+                oks, Gs = {rank: my_ok}, {rank: my_G}
+            else:
+                with torch.cuda.stream(self._align_stream):
+                    Gs, oks = aligner.step(chunk, w0, n)
+                    if chunk is not None:
+                        transform_chunk(chunk, Gs[rank], device=str(self.device), absolute=True)
             payload = None if chunk is None else (c, {k: chunk[k] for k in keep if k in chunk}, bool(oks[rank]),
                                                   Gs[rank])
             parts = gather_objects(payload)

@@ -187,26 +187,23 @@ class OfflineReconstructor:
           3. rank r solves only its own T_{c-1<-c}; a 136-byte all-gather distributes the [accepted, T] records;
           4. every rank forms G_c = G_{c-1} . T_c by the prefix product (dist.align_wave) and applies G_c to its chunk.
         Rank 0 collects the transformed chunks for the trajectory / point-cloud files.
-        With bundle_adjust=False this equals the sequential run: both solve on chunk-frame fp16 values and compose
-        (alignment.align_and_refine_reconstructions).  With bundle_adjust=True it does NOT: the per-chunk refinement
-        (chunk_reconstruction.py:188-219) runs on every rank, but the prior-constrained refinement after each alignment
-        (reconstruction_alignment.py:107-171) needs the REFINED predecessor - a strictly sequential chain
-        (offline_reconstructor.py:130-133) - and is skipped; self.refinement_stages says which stages ran and the run
-        prints it.  tests/test_pipeline_gpu.py bounds the trajectory difference on consistent data.
+        This wave form serves bundle_adjust=False and equals the sequential run: both solve on chunk-frame fp16 values
+        and compose (alignment.align_and_refine_reconstructions).  With bundle_adjust=True the refinement after each
+        alignment (reconstruction_alignment.py:107-171) needs the REFINED predecessor - a strictly sequential chain
+        (offline_reconstructor.py:130-133) - so run() goes through _run_distributed_chain instead, which reproduces the
+        single-process trajectory exactly; self.refinement_stages says which stages ran.
         `solve` (tests): replaces the device solver, see dist.default_solver."""
         import torch.distributed as dist
 
         from .alignment import transform_chunk
         from .dist import WaveAligner, gather_objects
+        if self.bundle_adjust and solve is None:
+            return self._run_distributed_chain(rank, world)
         files = self._load_chunks()
         n_chunks = len(files)
         aligner = WaveAligner(rank, world, self.overlap, self.chunk_length, self.device, solve)
         print(f"🔄 Reconstructing {n_chunks} chunks from {self.chunk_dir} on {world} ranks (rank {rank})")
         self.refinement_stages = (["per_chunk_bundle_adjust"] if self.bundle_adjust else []) + ["closed_form_sim3"]
-        if self.bundle_adjust and rank == 0:
-            print("   ℹ️  chunk-parallel run: per-chunk bundle adjustment + closed-form Sim(3) chain; the prior-constrained "
-                  "bundle adjustment after each alignment is sequential by construction and is NOT run "
-                  "(single-process run, or --no-bundle-adjust, for identical trajectories)")
         mine: List[Dict] = []
         for w0 in range(0, n_chunks, world):
             c = w0 + rank
@@ -229,6 +226,52 @@ class OfflineReconstructor:
                     self._save_observations(data, c)
         keep = ("points", "colors", "keypoints", "masks", "camera_poses", "image_paths", "chunk_order", "alignment_ok")
         parts = gather_objects([{k: d[k] for k in keep if k in d} for d in mine])
+        if rank == 0:
+            self.reconstructions = sorted((d for part in parts for d in part), key=lambda d: d["chunk_order"])
+            self._write_outputs()
+        dist.barrier()
+
+    def _run_distributed_chain(self, rank: int, world: int) -> None:
+        """Bundle adjustment on, several ranks: the SAME arithmetic as the single-process run, chunk c on rank
+        c % world.  The per-chunk adjustment of a rank's chunks is independent and runs up front; alignment + the
+        prior-constrained adjustment need the refined predecessor, so the ranks take turns in chunk order and the refined
+        chunk travels to the next owner (dist.chain_step).  Identical trajectories to `run()` without torchrun (tested)."""
+        import torch.distributed as dist
+
+        from .dist import chain_payload, chain_step, gather_objects
+        files = self._load_chunks()
+        n_chunks = len(files)
+        self.refinement_stages = ["per_chunk_bundle_adjust", "closed_form_sim3", "prior_constrained_bundle_adjust"]
+        print(f"🔄 Reconstructing {n_chunks} chunks from {self.chunk_dir} on {world} ranks (rank {rank}), sequential "
+              f"refinement chain (bundle adjustment on)")
+        own: Dict[int, Dict] = {}
+        for c in range(rank, n_chunks, world):          # independent per chunk: every rank works on its own
+            data = torch.load(files[c], map_location="cpu", weights_only=False)
+            self._bundle_adjust_new_chunk(data, c)
+            own[c] = data
+        matches = create_view_graph_matches(self.chunk_length, self.overlap)
+        prev: Optional[Dict] = None
+        for c in range(n_chunks):
+            owner = c % world
+            payload = None
+            if rank == owner:
+                data = own[c]
+                ok = True
+                if c > 0:
+                    ok, info = align_and_refine_reconstructions(prev, data, matches, device=self.device,
+                                                                bundle_adjust=self._ba_args(data))
+                    self.alignment_infos.append(info if ok else None)
+                    if not ok:
+                        print(f"   ❌ Alignment failed for chunk {c}")
+                data["chunk_order"], data["alignment_ok"] = c, bool(ok)
+                payload = chain_payload(data)
+                if self.save_per_chunk:
+                    self._save_chunk(data, c)
+                if self.save_observations:
+                    self._save_observations(data, c)
+            prev = chain_step(payload, owner)
+        keep = ("points", "colors", "keypoints", "masks", "camera_poses", "image_paths", "chunk_order", "alignment_ok")
+        parts = gather_objects([{k: d[k] for k in keep if k in d} for d in own.values()])
         if rank == 0:
             self.reconstructions = sorted((d for part in parts for d in part), key=lambda d: d["chunk_order"])
             self._write_outputs()

@@ -35,6 +35,17 @@ def main():
         os.makedirs(os.path.join(recon_dir, "online"), exist_ok=True)
         assert slam.get_reconstruction_count() == len(res)
         slam.save_trajectory_tum(os.path.join(recon_dir, "online", "traj.txt"), integer_timestamp=True)
+    # the same stream with bundle adjustment ON: under torchrun the ranks take turns for alignment + refinement
+    # (dist.chain_step); on recipe-weight geometry the sanity gate rejects the adjustments in both runs, so this checks
+    # the chain's plumbing (who aligns to what, in which order), not the adjuster
+    slam2 = Pi3SLAMOnline(model=creator.model, chunk_length=8, overlap=3, device=str(creator.device), keypoint_type="grid",
+                          max_num_keypoints=100, estimate_camera_params=True, hip_graph=False,
+                          output_dir=os.path.join(recon_dir, "online_ba"), bundle_adjust=True)
+    res2 = slam2.process_chunks(paths)
+    if slam2.rank == 0:
+        os.makedirs(os.path.join(recon_dir, "online_ba"), exist_ok=True)
+        assert slam2.get_reconstruction_count() == len(res2)
+        slam2.save_trajectory_tum(os.path.join(recon_dir, "online_ba", "traj.txt"), integer_timestamp=True)
     if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
 

@@ -232,3 +232,61 @@ def test_post_processing_full_chunk_vs_oracle(dev, H, W):
         assert torch.equal(a, b), (k, float((a != b).float().mean()))
     col = post_ref.keypoint_colors(imgs, kp)
     assert torch.equal(out["colors"].cpu().float(), col.float())
+
+
+@pytest.mark.parametrize("H,W", [(308, 406), (280, 448)])
+def test_pointmap_and_camera_heads_full_chunk(dev, H, W):
+    """The tail of Pi3.forward over a whole chunk: `pi3_unpatchify_points` (pixel_shuffle(14) of the
+    588 / 196-wide patch features, z = exp(z), local = (x z, y z, z), world = pose . [local, 1]: transformer_head.py:70-80,
+    pi3.py:195-209) and `pi3_camera_tail` (mean over the patch tokens, two MLP layers, fc_t / fc_rot, SVD
+    orthogonalisation: camera_head.py:48-93) at 100 frames, against the oracle's own functions (oracle/pi3_ref.py, pinned
+    to the real Pi3 class by pi3_tiny_*.npz).  Row strides of the feature buffers are the engine's (640 / 256 floats)."""
+    from oracle import pi3_ref
+    from pi3_slam_amd import ops
+    Fr, nreg, C = 100, 5, 512
+    ph, pw = H // 14, W // 14
+    P, T = ph * pw, ph * pw + nreg
+    g = torch.Generator().manual_seed(H)
+    # ---- camera tail
+    feat = torch.randn(Fr * T, C, generator=g) * 0.5
+    w = {"camera_head.more_mlps.0.weight": torch.randn(C, C, generator=g) / C ** 0.5,
+         "camera_head.more_mlps.0.bias": torch.randn(C, generator=g) * 0.1,
+         "camera_head.more_mlps.2.weight": torch.randn(C, C, generator=g) / C ** 0.5,
+         "camera_head.more_mlps.2.bias": torch.randn(C, generator=g) * 0.1,
+         "camera_head.fc_t.weight": torch.randn(3, C, generator=g) / C ** 0.5, "camera_head.fc_t.bias": torch.randn(3, generator=g),
+         "camera_head.fc_rot.weight": torch.randn(9, C, generator=g) / C ** 0.5, "camera_head.fc_rot.bias": torch.randn(9, generator=g)}
+    wd = {k: v.to(dev).contiguous() for k, v in w.items()}
+    poses = torch.empty(Fr, 4, 4, device=dev)
+    ops.camera_tail(feat.to(dev), T, nreg, Fr, P, wd, poses)
+    v = feat.view(Fr, T, C)[:, nreg:].mean(dim=1)
+    v = torch.relu(torch.nn.functional.linear(v, w["camera_head.more_mlps.0.weight"], w["camera_head.more_mlps.0.bias"]))
+    v = torch.relu(torch.nn.functional.linear(v, w["camera_head.more_mlps.2.weight"], w["camera_head.more_mlps.2.bias"]))
+    t = torch.nn.functional.linear(v, w["camera_head.fc_t.weight"], w["camera_head.fc_t.bias"])
+    R = pi3_ref.svd_orthogonalize(torch.nn.functional.linear(v, w["camera_head.fc_rot.weight"], w["camera_head.fc_rot.bias"]))
+    got = poses.cpu()
+    assert torch.allclose(got[:, :3, 3], t, rtol=1e-4, atol=1e-5)
+    assert (got[:, :3, :3] - R).abs().max() < 1e-4                                   # a rotation: absolute
+    RtR = got[:, :3, :3].transpose(1, 2) @ got[:, :3, :3]
+    assert (RtR - torch.eye(3)).abs().max() < 1e-5 and torch.allclose(torch.det(got[:, :3, :3]), torch.ones(Fr), atol=1e-5)
+    assert torch.equal(got[:, 3], torch.tensor([0.0, 0.0, 0.0, 1.0]).expand(Fr, 4))
+    # ---- point map
+    pfeat = torch.zeros(Fr * T, 640)
+    cfeat = torch.zeros(Fr * T, 256)
+    pfeat[:, :588] = torch.randn(Fr * T, 588, generator=g) * 0.5
+    cfeat[:, :196] = torch.randn(Fr * T, 196, generator=g) * 2.0
+    lp = torch.empty(Fr, H, W, 3, device=dev)
+    pts = torch.empty(Fr, H, W, 3, device=dev)
+    conf = torch.empty(Fr, H, W, 1, device=dev)
+    ops.unpatchify_points(pfeat.to(dev), cfeat.to(dev), poses, Fr, H, W, T, nreg, lp, pts, conf)
+    def shuffle(f, c):                       # LinearPts3d.forward after its Linear (transformer_head.py:74-79)
+        x = f.view(Fr, T, -1)[:, nreg:, :c * 196].transpose(-1, -2).reshape(Fr, c * 196, ph, pw)
+        return torch.nn.functional.pixel_shuffle(x, 14).permute(0, 2, 3, 1)
+    ret = shuffle(pfeat, 3)
+    z = torch.exp(ret[..., 2:])
+    lref = torch.cat([ret[..., :2] * z, z], dim=-1)
+    assert torch.equal(conf.cpu(), shuffle(cfeat, 1))                                # a pure gather
+    assert torch.allclose(lp.cpu(), lref, rtol=3e-6, atol=0)                         # expf: <= 2 ulp
+    hom = torch.cat([lp.cpu(), torch.ones(Fr, H, W, 1)], dim=-1)
+    pref = torch.einsum("nij,nhwj->nhwi", got, hom)[..., :3]
+    scale = pref.abs().amax()
+    assert (pts.cpu() - pref).abs().max() <= 4e-7 * scale                            # fp32 3-term dot products

@@ -28,7 +28,13 @@ CASES = {
     "pi3_tiny_a": (1, 3, 28, 42),
     "pi3_tiny_b": (1, 2, 42, 56),
     "pi3_tiny_c": (1, 5, 56, 70),
+    # 8 frames at the size every 4:3 input becomes (308 x 406): S = 5 144 tokens, M = 5 144 rows.  At this size the HIP
+    # path runs the kernels that ship (256x256 GEMM, 64-row attention with four-wave workgroups on the 643-token frame
+    # sequences and eight-wave workgroups on the global one); the tiny cases above go through the small-shape kernels.
+    # Dense maps are stored every SUB-th pixel, intermediates every ROWS-th token (the file stays < 2 MB).
+    "pi3_mid": (1, 8, 308, 406),
 }
+SUBSAMPLED = {"pi3_mid": (7, 16)}     # name: (pixel stride SUB, token-row stride ROWS)
 
 
 def golden_images(name: str, B: int, N: int, H: int, W: int) -> torch.Tensor:
@@ -55,7 +61,11 @@ def main() -> None:
 
     out_dir = os.path.join(REPO, "tests", "golden")
     os.makedirs(out_dir, exist_ok=True)
+    only = sys.argv[1:]
     for name, (B, N, H, W) in CASES.items():
+        if only and name not in only:
+            continue
+        sub, rows = SUBSAMPLED.get(name, (1, 1))
         imgs = golden_images(name, B, N, H, W)
         cap = {}
         hooks = [
@@ -77,14 +87,14 @@ def main() -> None:
         t0 = time.time()
         orc = pi3_ref.pi3_forward(sd, imgs, cfg, return_intermediates=True)
         print(f"{name}: oracle forward {time.time() - t0:.1f}s")
-        save = {"shape": np.array([B, N, H, W])}
+        save = {"shape": np.array([B, N, H, W]), "strides": np.array([sub, rows])}
         for k in ("points", "local_points", "conf", "camera_poses"):
-            save[k] = ref[k].numpy()
+            save[k] = ref[k].numpy() if k == "camera_poses" else ref[k][:, :, ::sub, ::sub].numpy()
             d = (ref[k] - orc[k]).abs().max().item()
             print(f"   {k:14s} ref-vs-oracle max|d| = {d:.3e}   (ref max {ref[k].abs().max().item():.3f})")
         for k, v in cap.items():
             v2 = v.reshape(-1, v.shape[-1])
-            save["i_" + k] = v2.numpy()
+            save["i_" + k] = v2[::rows].numpy()
             d = (v2 - orc["_intermediates"][k]).abs().max().item()
             print(f"   i_{k:12s} ref-vs-oracle max|d| = {d:.3e}   (ref max {v2.abs().max().item():.3f})")
         # Tolerance anchor: the reference's OWN bf16-autocast execution vs its fp32 execution on the same weights

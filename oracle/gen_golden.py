@@ -31,10 +31,10 @@ CASES = {
     # 8 frames at the size every 4:3 input becomes (308 x 406): S = 5 144 tokens, M = 5 144 rows.  At this size the HIP
     # path runs the kernels that ship (256x256 GEMM, 64-row attention with four-wave workgroups on the 643-token frame
     # sequences and eight-wave workgroups on the global one); the tiny cases above go through the small-shape kernels.
-    # Dense maps are stored every SUB-th pixel, intermediates every ROWS-th token (the file stays < 2 MB).
+    # Dense maps are stored every SUB-th pixel, intermediates every ROWS-th token (the file stays < 4 MB).
     "pi3_mid": (1, 8, 308, 406),
 }
-SUBSAMPLED = {"pi3_mid": (7, 16)}     # name: (pixel stride SUB, token-row stride ROWS)
+SUBSAMPLED = {"pi3_mid": (7, 64)}     # name: (pixel stride SUB, token-row stride ROWS)
 
 
 def golden_images(name: str, B: int, N: int, H: int, W: int) -> torch.Tensor:

@@ -70,7 +70,7 @@ def test_full_model_mid_size_through_the_shipped_kernels(full_engine):
     headline run - gemm256 (M >= 1024, N % 256 == 0) with the fused q/k epilogue, `attn_fwd64_kernel<4>` on the
     643-token frame sequences, `attn_fwd64_kernel<8>` on the 5 144-token global one, the full-size pointmap / camera
     heads - where the tiny fixtures run the small-shape kernels.  Dense maps are stored every 7th pixel, intermediates
-    every 16th token row.  Gates as for the tiny fixtures: 2x the reference's own bf16-autocast deviation (computed by the
+    every 64th token row.  Gates as for the tiny fixtures: 2x the reference's own bf16-autocast deviation (computed by the
     generator on the full arrays), intermediates < 1.5 % relative mean error."""
     from oracle.gen_golden import CASES, golden_images
     g = np.load(os.path.join(GOLDEN, "pi3_mid.npz"))

@@ -202,3 +202,51 @@ def test_in_order_drain_releases_chunks_in_chunk_order():
     assert got == list(range(23)) and len(d) == 0 and d.next_index == 23
     with pytest.raises(ValueError):
         d.put(3, "again")
+
+
+def test_use_inverse_depth_is_refused_not_ignored(tmp_path):
+    """utils/chunk_reconstruction.py:186-187,199-204 / utils/reconstruction_alignment.py:147-152: the reference's
+    inverse-depth parametrisation is not implemented by the device adjuster; the flag must raise, not change meaning."""
+    from pi3_slam_amd.alignment import align_and_refine_reconstructions
+    from pi3_slam_amd.reconstructor import OfflineReconstructor
+    with pytest.raises(NotImplementedError):
+        OfflineReconstructor(str(tmp_path), str(tmp_path / "o"), use_inverse_depth=True)
+    with pytest.raises(NotImplementedError):
+        align_and_refine_reconstructions({}, {}, [(0, 0)], use_inverse_depth=True)
+    r = OfflineReconstructor(str(tmp_path), str(tmp_path / "o"), device="cpu")
+    assert r.use_inverse_depth is False and r.bundle_adjust is True
+
+
+def test_bundle_adjust_sanity_gate():
+    """bundle_adjust.sanity_gate: a 'successful' adjustment is not taken over when fewer than three tracks survive the
+    outlier test or a camera moved by more than the scene extent (pure host logic on the solver's outputs)."""
+    import torch
+    from pi3_slam_amd.bundle_adjust import sanity_gate
+    g = torch.Generator().manual_seed(0)
+    pts = torch.randn(40, 3, generator=g, dtype=torch.float64) + torch.tensor([0.0, 0.0, 5.0], dtype=torch.float64)
+    rc = torch.zeros(4, 12, dtype=torch.float64)
+    rc[:, 9:] = torch.randn(4, 3, generator=g, dtype=torch.float64) * 0.2
+    est = torch.ones(4, 10, dtype=torch.bool)
+    assert sanity_gate(pts, rc, pts, rc, est, None) is None
+    few = torch.zeros(4, 10, dtype=torch.bool); few[0, :2] = True
+    assert "tracks survived" in sanity_gate(pts, rc, pts, rc, few, None)
+    # cumulative flag: tracks that took no part do not count as lost
+    before = torch.zeros(4, 10, dtype=torch.bool); before[1, :5] = True
+    assert sanity_gate(pts, rc, pts, rc, before.clone(), before) is None
+    moved = rc.clone(); moved[2, 9:] += 100.0
+    assert "scene extent" in sanity_gate(pts, rc, pts, moved, est, None)
+    nan = rc.clone(); nan[1, 9] = float("nan")
+    assert sanity_gate(pts, rc, pts, nan, est, None) is not None          # a NaN move is not '<= extent'
+
+
+def test_chain_payload_carries_what_the_next_alignment_reads():
+    """dist.chain_payload: the refined chunk handed to the next owner under torchrun with bundle adjustment on."""
+    import torch
+    from pi3_slam_amd.dist import CHAIN_KEYS, chain_payload
+    ch = dict(points=torch.zeros(3, 4, 3), keypoints=torch.zeros(3, 4, 2).half(), masks=torch.ones(3, 4, 1, dtype=torch.bool),
+              camera_poses=torch.eye(4).repeat(3, 1, 1), colors=torch.zeros(3, 4, 3), image_paths=[["a"], ["b"], ["c"]],
+              _chunk_frame={"points": torch.zeros(3, 4, 3).half(), "camera_poses": torch.eye(4).repeat(3, 1, 1)},
+              _sim3_global=torch.eye(4, dtype=torch.float64), _observations=("big", "device", "arrays"))
+    pay = chain_payload(ch)
+    assert set(pay) == {"points", "keypoints", "masks", "camera_poses", "_chunk_frame", "_sim3_global"} <= set(CHAIN_KEYS)
+    assert pay["_chunk_frame"]["points"].dtype == torch.float16 and chain_payload(None) is None

@@ -26,7 +26,8 @@ import torch
 
 from . import ops
 from .vit import run_block
-from .weights import IMAGE_MEAN, IMAGE_STD, Pi3Config, load_checkpoint, param_shapes, recipe_fill_device
+from .weights import (IMAGE_MEAN, IMAGE_STD, Pi3Config, config_from_checkpoint_dir, load_checkpoint, param_shapes,
+                      recipe_fill_device)
 
 _BF16_SUFFIXES = ("attn.qkv.weight", "attn.proj.weight", "mlp.fc1.weight", "mlp.fc2.weight", "projects.weight",
                   "linear_out.weight", "patch_embed.proj.weight")
@@ -97,7 +98,7 @@ class Pi3Engine:
     @classmethod
     def from_pretrained(cls, path: str, device: str = "cuda:0") -> "Pi3Engine":
         """Local directory / file with the reference checkpoint layout (pi3.py:14-16)."""
-        return cls(Pi3Config(), device, load_checkpoint(path))
+        return cls(config_from_checkpoint_dir(path), device, load_checkpoint(path))
 
     # ------------------------------------------------------------------ weights
     def _install(self, name: str, t: torch.Tensor) -> None:

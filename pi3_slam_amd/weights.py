@@ -124,6 +124,29 @@ def recipe_fill_device(name: str, shape, device, dtype=torch.float32) -> torch.T
     return t
 
 
+def config_from_checkpoint_dir(path: str) -> "Pi3Config":
+    """Pi3.from_pretrained on a local directory (huggingface_hub.PyTorchModelHubMixin) passes the init kwargs stored in
+    `<dir>/config.json` to Pi3.__init__ (pi3/models/pi3.py:17-21): `pos_type` ('rope<freq>', default 'rope100') and
+    `decoder_size` (default 'large').  The RoPE base follows pos_type; 'small' / 'base' decoders cannot even be run by
+    the reference (the 384 / 768-wide decoder is fed the 1024-wide encoder tokens without a projection, pi3.py:140-160),
+    so anything but 'large' is refused."""
+    import json
+    from dataclasses import replace
+    cfg = Pi3Config()
+    cj = os.path.join(path, "config.json") if os.path.isdir(path) else None
+    if cj and os.path.exists(cj):
+        with open(cj) as f:
+            kw = json.load(f)
+        pos_type = kw.get("pos_type", "rope100") or "none"
+        if not str(pos_type).startswith("rope"):
+            raise NotImplementedError(f"pos_type={pos_type!r}: the reference itself only implements 'rope<freq>' (pi3.py:36-43)")
+        cfg = replace(cfg, rope_base=float(str(pos_type)[len("rope"):]))
+        size = kw.get("decoder_size", "large")
+        if size != "large":
+            raise NotImplementedError(f"decoder_size={size!r}: only 'large' is a runnable reference model")
+    return cfg
+
+
 def load_checkpoint(path: str) -> Dict[str, torch.Tensor]:
     """`path` is a directory holding model.safetensors (the PyTorchModelHubMixin layout) or a .safetensors/.pt file."""
     if os.path.isdir(path):

@@ -250,3 +250,20 @@ def test_chain_payload_carries_what_the_next_alignment_reads():
     pay = chain_payload(ch)
     assert set(pay) == {"points", "keypoints", "masks", "camera_poses", "_chunk_frame", "_sim3_global"} <= set(CHAIN_KEYS)
     assert pay["_chunk_frame"]["points"].dtype == torch.float16 and chain_payload(None) is None
+
+
+def test_checkpoint_directory_config_json(tmp_path):
+    """Pi3.from_pretrained(<dir>) hands `<dir>/config.json` to Pi3.__init__ (PyTorchModelHubMixin; pi3.py:17-21):
+    pos_type sets the RoPE base, decoder sizes the reference cannot run are refused, no file = the defaults."""
+    import json
+    from pi3_slam_amd.weights import Pi3Config, config_from_checkpoint_dir
+    assert config_from_checkpoint_dir(str(tmp_path)) == Pi3Config()
+    (tmp_path / "config.json").write_text(json.dumps({"pos_type": "rope50", "decoder_size": "large"}))
+    cfg = config_from_checkpoint_dir(str(tmp_path))
+    assert cfg.rope_base == 50.0 and cfg.dec_depth == 36
+    (tmp_path / "config.json").write_text(json.dumps({"decoder_size": "small"}))
+    with pytest.raises(NotImplementedError):
+        config_from_checkpoint_dir(str(tmp_path))
+    (tmp_path / "config.json").write_text(json.dumps({"pos_type": None}))
+    with pytest.raises(NotImplementedError):
+        config_from_checkpoint_dir(str(tmp_path))

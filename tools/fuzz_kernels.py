@@ -64,7 +64,11 @@ while time.time() < t_end:
             qkv[rng.randrange(B * S), H * 64: H * 64 + 64] *= 6.0      # one heavy key: online-max rescale / bound miss
         qkv = qkv.bfloat16()
         out = torch.empty(B * S, H * 64, device=dev, dtype=torch.bfloat16)
-        ops.attention(qkv, out, B, S, H)
+        k2 = None
+        if S >= 256 and rng.random() < 0.5:      # max |k|^2 supplied, as the qkv epilogue does: bounded-score loop on the
+            kk = qkv.view(B, S, 3, H, 64)[:, :, 1].float()      # four-wave kernel too (missing query blocks / key halves)
+            k2 = (kk * kk).sum(-1).amax(1).reshape(-1).contiguous()
+        ops.attention(qkv, out, B, S, H, k2max=k2)
         ref = attn_ref(qkv, B, S, H)
         e = rel(out, ref)
         if not (e < 1e-2) or not torch.isfinite(out.float()).all():

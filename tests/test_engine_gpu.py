@@ -96,7 +96,8 @@ def test_full_model_mid_size_through_the_shipped_kernels(full_engine):
     assert (out["local_points"][..., 2] > 0).all()
 
 
-@pytest.mark.parametrize("shape", [(1, 3, 28, 42), (2, 2, 70, 70), (1, 4, 56, 84)])
+@pytest.mark.parametrize("shape", [(1, 3, 28, 42), (2, 2, 70, 70), (1, 4, 56, 84), (1, 1, 14, 14), (1, 1, 42, 28),
+                                   (3, 1, 28, 28), (1, 2, 28, 70)])
 def test_small_config_against_oracle(dev, shape):
     """Same code path at a width the CPU oracle evaluates in a second (dim 128, 2+4+1 blocks); covers B > 1 and the
     global-attention batching."""

@@ -134,6 +134,8 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=8, help="frames of the CPU baseline sample (8: ~30 s; 32 = BASELINE configs[0])")
     ap.add_argument("--no-extras", action="store_true", help="skip the 378x504 / K=400 / from-disk extras")
+    ap.add_argument("--no-moge", action="store_true", help="diagnostic only: leave the MoGe metric scale out (the line then says "
+                    "moge_metric_scale_in_timed_region: false and is not the headline workload)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -170,7 +172,8 @@ def main() -> None:
     moge = None
     try:
         from pi3_slam_amd.moge import MoGeEngine
-        moge = MoGeEngine.from_pretrained("recipe", str(dev))
+        if not args.no_moge:
+            moge = MoGeEngine.from_pretrained("recipe", str(dev))
     except Exception as e:  # noqa: BLE001
         if rank == 0:
             print(f"[bench] MoGe engine unavailable ({e}); metric scaling is NOT in the timed region", file=sys.stderr)

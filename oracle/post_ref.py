@@ -29,10 +29,11 @@ def depth_edge(depth: torch.Tensor, rtol: float, kernel_size: int = 3) -> torch.
     return edge.reshape(*shape)
 
 
-def compute_masks(conf: torch.Tensor, local_points: torch.Tensor) -> torch.Tensor:
-    """OfflineChunkCreator._compute_masks (slam/offline_chunk_creator.py:114-119).  conf (..., H, W, 1)."""
-    masks = torch.sigmoid(conf[..., 0]) > 0.1
-    return torch.logical_and(masks, ~depth_edge(local_points[..., 2], rtol=0.03))
+def compute_masks(conf: torch.Tensor, local_points: torch.Tensor, conf_thr: float = 0.1, rtol: float = 0.03) -> torch.Tensor:
+    """OfflineChunkCreator._compute_masks (slam/offline_chunk_creator.py:114-119).  conf (..., H, W, 1).  The
+    reference hard-codes 0.1 and 0.03; the C-ABI takes them as arguments, hence the parameters."""
+    masks = torch.sigmoid(conf[..., 0]) > conf_thr
+    return torch.logical_and(masks, ~depth_edge(local_points[..., 2], rtol=rtol))
 
 
 def scale_factor(moge_depth: torch.Tensor, pi3_depth: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:

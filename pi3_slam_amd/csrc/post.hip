@@ -5,6 +5,8 @@
 #include "common.h"
 #include <hip/hip_fp16.h>
 #include <float.h>
+#include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -12,103 +14,120 @@
 // depth_edge (pi3/utils/geometry.py:347-375): diff = maxpool3(z) + maxpool3(-z) with max_pool2d's implicit -inf
 // padding (borders use the valid neighbours only); edge = nan_to_num(diff / z) > rtol.
 // ---------------------------------------------------------------------------------------------------------------
-// One workgroup = a strip of MK_ROWS image rows of one frame (14: 308 = 22 x 14, 280 = 20 x 14; halo re-read 2 / 14).
-// Phase 1 stages the z channel of the strip and its two halo rows in LDS from the interleaved (x, y, z) rows with
-// 16-byte loads: a float4 at strip offset s = 3 pix + r holds the z of pixel pix at lane element (2 - r) mod 3 (and a
-// second one, of pix + 1, when r == 2), and a thread's next float4 is 1024 floats on = 341 pixels + 1 float, so the
-// walk needs no division (round 2 read one float per instruction and did `% 3` and `/ 3` per element: 1.1 TB/s).
-// An aligned 16-byte load that holds one valid float cannot cross a page, so the ragged first / last float4 are safe.
-// The LDS image has one extra column on either side holding a copy of the row's first / last pixel, and rows are
-// addressed with a clamp: max_pool2d's implicit -inf padding means "ignore what is outside", and a replicated edge
-// value is a value the window contains anyway - so phase 2 has NO bounds tests (they were 36 of ~100 instructions per
-// pixel; the kernel is VALU-bound, not memory-bound: 9 window reads, NaN tracking, an IEEE division, a sigmoid).
-// Phase 2 walks the strip as ONE contiguous pixel range (full rows of a [F][H][W] array are contiguous), consecutive
-// lanes on consecutive pixels.
-#define MK_ROWS 14
+// One workgroup = a strip of R image rows of one frame (R chosen on the host so that five workgroups share a CU's LDS).
+// Staging (round 3, third form): the strip's interleaved (x, y, z) rows with one halo row either side, and the strip's
+// confidences, are two contiguous byte ranges of the [F][H][W] arrays; both go to LDS by LDS-DMA
+// (global_load_lds_dwordx4, 16 bytes per lane, from the 16-byte aligned address at or below the range) - every byte of
+// the workgroup is in flight at once, no registers, no address walk.  (Round 2 read one float per instruction with `%
+// 3` and `/ 3` per element: 1.1 TB/s; the first round-3 form walked float4 loads through registers into a compacted z
+// image, one memory latency per loop trip: 2.35 TB/s.)  An aligned 16-byte load that holds one valid float cannot cross
+// a page, so the ragged first / last 16 bytes are safe; lanes beyond the range re-read its last 16 bytes.
+// The window then reads z of pixel p of the staged rows at float `lead + 3 p + 2`: consecutive lanes on consecutive
+// pixels are 3 words apart, which 64 banks serve without conflict.  max_pool2d's implicit -inf padding means "ignore
+// what is outside", and a clamped coordinate names a value the window holds anyway, so borders are two clamps.
 #define MK_MAXW 1024
+#define MK_LDS_BUDGET (32 * 1024)       // 5 workgroups per CU (160 KB): 3 rows at W = 406 / 448, measured best of 2..8
 
-// zr0 / zr1 / zr2: LDS rows above / at / below the pixel (clamped), already offset so that index x is the pixel's left
-// neighbour (the image is stored from column 1).
+struct MaskWin { float a0, a1, a2, b0, z, b2, c0, c1, c2; };
+
 // estar: the largest e >= 0 with fl(1 / fl(1 + e)) > thr (found on the host, see pi3_compute_masks): sigmoid(c) > thr
 // <=> expf(-c) <= estar, decision for decision (the outer 1 / (1 + e) is monotone in e and correctly rounded on both
 // sides), without the add and the IEEE division per pixel.
-__device__ __forceinline__ uint8_t mask_pixel(const float* zr0, const float* zr1, const float* zr2, int x, float c,
-                                              float estar, float rtol) {
-  const float a0 = zr0[x], a1 = zr0[x + 1], a2 = zr0[x + 2];
-  const float b0 = zr1[x], z = zr1[x + 1], b2 = zr1[x + 2];
-  const float c0 = zr2[x], c1 = zr2[x + 1], c2 = zr2[x + 2];
+__device__ __forceinline__ uint8_t mask_pixel(const MaskWin& w, float c, float estar, float rtol) {
   // max_pool2d propagates NaN (a NaN in the window wins), fmaxf would drop it
-  const bool anynan = isnan(a0) | isnan(a1) | isnan(a2) | isnan(b0) | isnan(z) | isnan(b2) | isnan(c0) | isnan(c1) | isnan(c2);
-  const float mx = fmaxf(fmaxf(fmaxf(a0, a1), fmaxf(a2, b0)), fmaxf(fmaxf(z, b2), fmaxf(fmaxf(c0, c1), c2)));
-  const float mn = fminf(fminf(fminf(a0, a1), fminf(a2, b0)), fminf(fminf(z, b2), fminf(fminf(c0, c1), c2)));
-  float ratio = anynan ? __uint_as_float(0x7fc00000u) : (mx + (-mn)) / z;
+  const bool anynan = isnan(w.a0) | isnan(w.a1) | isnan(w.a2) | isnan(w.b0) | isnan(w.z) | isnan(w.b2) | isnan(w.c0) |
+                      isnan(w.c1) | isnan(w.c2);
+  const float mx = fmaxf(fmaxf(fmaxf(w.a0, w.a1), fmaxf(w.a2, w.b0)), fmaxf(fmaxf(w.z, w.b2), fmaxf(fmaxf(w.c0, w.c1), w.c2)));
+  const float mn = fminf(fminf(fminf(w.a0, w.a1), fminf(w.a2, w.b0)), fminf(fminf(w.z, w.b2), fminf(fminf(w.c0, w.c1), w.c2)));
+  float ratio = anynan ? __uint_as_float(0x7fc00000u) : (mx + (-mn)) / w.z;
   if (isnan(ratio)) ratio = 0.f;
   else if (isinf(ratio)) ratio = ratio > 0.f ? FLT_MAX : -FLT_MAX;
   const bool edge = ratio > rtol;
   return (expf(-c) <= estar && !edge) ? 1 : 0;
 }
 
+// The same decisions without the IEEE division and the expf in all but a sliver of the cases.  Preconditions,
+// established per strip / on the host: no NaN among the staged z (fmaxf / fminf then ARE max_pool2d), 0 <= rtol <
+// FLT_MAX (nan_to_num then never changes the outcome of `> rtol`: NaN -> 0 and NaN itself both compare false, +inf ->
+// FLT_MAX and +inf itself both compare true).
+//  edge: q = d * rcp(z) is within a few ulp of d / z for 2^-100 < |z| < 2^100; outside [rlo, rhi] = rtol (1 -+ 1e-5) the
+//        correctly rounded quotient is on the same side of rtol; inside (or z out of range, or q NaN) divide exactly.
+//  conf: expf(-c) <= estar holds for c > chi and fails for c < clo, where [clo, chi] brackets -ln(estar) by 1e-5 (1 +
+//        |ln estar|), 40x what the expf's few ulp can move the crossing; inside the bracket (or c NaN) evaluate it.
+struct MaskFast { float rlo, rhi, clo, chi; int ok; };
+
+__device__ __forceinline__ uint8_t mask_pixel_fast(const MaskWin& w, float c, float estar, float rtol, const MaskFast& mf) {
+  const float mx = fmaxf(fmaxf(fmaxf(w.a0, w.a1), w.a2), fmaxf(fmaxf(fmaxf(w.b0, w.z), w.b2), fmaxf(fmaxf(w.c0, w.c1), w.c2)));
+  const float mn = fminf(fminf(fminf(w.a0, w.a1), w.a2), fminf(fminf(fminf(w.b0, w.z), w.b2), fminf(fminf(w.c0, w.c1), w.c2)));
+  const float d = mx + (-mn);
+  const float q = d * __builtin_amdgcn_rcpf(w.z);
+  const float az = fabsf(w.z);
+  bool edge = q > mf.rhi;
+  if (!(az > 0x1p-100f && az < 0x1p100f && (edge || q < mf.rlo))) {
+    float ratio = d / w.z;
+    if (isnan(ratio)) ratio = 0.f;
+    else if (isinf(ratio)) ratio = ratio > 0.f ? FLT_MAX : -FLT_MAX;
+    edge = ratio > rtol;
+  }
+  bool cok = c > mf.chi;
+  if (!cok && !(c < mf.clo)) cok = expf(-c) <= estar;
+  return (cok && !edge) ? 1 : 0;
+}
+
+// floats of LDS that a range of n floats starting `lead` floats into its first 16 bytes occupies (whole 64-lane DMAs)
+__host__ __device__ __forceinline__ int mk_lds_floats(int lead, int n) { return (((lead + n + 3) >> 2) + 63) / 64 * 256; }
+
+__device__ __forceinline__ void mk_stage(const float* first, int n, float* lds, int tid, int& lead) {
+  const uintptr_t addr = (uintptr_t)first, aligned = addr & ~(uintptr_t)15;
+  lead = (int)((addr - aligned) >> 2);
+  const float4* src = (const float4*)aligned;
+  const int nq = (lead + n + 3) >> 2;
+  const int wave = tid >> 6, lane = tid & 63;
+  for (int c = wave; c * 64 < nq; c += 4)
+    __builtin_amdgcn_global_load_lds(GLB_PTR(src + min(c * 64 + lane, nq - 1)), LDS_PTR(lds + c * 256), 16, 0, 0);
+}
+
 __global__ __launch_bounds__(256) void masks_kernel(const float* __restrict__ conf, const float* __restrict__ lp,
-                                                    int F, int H, int W, float thr, float rtol,
-                                                    uint8_t* __restrict__ out) {   // thr: the e-threshold (estar)
-  extern __shared__ __attribute__((aligned(16))) float zs[];          // (MK_ROWS + 2) rows of W + 2 floats
-  const int strips = (H + MK_ROWS - 1) / MK_ROWS;
-  const int f = blockIdx.x / strips, y0 = (blockIdx.x % strips) * MK_ROWS;
+                                                    int F, int H, int W, int R, int zfloats, float estar, float rtol,
+                                                    MaskFast mf, uint8_t* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) float zs[];          // staged rows (zfloats), then the confidences
+  const int strips = (H + R - 1) / R;
+  // workgroups go round-robin to the 8 XCDs: give XCD k the k-th eighth of the strips, in order, so that the halo rows
+  // two neighbouring strips share are fetched into one L2 once (the grid is padded to a multiple of 8)
+  const int per_xcd = gridDim.x >> 3;
+  const int wg = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  if (wg >= F * strips) return;
+  const int f = wg / strips, y0 = (wg % strips) * R;
   const int tid = threadIdx.x;
-  const int ylo = max(y0 - 1, 0), yhi = min(y0 + MK_ROWS + 1, H);       // staged rows [ylo, yhi)
-  const int P = W + 2, nst = yhi - ylo;
-  {
-    const float* first = lp + ((long)f * H + ylo) * W * 3;
-    const uintptr_t addr = (uintptr_t)first, aligned = addr & ~(uintptr_t)15;
-    const int lead = (int)((addr - aligned) >> 2);                      // floats in front of the strip in float4 0
-    const float4* src = (const float4*)aligned;
-    const int npix = nst * W;
-    const int nq = (lead + 3 * npix + 3) >> 2;
-    const int s3 = 4 * tid - lead + 3;                                  // strip offset of element 0, biased by +3 (>= 0)
-    int pix = s3 / 3 - 1, r = s3 - 3 * (s3 / 3);
-    // (row, x) of pixel `pix`, kept incrementally; pix = -1 (only possible for the very first float4) maps to (0, -1)
-    int row = pix < 0 ? 0 : pix / W, x = pix < 0 ? -1 : pix - row * W;
-    const bool wide = W >= 342;                                         // one conditional subtraction per step is enough
-    for (int q = tid; q < nq; q += 256) {
-      const float4 v = src[q];
-      const float za = r == 0 ? v.z : (r == 1 ? v.y : v.x);
-      if (pix >= 0 && pix < npix) zs[row * P + 1 + x] = za;
-      if (r == 2 && pix + 1 < npix) {
-        const bool wrap = x + 1 >= W;
-        zs[(wrap ? row + 1 : row) * P + 1 + (wrap ? 0 : x + 1)] = v.w;
-      }
-      pix += 341;                                                       // 256 threads x 4 floats = 1024 = 3 * 341 + 1
-      x += 341;
-      if (++r == 3) { r = 0; ++pix; ++x; }
-      if (wide) {
-        if (x >= W) { x -= W; ++row; }
-      } else {
-        row = pix / W;
-        x = pix - row * W;
-      }
-    }
-  }
-  __syncthreads();
-  if (tid < 2 * nst) {                                                  // replicated edge columns
-    const int rr = tid >> 1;
-    if (tid & 1) zs[rr * P + W + 1] = zs[rr * P + W];
-    else zs[rr * P] = zs[rr * P + 1];
-  }
-  __syncthreads();
-  const int rows = min(MK_ROWS, H - y0);
-  const int npx = rows * W;
+  const int ylo = max(y0 - 1, 0), yhi = min(y0 + R + 1, H);             // staged rows [ylo, yhi)
+  const int nst = yhi - ylo, rows = min(R, H - y0), npx = rows * W;
   const long p0 = ((long)f * H + y0) * W;                               // first pixel of the strip, frame-linear
+  float* cs = zs + zfloats;
+  int zlead, clead;
+  mk_stage(lp + ((long)f * H + ylo) * W * 3, 3 * nst * W, zs, tid, zlead);
+  mk_stage(conf + p0, npx, cs, tid, clead);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  const float* zz = zs + zlead + 2;                                     // z of staged pixel p: zz[3 p]
+  const float* cc = cs + clead;
+  int sawnan = 0;
+  for (int p = tid; p < nst * W; p += 256) { const float v = zz[3 * p]; sawnan |= v != v; }
+  const bool fast = !__syncthreads_or(sawnan) && mf.ok;                 // (the barrier is executed either way)
   const int yoff = y0 - ylo;                                            // staged row of the strip's first row (0 or 1)
-  // consecutive lanes take consecutive pixels: the nine window reads of a wave then walk consecutive LDS words (no bank
-  // conflict; four pixels per lane made every read 4-way conflicted), confidence loads and mask stores are coalesced
   int ry = tid / W, x = tid - ry * W;
   const bool wide = W >= 256;
   for (int e = tid; e < npx; e += 256) {
     const int yc = yoff + ry;
-    const float* zr1 = zs + yc * P;
-    const float* zr0 = zs + max(yc - 1, 0) * P;
-    const float* zr2 = zs + min(yc + 1, nst - 1) * P;
-    out[p0 + e] = mask_pixel(zr0, zr1, zr2, x, conf[p0 + e], thr, rtol);
+    const float* r1 = zz + 3 * (yc * W);
+    const float* r0 = zz + 3 * (max(yc - 1, 0) * W);
+    const float* r2 = zz + 3 * (min(yc + 1, nst - 1) * W);
+    const int xl = 3 * max(x - 1, 0), xc = 3 * x, xr = 3 * min(x + 1, W - 1);
+    MaskWin w;
+    w.a0 = r0[xl]; w.a1 = r0[xc]; w.a2 = r0[xr];
+    w.b0 = r1[xl]; w.z = r1[xc]; w.b2 = r1[xr];
+    w.c0 = r2[xl]; w.c1 = r2[xc]; w.c2 = r2[xr];
+    const float cf = cc[e];
+    out[p0 + e] = fast ? mask_pixel_fast(w, cf, estar, rtol, mf) : mask_pixel(w, cf, estar, rtol);
     x += 256;
     if (wide) {
       if (x >= W) { x -= W; ++ry; }
@@ -123,7 +142,7 @@ __global__ __launch_bounds__(256) void masks_kernel(const float* __restrict__ co
 extern "C" int pi3_compute_masks(const float* conf, const float* local_points, int F, int H, int W, float conf_thr,
                                  float rtol, unsigned char* masks, void* stream) {
   if (!conf || !local_points || !masks || F <= 0 || H <= 0 || W <= 0 || W > MK_MAXW ||
-      ((uintptr_t)local_points & 3) != 0) {
+      ((uintptr_t)local_points & 3) != 0 || ((uintptr_t)conf & 3) != 0) {
     pi3_set_error("pi3_compute_masks: bad arguments (W <= %d, 4-byte aligned maps)", MK_MAXW);
     return PI3_ERR_ARG;
   }
@@ -149,9 +168,29 @@ extern "C" int pi3_compute_masks(const float* conf, const float* local_points, i
       memcpy(&estar, &lo, 4);
     }
   }
-  const long nwg = (long)F * ((H + MK_ROWS - 1) / MK_ROWS);
-  hipLaunchKernelGGL(masks_kernel, dim3((unsigned)nwg), dim3(256), (size_t)(MK_ROWS + 2) * (W + 2) * sizeof(float),
-                     (hipStream_t)stream, conf, local_points, F, H, W, estar, rtol, masks);
+  MaskFast mf;
+  mf.ok = (rtol >= 0.0f && rtol < FLT_MAX && !getenv("PI3_MASKS_EXACT_ONLY")) ? 1 : 0;
+  mf.rlo = (float)((double)rtol * (1.0 - 1e-5));
+  mf.rhi = (float)((double)rtol * (1.0 + 1e-5));
+  mf.clo = -INFINITY;                              // "never decided without the expf" unless the bracket is sound
+  mf.chi = INFINITY;
+  if (estar > 1e-30f && estar < 1e30f) {
+    const double c0 = -log((double)estar), band = 1e-5 * (1.0 + fabs(c0));
+    mf.clo = (float)(c0 - band);
+    mf.chi = (float)(c0 + band);
+  }
+  // strip height: the tallest whose staged rows + confidences (worst-case 3 floats of lead each) fit the budget
+  int R = 16;
+  if (const char* e = getenv("PI3_MASKS_ROWS")) R = atoi(e) > 0 ? atoi(e) : R;
+  R = R < H ? R : H;
+  auto lds_bytes = [&](int r) { return (size_t)(mk_lds_floats(3, 3 * (r + 2) * W) + mk_lds_floats(3, r * W)) * sizeof(float); };
+  size_t budget = MK_LDS_BUDGET;
+  if (const char* e = getenv("PI3_MASKS_LDS_KB")) budget = (size_t)atoi(e) * 1024;
+  while (R > 1 && lds_bytes(R) > budget) --R;
+  const int zfloats = mk_lds_floats(3, 3 * (R + 2) * W);
+  const long nwg = (long)F * ((H + R - 1) / R);
+  hipLaunchKernelGGL(masks_kernel, dim3((unsigned)((nwg + 7) / 8 * 8)), dim3(256), lds_bytes(R), (hipStream_t)stream, conf, local_points,
+                     F, H, W, R, zfloats, estar, rtol, mf, masks);
   return pi3_check_launch("compute_masks");
 }
 

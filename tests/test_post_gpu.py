@@ -71,6 +71,53 @@ def test_masks_edge_cases(dev):
     assert torch.equal(got, post_ref.compute_masks(conf, lp))
 
 
+def _adversarial_maps(case, F, H, W, g):
+    lp = torch.randn(F, H, W, 3, generator=g)
+    z = torch.exp(0.3 * torch.randn(F, H, W, generator=g))
+    if case in ("smooth", "conf_at_crossing"):          # depth ratios of the 3x3 window around rtol = 0.03
+        z = (1.0 + torch.arange(H).view(1, H, 1) * 0.0148 + torch.arange(W).view(1, 1, W) * 0.0151
+             + 1e-4 * torch.randn(F, H, W, generator=g))
+    if case in ("specials", "specials_no_nan"):
+        r = torch.rand(F, H, W, generator=g)
+        if case == "specials":
+            z = torch.where(r < 0.01, torch.full_like(z, float("nan")), z)
+        z = torch.where((r > 0.01) & (r < 0.02), torch.full_like(z, float("inf")), z)
+        z = torch.where((r > 0.02) & (r < 0.03), torch.zeros_like(z), z)
+        z = torch.where((r > 0.03) & (r < 0.04), -z, z)
+        z = torch.where((r > 0.04) & (r < 0.05), z * 1e-42, z)
+        z = torch.where((r > 0.05) & (r < 0.06), z * 1e35, z)
+        z = torch.where((r > 0.06) & (r < 0.07), torch.full_like(z, float("-inf")), z)
+    lp[..., 2] = z
+    conf = torch.randn(F, H, W, 1, generator=g) * 3
+    if case == "conf_at_crossing":                       # confidences within 200 ulp of sigmoid(c) = 0.1
+        c0 = torch.full((F, H, W, 1), -float(np.log(9.0)))
+        conf = (c0.view(torch.int32) + torch.randint(-200, 200, (F, H, W, 1), generator=g, dtype=torch.int32)).view(torch.float32)
+    return conf.contiguous(), lp.contiguous()
+
+
+@pytest.mark.parametrize("case", ["random", "smooth", "specials", "specials_no_nan", "conf_at_crossing"])
+@pytest.mark.parametrize("shape", [(6, 61, 406), (3, 17, 5), (2, 9, 1024), (1, 1, 1), (2, 14, 342)])
+def test_masks_fast_decisions_equal_the_exact_arithmetic(dev, case, shape, monkeypatch):
+    """masks_kernel decides most pixels without the IEEE division and the expf (post.hip: mask_pixel_fast) and falls
+    back to them inside a band around the thresholds / for strips holding a NaN.  Both forms must give the decisions of
+    the oracle (= the reference's arithmetic); with confidences packed within ulps of the sigmoid's crossing, where the
+    device expf and the CPU exp may round differently, the two device forms are compared with each other."""
+    from oracle import post_ref
+    from pi3_slam_amd import ops
+    g = torch.Generator().manual_seed(hash((case,) + shape) % (1 << 31))
+    conf, lp = _adversarial_maps(case, *shape, g)
+    for thr, rtol in [(0.1, 0.03), (0.5, 0.0), (0.9, 1.0), (-1.0, 0.03), (1.0, 0.03), (1e-30, 3e38), (0.1, float("inf"))]:
+        monkeypatch.delenv("PI3_MASKS_EXACT_ONLY", raising=False)
+        fast = ops.compute_masks(conf.to(dev), lp.to(dev), thr, rtol).cpu()
+        monkeypatch.setenv("PI3_MASKS_EXACT_ONLY", "1")
+        exact = ops.compute_masks(conf.to(dev), lp.to(dev), thr, rtol).cpu()
+        monkeypatch.delenv("PI3_MASKS_EXACT_ONLY", raising=False)
+        assert torch.equal(fast, exact), (case, shape, thr, rtol, int((fast != exact).sum()))
+        if case != "conf_at_crossing":
+            want = post_ref.compute_masks(conf, lp, conf_thr=thr, rtol=rtol)
+            assert torch.equal(fast.bool(), want), (case, shape, thr, rtol, int((fast.bool() != want).sum()))
+
+
 def test_ratio_median_semantics(dev):
     from pi3_slam_amd import ops
     torch.manual_seed(0)

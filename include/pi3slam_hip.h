@@ -83,6 +83,10 @@ int pi3_qknorm_rope(void* qkv, long rows, int H, int T, const int* pos, const fl
 
 /* f32 -> bf16/f32 strided row copy (concat of the last two decoder outputs, pi3.py:168-171). */
 int pi3_cast_rows(const float* in, long ldi, void* out, long ldo, long rows, int cols, int out_dtype, void* stream);
+/* same, reading only the first in_cols columns of a row and writing zeros in [in_cols, cols): the K padding of the GEMM
+ * that follows a narrow MoGe map (moge/model/modules.py:242-254 feeds 32-channel maps to 1x1 convolutions). */
+int pi3_cast_rows_pad(const float* in, long ldi, int in_cols, void* out, long ldo, long rows, int cols, int out_dtype,
+                      void* stream);
 
 /* frames f32 [F][3][H][W] -> ImageNet-normalised (pi3.py:174) bf16 patch rows [F*P][KP], column c*196 + ky*14 + kx,
  * zero padded to KP: the im2col of PatchEmbed's Conv2d (patch_embed.py:65,75).  mean3/std3 are HOST arrays. */

@@ -168,6 +168,144 @@ static int launch_gemm(const GemmParams& p, hipStream_t stream) {
   return pi3_check_launch("gemm_tn");
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Narrow-N variant (round 3): 256 rows x (16 NT) columns per workgroup, NT = 2 or 4, the four waves stacked along M (64
+// rows each, all of them reading the whole W tile).  For the MoGe conv pyramid, whose finest levels are 32-channel maps
+// of ~900 k pixels: padded to the 128-column tile of the kernel above they did 4x the MFMA work and, worse, wrote 4x
+// the bytes (a 32-channel fp32 map as 128-float rows).  Same LDS image, swizzle and fragment reads as above.
+// CONV with cC == 32: a 128-byte LDS row holds the 32 channels of TWO taps (K-step t = taps 2t and 2t + 1, k = tap * 32
+// + ci; the weight rows carry zeros for the tenth tap, which is staged from tap 8 so that it is finite data): 5 K-steps
+// instead of 9 half-empty ones.
+// ---------------------------------------------------------------------------------------------------------------
+#define NBM 256
+
+template <int NT, bool CONV>
+__device__ __forceinline__ void stage_narrow(const GemmParams& p, int row0, int n0, int t, char* lds_a, char* lds_w,
+                                             int wave, int lane) {
+  const int pos = lane & 7;
+  // ---- A: segments 8 wave .. 8 wave + 7 (8 rows of 128 B each)
+  int tap = 0, c0 = 0, ky = 0, kx = 0;
+  const bool half = CONV && p.cC == 32;
+  if (CONV && !half) {
+    const int cblocks = p.cC >> 6;
+    tap = t / cblocks;
+    c0 = (t - tap * cblocks) << 6;
+    ky = tap / 3 - 1;
+    kx = tap - (tap / 3) * 3 - 1;
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int seg = wave * 8 + i;
+    const int row = seg * 8 + (lane >> 3);
+    const int c = pos ^ ((row >> 1) & 7);
+    int m = row0 + row;
+    m = m < p.M ? m : p.M - 1;
+    const char* src;
+    if constexpr (CONV) {
+      int cc = c;
+      if (half) {
+        tap = min(2 * t + (c >> 2), 8);
+        cc = c & 3;
+        ky = tap / 3 - 1;
+        kx = tap - (tap / 3) * 3 - 1;
+      }
+      const int x = m % p.cW;
+      const int by = m / p.cW;  // b * cH + y
+      const int y = by % p.cH;
+      int yy = y + ky, xx = x + kx;
+      yy = yy < 0 ? 0 : (yy >= p.cH ? p.cH - 1 : yy);
+      xx = xx < 0 ? 0 : (xx >= p.cW ? p.cW - 1 : xx);
+      const long pix = (long)(by - y + yy) * p.cW + xx;
+      src = (const char*)p.A + (pix * p.lda + c0) * 2 + cc * 16;
+    } else {
+      src = (const char*)p.A + ((long)m * p.lda + (long)t * 64) * 2 + c * 16;
+    }
+    __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(lds_a + seg * 1024), 16, 0, 0);
+  }
+  // ---- W: 2 NT segments, wave w takes w (and w + 4)
+#pragma unroll
+  for (int i = 0; i < NT / 2; ++i) {
+    const int seg = wave + 4 * i;
+    if (seg < 2 * NT) {
+      const int row = seg * 8 + (lane >> 3);
+      const int c = pos ^ ((row >> 1) & 7);
+      const char* src = (const char*)p.W + ((long)(n0 + row) * p.ldw + (long)t * 64) * 2 + c * 16;
+      __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(lds_w + seg * 1024), 16, 0, 0);
+    }
+  }
+}
+
+template <int NT, bool OUT_BF16, int ACT, bool CONV>
+__global__ __launch_bounds__(256) void gemm_narrow_kernel(GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int A_BYTES = NBM * 128, STAGE = A_BYTES + 16 * NT * 128;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nbm = (p.M + NBM - 1) / NBM, nbn = p.N / (16 * NT);
+  const int id = xcd_remap(blockIdx.x, nbm * nbn);
+  const int bm = id / nbn, bn = id - bm * nbn;      // the (few) column tiles of a row panel run back to back
+  const int nk = p.K / 64;
+
+  f32x4 acc[NT][4];
+#pragma unroll
+  for (int i = 0; i < NT; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  stage_narrow<NT, CONV>(p, bm * NBM, bn * 16 * NT, 0, smem, smem + A_BYTES, wave, lane);
+  __syncthreads();
+  const int frow = lane & 15, swz = (lane >> 1) & 7, cq = lane >> 4;
+  int cur = 0;
+  for (int t = 0; t < nk; ++t) {
+    if (t + 1 < nk)
+      stage_narrow<NT, CONV>(p, bm * NBM, bn * 16 * NT, t + 1, smem + (cur ^ 1) * STAGE, smem + (cur ^ 1) * STAGE + A_BYTES,
+                             wave, lane);
+    const char* la = smem + cur * STAGE + (wave * 64 + frow) * 128;
+    const char* lw = smem + cur * STAGE + A_BYTES + frow * 128;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const int off = ((cq + 4 * kk) ^ swz) << 4;
+      bf16x8 fa[4], fw[NT];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fa[i] = *(const bf16x8*)(la + i * 16 * 128 + off);
+#pragma unroll
+      for (int i = 0; i < NT; ++i) fw[i] = *(const bf16x8*)(lw + i * 16 * 128 + off);
+#pragma unroll
+      for (int ni = 0; ni < NT; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+          acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[ni], fa[mi], acc[ni][mi], 0, 0, 0);
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+  gemm_epilogue<OUT_BF16, ACT, NT, 4>(p, acc, bm * NBM + wave * 64, bn * 16 * NT, lane);
+}
+
+template <bool OUT_BF16, int ACT, bool CONV>
+static int launch_narrow(const GemmParams& p, hipStream_t stream) {
+  const int nbm = (p.M + NBM - 1) / NBM;
+  if (p.N % 64 == 0) {
+    auto kern = gemm_narrow_kernel<4, OUT_BF16, ACT, CONV>;
+    constexpr int lds = 2 * (NBM * 128 + 64 * 128);
+    static bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(nbm * (p.N / 64)), dim3(256), lds, stream, p);
+  } else {
+    auto kern = gemm_narrow_kernel<2, OUT_BF16, ACT, CONV>;
+    constexpr int lds = 2 * (NBM * 128 + 32 * 128);
+    static bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(nbm * (p.N / 32)), dim3(256), lds, stream, p);
+  }
+  return pi3_check_launch("gemm_narrow");
+}
+
 int pi3_gemm256_try(const GemmParams& p, int out_dtype, int act, hipStream_t stream);
 
 // in_dtype: 0 = bf16 operands, 1 = f32 operands.  out_dtype: 0 = bf16, 1 = f32.  act: 0 none, 1 GELU(erf), 2 ReLU.
@@ -176,8 +314,10 @@ extern "C" int pi3_gemm(const void* A, long lda, const void* W, long ldw, int M,
                         int out_dtype, int act, int rpg, int gstride, int goff, const float* addtab, long ldadd,
                         float qscale, int qcols, void* stream) {
   const int bk = in_dtype == 0 ? 64 : 32;
-  if (!A || !W || !out || M <= 0 || N <= 0 || K <= 0 || (N % BN) != 0 || (K % bk) != 0 || act < 0 || act > 2) {
-    pi3_set_error("pi3_gemm: bad arguments M=%d N=%d K=%d (N %% 128 == 0, K %% %d == 0 required)", M, N, K, bk);
+  const bool narrow = in_dtype == 0 && (N % BN) != 0 && (N % 32) == 0;     // bf16 operands, N = 32, 64, 96, 160, ...
+  if (!A || !W || !out || M <= 0 || N <= 0 || K <= 0 || ((N % BN) != 0 && !narrow) || (K % bk) != 0 || act < 0 || act > 2) {
+    pi3_set_error("pi3_gemm: bad arguments M=%d N=%d K=%d (N %% 128 == 0, or N %% 32 == 0 with bf16 operands; K %% %d == 0 required)",
+                  M, N, K, bk);
     return PI3_ERR_ARG;
   }
   if ((lda * (in_dtype == 0 ? 2 : 4)) % 16 || (ldw * (in_dtype == 0 ? 2 : 4)) % 16 || ((uintptr_t)A & 15) ||
@@ -193,6 +333,14 @@ extern "C" int pi3_gemm(const void* A, long lda, const void* W, long ldw, int M,
   p.cH = 0; p.cW = 0; p.cC = 0;
   p.qk_mode = 0; p.qk_k2max = nullptr; p.tile_gm = 0;
   hipStream_t s = (hipStream_t)stream;
+  if (narrow) {
+    if (out_dtype == 0 && act == 0) return launch_narrow<true, 0, false>(p, s);
+    if (out_dtype == 0 && act == 1) return launch_narrow<true, 1, false>(p, s);
+    if (out_dtype == 1 && act == 0) return launch_narrow<false, 0, false>(p, s);
+    if (out_dtype == 1 && act == 2) return launch_narrow<false, 2, false>(p, s);
+    pi3_set_error("pi3_gemm: unsupported (out_dtype=%d, act=%d) for a narrow N", out_dtype, act);
+    return PI3_ERR_ARG;
+  }
   if (in_dtype == 0) {  // large bf16 GEMMs: 256x256 pipelined kernel (PI3_GEMM_IMPL=1 forces the 128x128 kernel)
     static int impl = -1;
     if (impl < 0) {
@@ -293,19 +441,29 @@ extern "C" int pi3_gemm_qkv(const void* A, long lda, const void* W, long ldw, in
 extern "C" int pi3_conv3x3(const void* img, long ldc, int B, int H, int W, int C, const void* wgt, int N,
                            const float* bias, const float* resid, long ldr, void* out, long ldo, int out_dtype, int act,
                            void* stream) {
-  if (!img || !wgt || !out || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C % 64) || N <= 0 || (N % BN) || (ldc % 8) ||
-      ((uintptr_t)img & 15) || ((uintptr_t)wgt & 15) || ((uintptr_t)out & 15) || (ldo % 4) || act < 0 || act > 2 ||
-      (long)B * H * W > 0x7fffffffL) {
-    pi3_set_error("pi3_conv3x3: bad arguments B=%d H=%d W=%d C=%d N=%d (C %% 64 == 0, N %% 128 == 0)", B, H, W, C, N);
+  const bool narrow = (N % BN) != 0 || C == 32;
+  if (!img || !wgt || !out || B <= 0 || H <= 0 || W <= 0 || C <= 0 || ((C % 64) && C != 32) || N <= 0 || (N % 32) ||
+      (ldc % 8) || ((uintptr_t)img & 15) || ((uintptr_t)wgt & 15) || ((uintptr_t)out & 15) || (ldo % 4) || act < 0 ||
+      act > 2 || (long)B * H * W > 0x7fffffffL) {
+    pi3_set_error("pi3_conv3x3: bad arguments B=%d H=%d W=%d C=%d N=%d (C %% 64 == 0 or C == 32, N %% 32 == 0)", B, H, W, C, N);
     return PI3_ERR_ARG;
   }
   GemmParams p;
-  p.A = img; p.lda = ldc; p.W = wgt; p.ldw = 9L * C; p.M = B * H * W; p.N = N; p.K = 9 * C;
+  // C == 32: weight rows are [10 taps][32] (the tenth tap zero), two taps per K-step
+  const long kw = C == 32 ? 320 : 9L * C;
+  p.A = img; p.lda = ldc; p.W = wgt; p.ldw = kw; p.M = B * H * W; p.N = N; p.K = (int)kw;
   p.bias = bias; p.gamma = nullptr; p.resid = resid; p.ldr = ldr; p.out = out; p.ldo = ldo;
   p.rpg = 0; p.gstride = 0; p.goff = 0; p.addtab = nullptr; p.ldadd = 0; p.qscale = 1.f; p.qcols = 0;
   p.cH = H; p.cW = W; p.cC = C;
   p.qk_mode = 0; p.qk_k2max = nullptr; p.tile_gm = 0;
   hipStream_t s = (hipStream_t)stream;
+  if (narrow) {
+    if (out_dtype == 0 && act == 0) return launch_narrow<true, 0, true>(p, s);
+    if (out_dtype == 1 && act == 0) return launch_narrow<false, 0, true>(p, s);
+    if (out_dtype == 0 && act == 2) return launch_narrow<true, 2, true>(p, s);
+    pi3_set_error("pi3_conv3x3: unsupported (out_dtype=%d, act=%d)", out_dtype, act);
+    return PI3_ERR_ARG;
+  }
   if (out_dtype == 0 && act == 0) return launch_gemm<true, true, 0, true>(p, s);
   if (out_dtype == 1 && act == 0) return launch_gemm<true, false, 0, true>(p, s);
   if (out_dtype == 0 && act == 2) return launch_gemm<true, true, 2, true>(p, s);

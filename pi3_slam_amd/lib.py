@@ -26,6 +26,7 @@ SIGNATURES = {
     "pi3_layernorm": [_vp, _l, _i, _i, _vp, _vp, _f, _vp, _l, _i, _i, _i, _vp, _vp],
     "pi3_qknorm_rope": [_vp, _l, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _i, _vp],
     "pi3_cast_rows": [_vp, _l, _vp, _l, _l, _i, _i, _vp],
+    "pi3_cast_rows_pad": [_vp, _l, _i, _vp, _l, _l, _i, _i, _vp],
     "pi3_patch_gather": [_vp, _i, _i, _i, _vp, _i, C.POINTER(_f), C.POINTER(_f), _vp],
     "pi3_resample_grid": [_vp, _i, _i, _i, _vp, _vp, _i, _i, _vp, _vp],
     "pi3_fill_tokens": [_vp, _i, _i, _i, _i, _i, _vp, _vp],

@@ -62,6 +62,19 @@ def _up(x, m):
     return (x + m - 1) // m * m
 
 
+def _npad(c):
+    """Row stride of an fp32 NHWC map / output columns of a GEMM or convolution: the narrow-N kernels (gemm.hip:
+    gemm_narrow_kernel) take any multiple of 32, so a 32-channel map of the finest pyramid levels is stored as 32-float
+    rows, not padded to the 128-column tile of the big kernels (4x the bytes on ~900 k pixels)."""
+    return _up(c, 32)
+
+
+def _cpad(c):
+    """Channel stride of a bf16 staging image that a 3x3 convolution reads: one 64-channel block per tap, or - for maps of
+    up to 32 channels - 32 channels with two taps per K-step (pi3_conv3x3, C == 32)."""
+    return 32 if c <= 32 else _up(c, 64)
+
+
 ACTS = {"relu": 2, "leaky_relu": 3, "silu": 4, "elu": 5}          # ops.ACT_* codes of pi3_groupnorm_apply
 NORMS = ("group_norm", "layer_norm", "instance_norm", "none")
 UPSAMPLERS = ("conv_transpose", "pixel_shuffle", "nearest", "bilinear")
@@ -304,24 +317,28 @@ class MoGeEngine:
             self.w[name] = w
         elif ".backbone.blocks." in name and name.endswith(("qkv.weight", "proj.weight", "fc1.weight", "fc2.weight")):
             self.w[name] = t.to(bf).contiguous()
-        elif t.dim() == 4 and t.shape[2] == 3:            # 3x3 conv [Co, Ci, 3, 3] -> [Co_pad128, 3*3*Ci_pad64]
+        elif t.dim() == 4 and t.shape[2] == 3:            # 3x3 conv [Co, Ci, 3, 3] -> [Co_pad32, 3*3*Ci_pad64] / [Co_pad32, 10*32]
             if name.rsplit(".", 1)[0] in self._ps_convs:  # PixelShuffle(2): channel co*4 + q -> row q*Cn + co
                 Cn = t.shape[0] // 4
                 t = t.reshape(Cn, 4, *t.shape[1:]).transpose(0, 1).reshape(4 * Cn, *t.shape[1:])
             Co, Ci = t.shape[:2]
-            w = torch.zeros(_up(Co, 128), 3, 3, _up(Ci, 64), device=dev, dtype=bf)
-            w[:Co, :, :, :Ci] = t.permute(0, 2, 3, 1).to(bf)
+            if _cpad(Ci) == 32:       # ten tap slots of 32 channels (two taps per K-step), the tenth stays zero
+                w = torch.zeros(_npad(Co), 10, 32, device=dev, dtype=bf)
+                w[:Co, :9, :Ci] = t.permute(0, 2, 3, 1).reshape(Co, 9, Ci).to(bf)
+            else:
+                w = torch.zeros(_npad(Co), 3, 3, _up(Ci, 64), device=dev, dtype=bf)
+                w[:Co, :, :, :Ci] = t.permute(0, 2, 3, 1).to(bf)
             self.w[name] = w.reshape(w.shape[0], -1).contiguous()
         elif t.dim() == 4 and t.shape[2] == 2:            # ConvTranspose2d [Ci, Co, 2, 2] -> [(dy*2+dx)*Co + co, Ci_pad64]
             Ci, Co = t.shape[:2]
-            assert (4 * Co) % 128 == 0, "conv_transpose output channels must be a multiple of 32"
+            assert (4 * Co) % 32 == 0, "conv_transpose output channels must be a multiple of 8"
             w = torch.zeros(4 * Co, _up(Ci, 64), device=dev, dtype=bf)
             w[:, :Ci] = t.permute(2, 3, 1, 0).reshape(4 * Co, Ci).to(bf)
             self.w[name] = w.contiguous()
         elif t.dim() == 4:                                # 1x1 conv [Co, Ci, 1, 1]
             Co, Ci = t.shape[:2]
             self.w[name + "#f32"] = t.reshape(Co, Ci).contiguous()     # UV columns are applied in fp32
-            w = torch.zeros(_up(Co, 128), _up(Ci, 64), device=dev, dtype=bf)
+            w = torch.zeros(_npad(Co), _up(Ci, 64), device=dev, dtype=bf)
             w[:Co, :Ci] = t.reshape(Co, Ci).to(bf)
             self.w[name] = w.contiguous()
         elif ".resamplers." in name and name.endswith(".0.bias") and name.rsplit(".", 1)[0] in self._ps_convs:
@@ -334,7 +351,7 @@ class MoGeEngine:
                                          or ".res_blocks." in name and name.split(".")[-2] in ("2", "5")
                                          or ".resamplers." in name
                                          or name.startswith("encoder.output_projections")):
-            b = torch.zeros(_up(t.shape[0], 128), device=dev)
+            b = torch.zeros(_npad(t.shape[0]), device=dev)
             b[: t.shape[0]] = t
             self.w[name] = b
         else:
@@ -344,12 +361,13 @@ class MoGeEngine:
     def _new(self, rows: int, cols: int, dtype=torch.float32) -> torch.Tensor:
         return torch.empty(rows, cols, device=self.device, dtype=dtype)
 
-    def _to_bf16(self, a: _Act) -> torch.Tensor:
-        """bf16 NHWC staging copy, channel stride = C rounded up to 64.  The fp32 maps keep exact zeros in their padded
-        columns (zero-padded weights and biases), so the pad of the copy is zero as well."""
-        Cp = _up(a.C, 64)
+    def _to_bf16(self, a: _Act, conv: bool = False) -> torch.Tensor:
+        """bf16 NHWC staging copy for a 1x1 convolution (channel stride = C rounded up to 64, the GEMM's K-step) or, with
+        conv=True, for a 3x3 one (_cpad).  The fp32 maps keep exact zeros in their padded columns (zero-padded weights and
+        biases); columns beyond the map's row are written as zeros."""
+        Cp = _cpad(a.C) if conv else _up(a.C, 64)
         out = self._new(a.H * a.W, Cp, torch.bfloat16)
-        ops.cast_rows(a.t, out, rows=a.H * a.W, cols=Cp)
+        ops.cast_rows(a.t, out, rows=a.H * a.W, cols=Cp, in_cols=min(Cp, a.t.shape[1]))
         return out
 
     def _uv(self, H: int, W: int, ar: float):
@@ -373,7 +391,7 @@ class MoGeEngine:
     def _norm_act(self, src: _Act, key: str, norm: str, act: int) -> torch.Tensor:
         """norm + activation of a map -> bf16 NHWC staging image for the following 3x3 convolution."""
         HW, C = src.H * src.W, src.C
-        Cp = _up(C, 64)
+        Cp = _cpad(C)
         a = self._new(HW, Cp, torch.bfloat16)
         if norm == "none":
             ops.groupnorm_apply(src.t, HW, C, Cp, 0, None, None, None, 1e-5, act, a)
@@ -390,10 +408,10 @@ class MoGeEngine:
         """ResidualConvBlock (modules.py:18-68) with in == out channels: x += conv(act(norm(conv(act(norm(x))))))."""
         C, hid = x.C, mult * x.C
         a = self._norm_act(x, f"{p}.0", in_norm, act)
-        h = _Act(self._new(x.H * x.W, _up(hid, 128)), hid, x.H, x.W)
-        ops.conv3x3(a, x.H, x.W, _up(C, 64), self.w[f"{p}.2.weight"], self.w[f"{p}.2.bias"], h.t)
+        h = _Act(self._new(x.H * x.W, _npad(hid)), hid, x.H, x.W)
+        ops.conv3x3(a, x.H, x.W, _cpad(C), self.w[f"{p}.2.weight"], self.w[f"{p}.2.bias"], h.t)
         a = self._norm_act(h, f"{p}.3", hid_norm, act)
-        ops.conv3x3(a, x.H, x.W, _up(hid, 64), self.w[f"{p}.5.weight"], self.w[f"{p}.5.bias"], x.t, resid=x.t)
+        ops.conv3x3(a, x.H, x.W, _cpad(hid), self.w[f"{p}.5.weight"], self.w[f"{p}.5.bias"], x.t, resid=x.t)
 
     def _resample(self, p: str, kind: str, x: _Act, Cn: int) -> _Act:
         """Resampler (modules.py:139-182), scale factor 2."""
@@ -401,18 +419,18 @@ class MoGeEngine:
         if kind == "conv_transpose":          # ConvTranspose2d(k = s = 2) as a GEMM + scatter, then Conv2d 3x3
             g = self._new(H * W, 4 * Cn)
             ops.gemm(self._to_bf16(x), self.w[p + ".0.weight"], g, M=H * W, bias=self.w[p + ".0.bias"])
-            up = self._new(4 * H * W, _up(Cn, 64), torch.bfloat16)
-            ops.convt_scatter(g, H, W, Cn, Cn, _up(Cn, 64), up)
-            out = _Act(self._new(4 * H * W, _up(Cn, 128)), Cn, 2 * H, 2 * W)
-            ops.conv3x3(up, 2 * H, 2 * W, _up(Cn, 64), self.w[p + ".1.weight"], self.w[p + ".1.bias"], out.t)
+            up = self._new(4 * H * W, _cpad(Cn), torch.bfloat16)
+            ops.convt_scatter(g, H, W, Cn, Cn, _cpad(Cn), up)
+            out = _Act(self._new(4 * H * W, _npad(Cn)), Cn, 2 * H, 2 * W)
+            ops.conv3x3(up, 2 * H, 2 * W, _cpad(Cn), self.w[p + ".1.weight"], self.w[p + ".1.bias"], out.t)
             return out
         if kind == "pixel_shuffle":           # Conv2d(C, 4 Cn, 3) with (dy, dx, co)-major rows + the same scatter
-            g = self._new(H * W, _up(4 * Cn, 128))
-            ops.conv3x3(self._to_bf16(x), H, W, _up(C, 64), self.w[p + ".0.weight"], self.w[p + ".0.bias"], g)
-            up = self._new(4 * H * W, _up(Cn, 64), torch.bfloat16)
-            ops.convt_scatter(g, H, W, Cn, Cn, _up(Cn, 64), up)
-            out = _Act(self._new(4 * H * W, _up(Cn, 128)), Cn, 2 * H, 2 * W)
-            ops.conv3x3(up, 2 * H, 2 * W, _up(Cn, 64), self.w[p + ".2.weight"], self.w[p + ".2.bias"], out.t)
+            g = self._new(H * W, _npad(4 * Cn))
+            ops.conv3x3(self._to_bf16(x, conv=True), H, W, _cpad(C), self.w[p + ".0.weight"], self.w[p + ".0.bias"], g)
+            up = self._new(4 * H * W, _cpad(Cn), torch.bfloat16)
+            ops.convt_scatter(g, H, W, Cn, Cn, _cpad(Cn), up)
+            out = _Act(self._new(4 * H * W, _npad(Cn)), Cn, 2 * H, 2 * W)
+            ops.conv3x3(up, 2 * H, 2 * W, _cpad(Cn), self.w[p + ".2.weight"], self.w[p + ".2.bias"], out.t)
             return out
         # nn.Upsample(scale_factor=2, mode=nearest | bilinear(align_corners=False)) then Conv2d(C, Cn, 3)
         key = ("up2", kind, H, W)
@@ -430,12 +448,10 @@ class MoGeEngine:
         ld = x.t.shape[1]
         big = self._new(4 * H * W, ld)
         ops.resize_taps(x.t, (1, W * ld, ld), C, ys, yw, xs, xw, 2 * H, 2 * W, big, (1, 2 * W * ld, ld))
-        a = self._new(4 * H * W, _up(C, 64), torch.bfloat16)
-        if _up(C, 64) > C:
-            a.zero_()
-        ops.cast_rows(big, a, rows=4 * H * W, cols=C if C % 4 == 0 else _up(C, 4))
-        out = _Act(self._new(4 * H * W, _up(Cn, 128)), Cn, 2 * H, 2 * W)
-        ops.conv3x3(a, 2 * H, 2 * W, _up(C, 64), self.w[p + ".1.weight"], self.w[p + ".1.bias"], out.t)
+        a = self._new(4 * H * W, _cpad(C), torch.bfloat16)
+        ops.cast_rows(big, a, rows=4 * H * W, cols=_cpad(C), in_cols=C if C % 4 == 0 else _up(C, 4))
+        out = _Act(self._new(4 * H * W, _npad(Cn)), Cn, 2 * H, 2 * W)
+        ops.conv3x3(a, 2 * H, 2 * W, _cpad(C), self.w[p + ".1.weight"], self.w[p + ".1.bias"], out.t)
         return out
 
     def _conv_stack(self, name: str, cfg: Dict, feats: List[Optional[_Act]], uv_levels: bool, base_h: int, base_w: int,
@@ -455,7 +471,7 @@ class MoGeEngine:
             H, W = base_h * 2 ** i, base_w * 2 ** i
             C = dims[i]
             if i == 0:
-                x = _Act(self._new(H * W, _up(C, 128)), C, H, W)
+                x = _Act(self._new(H * W, _npad(C)), C, H, W)
             f = feats[i]
             wk, bk = f"{name}.input_blocks.{i}.weight", f"{name}.input_blocks.{i}.bias"
             have_feat = False
@@ -482,7 +498,7 @@ class MoGeEngine:
             if not (all_outputs or i == n - 1):
                 outs.append(None)
             elif dim_out[i] is not None:
-                o = _Act(self._new(H * W, _up(dim_out[i], 128)), dim_out[i], H, W)
+                o = _Act(self._new(H * W, _npad(dim_out[i])), dim_out[i], H, W)
                 ops.gemm(self._to_bf16(x), self.w[f"{name}.output_blocks.{i}.weight"], o.t, M=H * W,
                          bias=self.w[f"{name}.output_blocks.{i}.bias"])
                 outs.append(o)
@@ -538,7 +554,7 @@ class MoGeEngine:
         n_int = cfg["encoder"]["intermediate_layers"]
         take = list(range(bb["depth"] - n_int, bb["depth"])) if isinstance(n_int, int) else list(n_int)
         Cenc = cfg["encoder"]["dim_out"]
-        feat = _Act(self._new(P, _up(Cenc, 128)), Cenc, bh, bw)
+        feat = _Act(self._new(P, _npad(Cenc)), Cenc, bh, bw)
         cls = self._new(1, D)
         k = 0
         for i in range(bb["depth"]):

@@ -116,13 +116,17 @@ def qknorm_rope(qkv: torch.Tensor, rows: int, H: int, T: int, pos: Optional[torc
     return qkv
 
 
-def cast_rows(x: torch.Tensor, out: torch.Tensor, rows: Optional[int] = None, cols: Optional[int] = None):
+def cast_rows(x: torch.Tensor, out: torch.Tensor, rows: Optional[int] = None, cols: Optional[int] = None,
+              in_cols: Optional[int] = None):
+    """out[r, :cols] = x[r, :cols]; with in_cols < cols only x[r, :in_cols] is read and out[r, in_cols:cols] = 0."""
     lib = _L.load()
     assert x.dtype == torch.float32 and x.stride(1) == 1 and out.stride(1) == 1
     rows = x.shape[0] if rows is None else rows
     cols = x.shape[1] if cols is None else cols
-    rc = lib.pi3_cast_rows(x.data_ptr(), x.stride(0), out.data_ptr(), out.stride(0), rows, cols, _dt(out),
-                           _L.stream_ptr())
+    in_cols = cols if in_cols is None else in_cols
+    assert in_cols <= x.shape[1] and cols <= out.shape[1]
+    rc = lib.pi3_cast_rows_pad(x.data_ptr(), x.stride(0), in_cols, out.data_ptr(), out.stride(0), rows, cols, _dt(out),
+                               _L.stream_ptr())
     _L.check(rc, "pi3_cast_rows")
     return out
 
@@ -330,9 +334,10 @@ def focal_shift(local_points: torch.Tensor, conf: Optional[torch.Tensor], uvx: t
 # ----------------------------------------------------------------------------------------------- MoGe conv pyramid
 def conv3x3(img: torch.Tensor, H: int, W: int, C: int, wgt: torch.Tensor, bias: Optional[torch.Tensor],
             out: torch.Tensor, resid: Optional[torch.Tensor] = None, act: int = ACT_NONE) -> torch.Tensor:
-    """img bf16 NHWC [H*W, ldc] (one image), wgt bf16 [N, 9*C]; out [H*W, >=N] f32/bf16."""
+    """img bf16 NHWC [H*W, ldc] (one image), wgt bf16 [N, 9*C] (C % 64 == 0) or [N, 10*32] (C == 32: ten tap slots, the
+    tenth zero); out [H*W, >=N] f32/bf16."""
     lib = _L.load()
-    assert img.dtype == torch.bfloat16 and wgt.dtype == torch.bfloat16 and wgt.shape[1] == 9 * C
+    assert img.dtype == torch.bfloat16 and wgt.dtype == torch.bfloat16 and wgt.shape[1] == (320 if C == 32 else 9 * C)
     rc = lib.pi3_conv3x3(img.data_ptr(), img.stride(0), 1, H, W, C, wgt.data_ptr(), wgt.shape[0], _L.ptr(bias),
                          _L.ptr(resid), resid.stride(0) if resid is not None else 0, out.data_ptr(), out.stride(0),
                          _dt(out), act, _L.stream_ptr())

@@ -173,3 +173,132 @@ def test_moge_rejects_configs_outside_the_reference():
         cfg["neck"][key] = val
         with pytest.raises(NotImplementedError):
             moge_param_shapes(cfg)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# kernel-level checks of what the conv pyramid runs on (csrc/gemm.hip: gemm_narrow_kernel, pi3_conv3x3; csrc/moge.hip:
+# groupnorm_apply; csrc/elem.hip: cast_rows with K padding) against the op written out in fp32 with torch
+# ---------------------------------------------------------------------------------------------------------------
+def _conv_weight_rows(w4, Cpad_in):
+    """[Co, Ci, 3, 3] fp32 -> the bf16 row layout MoGeEngine._install gives pi3_conv3x3."""
+    Co, Ci = w4.shape[:2]
+    Np = (Co + 31) // 32 * 32
+    if Cpad_in == 32:
+        w = torch.zeros(Np, 10, 32)
+        w[:Co, :9, :Ci] = w4.permute(0, 2, 3, 1).reshape(Co, 9, Ci)
+    else:
+        w = torch.zeros(Np, 3, 3, Cpad_in)
+        w[:Co, :, :, :Ci] = w4.permute(0, 2, 3, 1)
+    return w.reshape(Np, -1).to(torch.bfloat16).contiguous()
+
+
+@pytest.mark.parametrize("H,W,Ci,Co,fp32_out,resid", [
+    (19, 23, 32, 32, True, False),      # two taps per K-step, 32-column tile
+    (19, 23, 32, 64, True, True),       # ... 64-column tile, residual
+    (16, 40, 20, 3, True, False),       # ragged channel counts inside the 32 / 32 padding
+    (19, 23, 64, 32, True, True),       # one tap per K-step, narrow N
+    (9, 31, 128, 96, False, False),     # two channel blocks per tap, N = 96, bf16 out
+    (33, 17, 64, 128, True, False),     # the 128-column kernel, for comparison
+    (300, 5, 32, 32, True, False),      # more than one 256-row tile, very narrow image (every pixel near a border)
+])
+def test_conv3x3_narrow_and_wide_against_torch(built_lib, H, W, Ci, Co, fp32_out, resid):
+    """3x3, stride 1, replicate padding (moge/model/modules.py:47-60) on bf16-rounded operands, fp32 accumulation."""
+    from pi3_slam_amd import ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(H * 1000 + W * 10 + Ci + Co)
+    Cp = 32 if Ci <= 32 else (Ci + 63) // 64 * 64
+    Np = (Co + 31) // 32 * 32
+    x = torch.randn(H, W, Ci, generator=g)
+    w4 = torch.randn(Co, Ci, 3, 3, generator=g) / (3.0 * Ci ** 0.5)
+    bias = torch.randn(Co, generator=g)
+    img = torch.zeros(H * W, Cp)
+    img[:, :Ci] = x.reshape(H * W, Ci)
+    img_bf = img.to(torch.bfloat16)
+    rows = _conv_weight_rows(w4, Cp)
+    b = torch.zeros(Np)
+    b[:Co] = bias
+    out = torch.full((H * W, Np), float("nan"), dtype=torch.float32 if fp32_out else torch.bfloat16, device=dev)
+    r = torch.randn(H * W, Np, generator=g) if resid else None
+    if resid:
+        r[:, Co:] = 0
+    ops.conv3x3(img_bf.to(dev), H, W, Cp, rows.to(dev), b.to(dev), out, resid=r.to(dev) if resid else None)
+    xr = img_bf.float()[:, :Ci].reshape(1, H, W, Ci).permute(0, 3, 1, 2)
+    wr = w4.to(torch.bfloat16).float()
+    want = torch.nn.functional.conv2d(torch.nn.functional.pad(xr.double(), (1, 1, 1, 1), mode="replicate"), wr.double(),
+                                      bias.double())[0].permute(1, 2, 0).reshape(H * W, Co)
+    if resid:
+        want = want + r[:, :Co].double()
+    got = out.float().cpu()
+    tol = 2e-5 if fp32_out else 2e-2
+    assert torch.allclose(got[:, :Co].double(), want, atol=tol * max(1.0, float(want.abs().max())), rtol=0), \
+        float((got[:, :Co].double() - want).abs().max())
+    assert torch.equal(got[:, Co:], torch.zeros(H * W, Np - Co))       # padded columns: exact zeros, as the maps rely on
+
+
+@pytest.mark.parametrize("M,N,K,out_bf16,act,resid", [(700, 32, 64, False, 0, True), (700, 64, 128, False, 2, False),
+                                                       (513, 96, 64, True, 0, False), (257, 160, 192, True, 1, False),
+                                                       (1, 32, 64, False, 0, False)])
+def test_narrow_gemm_against_torch(built_lib, M, N, K, out_bf16, act, resid):
+    from pi3_slam_amd import ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(M + N + K)
+    a = torch.randn(M, K, generator=g).to(torch.bfloat16)
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(torch.bfloat16)
+    bias = torch.randn(N, generator=g)
+    r = torch.randn(M, N, generator=g) if resid else None
+    out = torch.empty(M, N, dtype=torch.bfloat16 if out_bf16 else torch.float32, device=dev)
+    ops.gemm(a.to(dev), w.to(dev), out, bias=bias.to(dev), resid=r.to(dev) if resid else None, act=act)
+    want = a.double() @ w.double().t() + bias.double()
+    if act == 1:
+        want = torch.nn.functional.gelu(want)
+    elif act == 2:
+        want = want.clamp_min(0)
+    if resid:
+        want = want + r.double()
+    tol = 2e-2 if out_bf16 else 2e-5
+    err = float((out.float().cpu().double() - want).abs().max())
+    assert err <= tol * max(1.0, float(want.abs().max())), err
+
+
+@pytest.mark.parametrize("C,Cpad,G,affine,act,ld", [(32, 32, 1, True, 2, 32), (32, 64, 1, True, 4, 32), (64, 64, 2, True, 3, 64),
+                                                     (384, 384, 12, True, 2, 384), (20, 32, 20, False, 5, 32),
+                                                     (6, 32, 0, False, 2, 8), (96, 128, 3, True, 2, 96)])
+def test_groupnorm_apply_against_torch(built_lib, C, Cpad, G, affine, act, ld):
+    """nn.GroupNorm(G, C) (G = C: InstanceNorm2d without affine; G = 0: no norm) + activation -> bf16 NHWC staging
+    image with zeroed pad channels."""
+    from pi3_slam_amd import ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(C * 7 + G)
+    HW = 1531
+    x = torch.randn(HW, ld, generator=g) * 2 + 0.5
+    gamma, beta = torch.randn(C, generator=g), torch.randn(C, generator=g)
+    out = torch.full((HW, Cpad), float("nan"), dtype=torch.bfloat16, device=dev)
+    xd = x.to(dev)
+    stats = None
+    if G > 0:
+        stats = torch.empty(2 * G, device=dev, dtype=torch.float64)
+        ops.groupnorm_stats(xd, HW, C, G, stats)
+    ops.groupnorm_apply(xd, HW, C, Cpad, G, stats, gamma.to(dev) if affine else None, beta.to(dev) if affine else None,
+                        1e-5, act, out)
+    v = x[:, :C].double().t().reshape(1, C, HW)
+    if G > 0:
+        v = torch.nn.functional.group_norm(v, G, gamma.double() if affine else None, beta.double() if affine else None, 1e-5)
+    fn = {2: torch.relu, 3: lambda t: torch.nn.functional.leaky_relu(t, 0.2), 4: torch.nn.functional.silu,
+          5: torch.nn.functional.elu}[act]
+    want = fn(v)[0].t()
+    got = out.float().cpu()
+    assert torch.allclose(got[:, :C].double(), want, atol=1e-2 * max(1.0, float(want.abs().max())), rtol=0)
+    assert torch.equal(got[:, C:], torch.zeros(HW, Cpad - C))
+
+
+def test_cast_rows_with_k_padding(built_lib):
+    from pi3_slam_amd import ops
+    dev = torch.device("cuda:0")
+    x = torch.randn(1000, 32, device=dev)
+    out = torch.full((1000, 64), float("nan"), dtype=torch.bfloat16, device=dev)
+    ops.cast_rows(x, out, cols=64, in_cols=32)
+    assert torch.equal(out[:, :32], x.to(torch.bfloat16)) and torch.equal(out[:, 32:].float(), torch.zeros(1000, 32, device=dev))
+    x = torch.randn(777, 96, device=dev)
+    o2 = torch.empty(777, 200, device=dev)
+    ops.cast_rows(x, o2[:, 100:], cols=96)
+    assert torch.equal(o2[:, 100:196], x)

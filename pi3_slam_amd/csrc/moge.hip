@@ -22,17 +22,23 @@
 // NJ = channels per lane (C <= 64 NJ): compile-time so that the pixel loop carries no per-channel branches and four
 // pixels' loads are in flight per lane (the first version walked one pixel at a time under 16 predicated channel slots
 // and was latency-bound: 185 us for 30 MB)
-template <int NJ>
+// HALF (NJ == 1, C <= 32: the 32-channel maps of the finest levels, ~900 k pixels): a wave's row load covers TWO pixels
+// (lanes 0-31 an even one, lanes 32-63 the odd one after it) instead of leaving half of its lanes on a clamped
+// duplicate; the two halves are added at the end (even + odd, a fixed order).
+template <int NJ, bool HALF = false>
 __global__ __launch_bounds__(256) void groupnorm_stats_kernel(const float* __restrict__ x, long ldx, int HW, int C,
                                                               double* __restrict__ ws) {
+  static_assert(!HALF || NJ == 1, "HALF is the one-channel-per-lane form");
   __shared__ double part[3][2][64 * NJ];   // waves 1..3 hand their per-channel sums to wave 0
   const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  constexpr int PP = HALF ? 2 : 1;         // pixels per row load
+  const int sub = HALF ? lane >> 5 : 0;
   double s[NJ], q[NJ];
   int ch[NJ];       // clamped channel: loads stay in bounds, lanes past C are dropped at the end
 #pragma unroll
   for (int j = 0; j < NJ; ++j) {
     s[j] = 0.0; q[j] = 0.0;
-    const int c = lane + 64 * j;
+    const int c = (HALF ? lane & 31 : lane) + 64 * j;
     ch[j] = c < C ? c : C - 1;
   }
   const int per_block = (HW + gridDim.x - 1) / gridDim.x;
@@ -43,17 +49,17 @@ __global__ __launch_bounds__(256) void groupnorm_stats_kernel(const float* __res
 #pragma unroll
     for (int j = 0; j < NJ; ++j) { fs[j] = 0.f; fq[j] = 0.f; }
     const int pe = min(p1, pc + 64);
-    for (int p = pc; p < pe; p += 4) {
+    for (int p = pc; p < pe; p += 4 * PP) {
       float v[4][NJ];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        const float* row = xb + (long)min(p + u, pe - 1) * ldx;
+        const float* row = xb + (long)min(p + PP * u + sub, pe - 1) * ldx;
 #pragma unroll
         for (int j = 0; j < NJ; ++j) v[u][j] = row[ch[j]];
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        const bool live = p + u < pe;
+        const bool live = p + PP * u + sub < pe;
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
           const float t = live ? v[u][j] : 0.f;   // pixel by pixel, fp32 in the chunk
@@ -64,6 +70,10 @@ __global__ __launch_bounds__(256) void groupnorm_stats_kernel(const float* __res
     }
 #pragma unroll
     for (int j = 0; j < NJ; ++j) { s[j] += (double)fs[j]; q[j] += (double)fq[j]; }
+  }
+  if constexpr (HALF) {                    // even-pixel half + odd-pixel half
+    s[0] += __shfl_down(s[0], 32, 64);
+    q[0] += __shfl_down(q[0], 32, 64);
   }
   if (wave > 0) {
 #pragma unroll
@@ -78,7 +88,7 @@ __global__ __launch_bounds__(256) void groupnorm_stats_kernel(const float* __res
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
       const int c = lane + 64 * j;
-      if (c < C) {
+      if (c < C && (!HALF || lane < 32)) {
         double ss = s[j], qq = q[j];
 #pragma unroll
         for (int w = 0; w < 3; ++w) { ss += part[w][0][c]; qq += part[w][1][c]; }   // wave order 0, 1, 2, 3
@@ -89,19 +99,36 @@ __global__ __launch_bounds__(256) void groupnorm_stats_kernel(const float* __res
   }
 }
 
-__global__ __launch_bounds__(256) void groupnorm_finalize_kernel(const double* __restrict__ ws, int nblk, int C, int G,
-                                                                 double* __restrict__ stats) {
+// One workgroup of 1024 threads per sample.  Column c of [sum | sumsq][channel] is summed over the blocks by P = 1024 /
+// columns-per-pass threads (thread part p takes blocks p, p + P, ... in order), the P partial sums are then added in
+// part order: a fixed order again, P times shorter than the first version's single chain over up to 512 blocks (100 us
+// of one wave's latency per group norm at the finest level).
+__global__ __launch_bounds__(1024) void groupnorm_finalize_kernel(const double* __restrict__ ws, int nblk, int C, int G,
+                                                                  double* __restrict__ stats) {
   __shared__ double tot[2][64 * GN_MAXJ];
+  __shared__ double partial[1024];
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const double* w = ws + (long)b * nblk * 2 * C;
-  for (int c = tid; c < 2 * C; c += 256) {          // index c runs over [sum | sumsq][channel]: coalesced across lanes
+  const int ncol = 2 * C;
+  int cp = 1;                                     // columns per pass: the largest power of two <= min(ncol, 1024)
+  while (cp * 2 <= ncol && cp * 2 <= 1024) cp *= 2;
+  const int P = 1024 / cp;
+  for (int c0 = 0; c0 < ncol; c0 += cp) {
+    const int c = c0 + (tid & (cp - 1)), part = tid / cp;
     double a = 0.0;
-    for (int k = 0; k < nblk; ++k) a += w[(long)k * 2 * C + c];   // block order
-    tot[c >= C][c >= C ? c - C : c] = a;
+    if (c < ncol)
+      for (int k = part; k < nblk; k += P) a += w[(long)k * 2 * C + c];
+    partial[tid] = a;
+    __syncthreads();
+    if (tid < cp && c < ncol) {
+      double t = 0.0;
+      for (int pp = 0; pp < P; ++pp) t += partial[pp * cp + tid];
+      tot[c >= C][c >= C ? c - C : c] = t;
+    }
+    __syncthreads();
   }
-  __syncthreads();
   const int cpg = C / G;
-  for (int g = wave; g < G; g += 4) {
+  for (int g = wave; g < G; g += 16) {
     double ss = 0.0, qq = 0.0;
     for (int c = lane; c < cpg; c += 64) { ss += tot[0][g * cpg + c]; qq += tot[1][g * cpg + c]; }
     ss = wave_sum_f64(ss);
@@ -133,12 +160,13 @@ extern "C" int pi3_groupnorm_stats(const float* x, long ldx, int B, int HW, int 
   const int bx = gn_blocks(HW);
   const dim3 grid(bx, B), block(256);
   hipStream_t st = (hipStream_t)stream;
-  if (C <= 64) hipLaunchKernelGGL(groupnorm_stats_kernel<1>, grid, block, 0, st, x, ldx, HW, C, ws);
+  if (C <= 32) hipLaunchKernelGGL((groupnorm_stats_kernel<1, true>), grid, block, 0, st, x, ldx, HW, C, ws);
+  else if (C <= 64) hipLaunchKernelGGL(groupnorm_stats_kernel<1>, grid, block, 0, st, x, ldx, HW, C, ws);
   else if (C <= 128) hipLaunchKernelGGL(groupnorm_stats_kernel<2>, grid, block, 0, st, x, ldx, HW, C, ws);
   else if (C <= 256) hipLaunchKernelGGL(groupnorm_stats_kernel<4>, grid, block, 0, st, x, ldx, HW, C, ws);
   else if (C <= 512) hipLaunchKernelGGL(groupnorm_stats_kernel<8>, grid, block, 0, st, x, ldx, HW, C, ws);
   else hipLaunchKernelGGL(groupnorm_stats_kernel<16>, grid, block, 0, st, x, ldx, HW, C, ws);
-  hipLaunchKernelGGL(groupnorm_finalize_kernel, dim3(B), dim3(256), 0, st, ws, bx, C, G, stats);
+  hipLaunchKernelGGL(groupnorm_finalize_kernel, dim3(B), dim3(1024), 0, st, ws, bx, C, G, stats);
   return pi3_check_launch("groupnorm_stats");
 }
 
@@ -272,68 +300,119 @@ extern "C" int pi3_groupnorm_apply(const float* x, long ldx, int B, int HW, int 
 
 // ConvTranspose2d(k=2, s=2) second half (modules.py:160-163): the GEMM produced g[pixel][(dy*2+dx)*Cs + co] (f32, bias
 // included); scatter to the 2x up-sampled bf16 NHWC staging image out[b][2y+dy][2x+dx][co], pad channels = 0.
-__global__ __launch_bounds__(256) void convt_scatter_kernel(const float* __restrict__ g, long ldg, int B, int H, int W,
+// One workgroup per output row, four channels per thread (16-byte load, 8-byte store), 32-bit index arithmetic (the first
+// version: one element pair per thread behind five 64-bit divisions).
+__global__ __launch_bounds__(256) void convt_scatter_kernel(const float* __restrict__ g, long ldg, int H, int W,
                                                             int Cout, int Cs, int Cpad, bf16_t* __restrict__ out,
-                                                            long ldo, long total) {
-  const int cv = Cpad >> 1;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-    const int c = (int)(i % cv) * 2;
-    const long op = i / cv;  // output pixel index over [B][2H][2W]
-    const int ox = (int)(op % (2 * W));
-    const long r = op / (2 * W);
-    const int oy = (int)(r % (2 * H));
-    const int b = (int)(r / (2 * H));
-    const long ip = ((long)b * H + (oy >> 1)) * W + (ox >> 1);
-    const int q = (oy & 1) * 2 + (ox & 1);
-    const float a = c < Cout ? g[ip * ldg + (long)q * Cs + c] : 0.f;
-    const float bb = (c + 1) < Cout ? g[ip * ldg + (long)q * Cs + c + 1] : 0.f;
-    *(uint32_t*)(out + op * ldo + c) = pack_bf16x2(a, bb);
+                                                            long ldo) {
+  const int orow = blockIdx.x;                 // over [B][2H]
+  const int oy = orow % (2 * H), b = orow / (2 * H);
+  const int q = Cpad >> 2, n = 2 * W * q;
+  const float* grow = g + ((long)b * H + (oy >> 1)) * W * ldg + (long)(oy & 1) * 2 * Cs;
+  bf16_t* orowp = out + (long)orow * 2 * W * ldo;
+  const bool vec = (ldg & 3) == 0 && (Cs & 3) == 0 && ((uintptr_t)g & 15) == 0;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const int ox = i / q, c = (i - ox * q) * 4;
+    const float* src = grow + (long)(ox >> 1) * ldg + (ox & 1) * Cs + c;
+    float v[4];
+    if (vec && c + 3 < Cout) {
+      const f32x4 t = *(const f32x4*)src;
+      v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = c + e < Cout ? src[e] : 0.f;
+    }
+    u32x2 o;
+    o[0] = pack_bf16x2(v[0], v[1]);
+    o[1] = pack_bf16x2(v[2], v[3]);
+    *(u32x2*)(orowp + (long)ox * ldo + c) = o;
   }
 }
 
 extern "C" int pi3_convt_scatter(const float* g, long ldg, int B, int H, int W, int Cout, int Cs, int Cpad, void* out,
                                  long ldo, void* stream) {
-  if (!g || !out || B <= 0 || H <= 0 || W <= 0 || Cout <= 0 || Cs < Cout || Cpad < Cout || (Cpad % 2) || (ldo % 2)) {
-    pi3_set_error("pi3_convt_scatter: bad arguments");
+  if (!g || !out || B <= 0 || H <= 0 || W <= 0 || Cout <= 0 || Cs < Cout || Cpad < Cout || (Cpad % 4) || (ldo % 4) ||
+      ((uintptr_t)out & 7) || (long)B * 2 * H > 0x7fffffffL || (long)2 * W * (Cpad / 4) > 0x7fffffffL) {
+    pi3_set_error("pi3_convt_scatter: bad arguments (Cpad, ldo multiples of 4)");
     return PI3_ERR_ARG;
   }
-  const long total = (long)B * 4 * H * W * (Cpad / 2);
-  long blocks = (total + 255) / 256;
-  if (blocks > 256 * 32) blocks = 256 * 32;
-  hipLaunchKernelGGL(convt_scatter_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g, ldg, B, H, W,
-                     Cout, Cs, Cpad, (bf16_t*)out, ldo, total);
+  hipLaunchKernelGGL(convt_scatter_kernel, dim3((unsigned)(B * 2 * H)), dim3(256), 0, (hipStream_t)stream, g, ldg, H, W,
+                     Cout, Cs, Cpad, (bf16_t*)out, ldo);
   return pi3_check_launch("convt_scatter");
 }
 
 // 1x1 convolution of the 2-channel UV map (v2.py:141-147 concat + modules.py:214 input block), fused:
 // x[b][y][x][c] (+)= w[c][wofs] * u[x] + w[c][wofs+1] * v[y] + bias[c];  w row stride ldw.  accumulate != 0 adds.
+// blockIdx.x = image row (v[y] is then a workgroup constant), blockIdx.y = a segment of 1024 float4 of the row: four
+// independent float4 per thread (the loads of an accumulate pass in flight together), 32-bit index arithmetic, the
+// thread's four channels and their weights fixed across its iterations whenever C / 4 divides 256.
+#define UV_SEG 1024
 __global__ __launch_bounds__(256) void uv_affine_kernel(float* __restrict__ x, long ldx, int H, int W, int C,
                                                         const float* __restrict__ w, long ldw, int wofs,
                                                         const float* __restrict__ bias, const float* __restrict__ uvx,
-                                                        const float* __restrict__ uvy, int accumulate, long total) {
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-    const int c = (int)(i % C);
-    const long p = i / C;
-    const int px = (int)(p % W);
-    const int py = (int)((p / W) % H);
-    float v = w[(long)c * ldw + wofs] * uvx[px] + w[(long)c * ldw + wofs + 1] * uvy[py];
+                                                        const float* __restrict__ uvy, int accumulate, int vec) {
+  const int row = blockIdx.x;                  // over [B][H]
+  const float vy = uvy[row % H];
+  float* xr = x + (long)row * W * ldx;
+  if (vec) {
+    const int q = C >> 2, n4 = W * q;
+    const int i0 = blockIdx.y * UV_SEG + threadIdx.x, i1 = min(n4, (int)(blockIdx.y + 1) * UV_SEG);
+    const bool fixed = (256 % q) == 0;
+    f32x4 wa, wb, bs;
+    auto load_w = [&](int c) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        wa[e] = w[(long)(c + e) * ldw + wofs];
+        wb[e] = w[(long)(c + e) * ldw + wofs + 1];
+        bs[e] = bias ? bias[c + e] : 0.f;
+      }
+    };
+    if (fixed) load_w((i0 % q) * 4);
+#pragma unroll
+    for (int k = 0; k < UV_SEG / 256; ++k) {
+      const int i = i0 + k * 256;
+      if (i < i1) {
+        const int px = i / q, c = (i - px * q) * 4;
+        if (!fixed) load_w(c);
+        const float ux = uvx[px];
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v[e] = wa[e] * ux + wb[e] * vy;
+          if (bias) v[e] += bs[e];
+        }
+        f32x4* dst = (f32x4*)(xr + (long)px * ldx + c);
+        if (accumulate) {
+          const f32x4 o = *dst;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = o[e] + v[e];
+        }
+        *dst = v;
+      }
+    }
+    return;
+  }
+  const int n = W * C;
+  for (int i = blockIdx.y * (4 * UV_SEG) + threadIdx.x; i < min(n, (int)(blockIdx.y + 1) * 4 * UV_SEG); i += 256) {
+    const int px = i / C, c = i - px * C;
+    float v = w[(long)c * ldw + wofs] * uvx[px] + w[(long)c * ldw + wofs + 1] * vy;
     if (bias) v += bias[c];
-    float* dst = x + p * ldx + c;
+    float* dst = xr + (long)px * ldx + c;
     *dst = accumulate ? (*dst + v) : v;
   }
 }
 
 extern "C" int pi3_uv_affine(float* x, long ldx, int B, int H, int W, int C, const float* w, long ldw, int wofs,
                              const float* bias, const float* uvx, const float* uvy, int accumulate, void* stream) {
-  if (!x || !w || !uvx || !uvy || B <= 0 || H <= 0 || W <= 0 || C <= 0) {
+  if (!x || !w || !uvx || !uvy || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (long)B * H > 0x7fffffffL ||
+      (long)W * C > 0x3fffffffL) {
     pi3_set_error("pi3_uv_affine: bad arguments");
     return PI3_ERR_ARG;
   }
-  const long total = (long)B * H * W * C;
-  long blocks = (total + 255) / 256;
-  if (blocks > 256 * 32) blocks = 256 * 32;
-  hipLaunchKernelGGL(uv_affine_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, ldx, H, W, C, w,
-                     ldw, wofs, bias, uvx, uvy, accumulate, total);
+  const int vec = (C % 4) == 0 && (ldx % 4) == 0 && ((uintptr_t)x & 15) == 0;
+  const int segs = (W * C + 4 * UV_SEG - 1) / (4 * UV_SEG);     // 4 UV_SEG floats per segment in either form
+  hipLaunchKernelGGL(uv_affine_kernel, dim3((unsigned)(B * H), (unsigned)segs), dim3(256), 0, (hipStream_t)stream, x, ldx, H,
+                     W, C, w, ldw, wofs, bias, uvx, uvy, accumulate, vec);
   return pi3_check_launch("uv_affine");
 }
 

@@ -37,7 +37,8 @@ int pi3_device_count(void);
  *   out[orow(m)][n] = resid[orow(m)][n] + gamma[n] * act((A[m] . W[n] + bias[n]) * (n < qcols ? qscale : 1))
  *                     + addtab[m % rpg][n]
  *   orow(m) = rpg ? (m / rpg) * gstride + goff + m % rpg : m.   bias/gamma/resid/addtab may be NULL.
- * A [M][K] and W [N][K] share in_dtype (0: bf16 MFMA, 1: exact-fp32 MFMA); N % 128 == 0; K % 64 (bf16) / 32 (f32).
+ * A [M][K] and W [N][K] share in_dtype (0: bf16 MFMA, 1: exact-fp32 MFMA); N % 128 == 0, or with bf16 operands any
+ * N % 32 == 0 (32 / 64-column tiles: the narrow maps of the MoGe pyramid); K % 64 (bf16) / 32 (f32).
  * act: 0 none, 1 GELU(erf), 2 ReLU. */
 int pi3_gemm(const void* A, long lda, const void* W, long ldw, int M, int N, int K, int in_dtype, const float* bias,
              const float* gamma, const float* resid, long ldr, void* out, long ldo, int out_dtype, int act, int rpg,
@@ -153,8 +154,10 @@ int pi3_focal_shift(const float* local_points, const float* conf, const unsigned
 
 /* ---- MoGe-2 metric-scale forward (moge/model/v2.py:128-290, moge/model/modules.py:18-254) ------------------------ */
 
-/* nn.Conv2d(C, N, 3, padding=1, padding_mode='replicate') as an implicit GEMM on a bf16 NHWC image [B][H][W][ldc]
- * (C % 64 == 0); wgt bf16 [N][9*C] with k = (ky*3+kx)*C + ci; out rows = pixels; epilogue bias / resid / act. */
+/* nn.Conv2d(C, N, 3, padding=1, padding_mode='replicate') as an implicit GEMM on a bf16 NHWC image [B][H][W][ldc];
+ * out rows = pixels; epilogue bias / resid / act; N % 32 == 0.
+ *   C % 64 == 0: wgt bf16 [N][9*C], k = (ky*3+kx)*C + ci;
+ *   C == 32:     wgt bf16 [N][10*32], k = tap*32 + ci with a tenth, all-zero tap (two taps per 64-wide K-step). */
 int pi3_conv3x3(const void* img, long ldc, int B, int H, int W, int C, const void* wgt, int N, const float* bias,
                 const float* resid, long ldr, void* out, long ldo, int out_dtype, int act, void* stream);
 
@@ -166,7 +169,7 @@ int pi3_groupnorm_stats(const float* x, long ldx, int B, int HW, int C, int G, d
                         long ws_doubles, void* stream);
 
 /* Norm + activation in front of a ResidualConvBlock convolution (moge/model/modules.py:47-58) -> bf16 NHWC staging
- * image [B][HW][ldo], channels [C, Cpad) zeroed.  G groups (GroupNorm(C/32), 'layer_norm' = 1 group, InstanceNorm2d =
+ * image [B][HW][ldo], channels [C, Cpad) zeroed (Cpad % 4 == 0, ldo % 4 == 0).  G groups (GroupNorm(C/32), 'layer_norm' = 1 group, InstanceNorm2d =
  * C groups with gamma = beta = NULL); G = 0: no normalisation ('none').  act: 0 none, 2 ReLU, 3 LeakyReLU(0.2),
  * 4 SiLU, 5 ELU. */
 int pi3_groupnorm_apply(const float* x, long ldx, int B, int HW, int C, int Cpad, int G, const double* stats,
@@ -175,7 +178,8 @@ int pi3_groupnorm_apply(const float* x, long ldx, int B, int HW, int C, int Cpad
 /* x[r][0..C) += y[r][0..C) on fp32 maps: ConvStack with an identity input block (modules.py:245-249). */
 int pi3_add_rows(float* x, long ldx, const float* y, long ldy, long rows, int C, void* stream);
 
-/* ConvTranspose2d(k=2, s=2) scatter: g f32 [B*H*W][(dy*2+dx)*Cs + co] -> bf16 NHWC [B][2H][2W][ldo]. */
+/* ConvTranspose2d(k=2, s=2) scatter: g f32 [B*H*W][(dy*2+dx)*Cs + co] -> bf16 NHWC [B][2H][2W][ldo], channels
+ * [Cout, Cpad) zeroed (Cpad % 4 == 0, ldo % 4 == 0). */
 int pi3_convt_scatter(const float* g, long ldg, int B, int H, int W, int Cout, int Cs, int Cpad, void* out, long ldo,
                       void* stream);
 

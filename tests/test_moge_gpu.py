@@ -70,7 +70,10 @@ def _gate_end_to_end(eng, name):
     focal_ref, shift_ref = g["focal_shift"]
     focal, shift = out["focal"].item(), out["shift"].item()
     assert focal > 0.5 and focal_ref > 0.5
-    tol_f = 2.0 * abs(g["bf16_focal_shift"][0] - focal_ref) + 1e-3 * abs(focal_ref)
+    # floor: twice the MEDIAN of the reference's own bf16-vs-fp32 focal deviation over the seven fixtures that store it
+    # (5.7e-5 ... 5.7e-3 relative, median 9.5e-4; moge_vitb_reg drew the 5.7e-5): a single fixture's deviation is one
+    # sample of that spread, and a change of fp32 rounding order in one kernel moves the focal by as much
+    tol_f = 2.0 * abs(g["bf16_focal_shift"][0] - focal_ref) + 2e-3 * abs(focal_ref)
     tol_s = 2.0 * abs(g["bf16_focal_shift"][1] - shift_ref) + 1e-3
     assert abs(focal - focal_ref) <= tol_f, (focal, focal_ref, tol_f)
     assert abs(shift - shift_ref) <= tol_s, (shift, shift_ref, tol_s)

@@ -9,7 +9,8 @@ on the device's own inputs; (e) END TO END, on the pinhole-consistent fixtures (
 focal ~0.9 > 0, shift well conditioned - the regime a trained model runs in): `depth`, the only key the pipeline
 reads (offline_chunk_creator.py:184), within 2x the reference's own bf16-autocast-vs-fp32 deviation of depth (median,
 mean and 99th percentile of the relative error, stored with the vectors), focal and shift within 2x the reference's own
-bf16 deviation of them.  The purely random-weight fixtures (moge_small / moge_chunk) produce a map no camera could have
+bf16 deviation of them plus a floor (focal: 2e-3 relative = twice the median of that deviation over the fixtures; shift:
+1e-3).  The purely random-weight fixtures (moge_small / moge_chunk) produce a map no camera could have
 produced (their focal solves negative); they keep gating the network output, the mask and the depth algebra, not the
 ill-posed solve.
 """

@@ -8,17 +8,31 @@
 // output = 8 x 4 MFMA 16x16x32 tiles = 128 accumulator registers.  LDS = 2 K-tile buffers x {act half 0, act half 1,
 // W half 0, W half 1} x 16 KiB = 128 KiB; a wave reads exactly one act half (wm) and one W half (wn >> 1) per K tile.
 //
-// Per K tile u (buffer u & 1) four phases, each: fragment ds_reads -> one half-tile LDS-DMA prefetch (2 x
-// global_load_lds_dwordx4 per thread) -> s_waitcnt lgkmcnt(0) -> 16 MFMAs (one 64 x 32 quadrant, K = 64) -> s_barrier:
+// Per K tile u (buffer u & 1), the shipped form (G2_TWO_PHASE == 1, round 3) has two phases, each: fragment ds_reads ->
+// two half-tile LDS-DMA prefetches (4 x global_load_lds_dwordx4 per thread) -> s_waitcnt -> [s_barrier] -> 32 MFMAs (a
+// 64 x 64 half of the wave's block, K = 64) -> s_barrier:
+//   phase ab: read W(nh0)[4] + W(nh1)[4] + act(mh0)[8]   prefetch act halves 0, 1 of tile u+1   MFMA (mh0, nh0), (mh0, nh1)
+//   phase cd: read act(mh1)[8]   prefetch W halves 0, 1 of tile u+2, then s_waitcnt vmcnt(4)    MFMA (mh1, nh1), (mh1, nh0)
+// Hazards: a buffer region is re-staged only after the barrier that follows its last fragment read (W halves and act
+// half 0 after phase ab, act half 1 after phase cd); staged data is read in the phase AFTER the counted wait + barrier
+// that retires it (cd's vmcnt(4) leaves only the two newest half-tiles, W(u+2), in flight: tile u+1 is complete).  The
+// second wave of every SIMD runs one barrier behind the first (STAG, below); since a region is now re-staged ONE phase
+// after its last read, a wave's fragment reads must have RETURNED (s_waitcnt lgkmcnt(0)) and its counted vmcnt wait
+// must have been executed before the mid barrier of the phase, not merely issued before it.
+// The round-2 form (G2_TWO_PHASE == 0) splits each of these in two (16 MFMAs and one half-tile prefetch per phase):
 //   phase a: read W(nh0)[4] + act(mh0)[8]   MFMA (mh0, nh0)   prefetch act half 0 of tile u+1
 //   phase b: read W(nh1)[4]                 MFMA (mh0, nh1)   prefetch act half 1 of tile u+1
 //   phase c: read act(mh1)[8]               MFMA (mh1, nh1)   prefetch W half 0 of tile u+2   (W of this buffer is dead)
 //   phase d: (all fragments in registers)   MFMA (mh1, nh0)   prefetch W half 1 of tile u+2, then s_waitcnt vmcnt(4)
-// Hazards: a buffer region is re-staged only after the barrier that follows its last fragment read (W halves after
-// phase b, act halves after phase c); staged data is read in the phase AFTER the counted wait + barrier that retires
-// it (phase d's vmcnt(4) leaves only the two newest half-tiles, W(u+2), in flight: tile u+1 is complete).
 #include "gemm_common.h"
 #include <stdlib.h>
+// K-loop form (compile-time, -DG2_TWO_PHASE=n; measured on M = 64 300, three interleaved rounds, qkv / proj / fc1 / fc2 ms):
+//   0  four phases per K tile (16 MFMAs per phase, the round-2 form)          0.440 / 0.224 / 0.630 / 0.520 = 1.814
+//   1  two phases per K tile (32 MFMAs per phase, half the barriers): DEFAULT  0.421 / 0.217 / 0.613 / 0.498 = 1.749
+//   2  two phases, every operand staged three phases ahead                     0.424 / 0.227 / 0.606 / 0.527 = 1.784
+#ifndef G2_TWO_PHASE
+#define G2_TWO_PHASE 1
+#endif
 
 #define G2_BM 256
 #define G2_BN 256
@@ -375,6 +389,23 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
 #define STAGE_W(U, HALF) g2_stage_half(Wb, ldw_b, bn * G2_BN + (HALF) * 128, p.N, (long)(U) * 128, \
                                        smem + ((U) & 1) * G2_BUF + (2 + (HALF)) * G2_HALF, wave, lane)
 
+#if G2_TWO_PHASE == 2
+  // prologue: tile 0 complete; W(1) and act(1) half 0 in flight (what cd(-1) would have staged)
+  STAGE_A(0, 0);
+  STAGE_A(0, 1);
+  STAGE_W(0, 0);
+  STAGE_W(0, 1);
+  if (nk > 1) {
+    STAGE_W(1, 0);
+    STAGE_W(1, 1);
+    STAGE_A(1, 0);
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+#else
   // prologue: tile 0 complete, W halves of tile 1 in flight
   STAGE_A(0, 0);
   STAGE_A(0, 1);
@@ -389,6 +420,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
   }
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
+#endif
 
   const int frow = lane & 15;
   const int swz = (lane >> 1) & 7;
@@ -429,6 +461,78 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
   if constexpr (STAG) {
     if (wm == 1) { PHASE_END() }
   }
+#if G2_TWO_PHASE == 2
+  // Two phases per K tile (round 3 experiment): 32 MFMAs per phase, half the barriers, every operand staged three phases
+  // before it is read:
+  //   phase ab(u): read W(u) both halves + act(u) half 0;  stage act(u+1) half 1;           MFMA (mh0, nh0), (mh0, nh1)
+  //   phase cd(u): read act(u) half 1;  stage W(u+2) both halves + act(u+2) half 0;          MFMA (mh1, nh1), (mh1, nh0)
+  // A region is re-staged one phase after its last read and a staged operand is read two phases after the counted wait
+  // that retires it; with the half-phase lag of waves 4-7 that needs the fragment reads returned (lgkmcnt(0)) and the
+  // counted wait executed BEFORE the phase's mid barrier.  Counted waits: loads retire in issue order, so "everything
+  // up to the previous phase of the same kind" = allow what was issued since (2 + 6 half-tile segments per thread).
+  for (int u = 0; u < nk; ++u) {
+    const char* bp = smem + (u & 1) * G2_BUF;
+    const bool pre1 = (u + 1 < nk), pre2 = (u + 2 < nk);
+    READ_W(bp, 0)
+    READ_W(bp, 1)
+    READ_A(bp, 0)
+    if (pre1) {
+      STAGE_A(u + 1, 1);
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");      // act(u) half 1 (staged in ab(u-1)) is there for cd(u)
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    PHASE_MID()
+    MFMA_Q(0, 0)
+    MFMA_Q(0, 1)
+    PHASE_END()
+    READ_A(bp, 1)
+    if (pre2) {
+      STAGE_W(u + 2, 0);
+      STAGE_W(u + 2, 1);
+      STAGE_A(u + 2, 0);
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");      // W(u+1), act(u+1) half 0 (staged in cd(u-1)) are there for ab(u+1)
+    } else if (pre1) {
+      asm volatile("s_waitcnt vmcnt(2)" ::: "memory");      // only act(u+1) half 1 may still be in flight
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    PHASE_MID()
+    MFMA_Q(1, 1)
+    MFMA_Q(1, 0)
+    PHASE_END()
+  }
+#elif G2_TWO_PHASE == 1
+  // (simple form: the four-phase staging schedule with phases a+b and c+d merged)
+  for (int u = 0; u < nk; ++u) {
+    const char* bp = smem + (u & 1) * G2_BUF;
+    const bool pre1 = (u + 1 < nk), pre2 = (u + 2 < nk);
+    READ_W(bp, 0)
+    READ_W(bp, 1)
+    READ_A(bp, 0)
+    if (pre1) { STAGE_A(u + 1, 0); STAGE_A(u + 1, 1); }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    PHASE_MID()
+    MFMA_Q(0, 0)
+    MFMA_Q(0, 1)
+    PHASE_END()
+    READ_A(bp, 1)
+    if (pre2) {
+      STAGE_W(u + 2, 0);
+      STAGE_W(u + 2, 1);
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    PHASE_MID()
+    MFMA_Q(1, 1)
+    MFMA_Q(1, 0)
+    PHASE_END()
+  }
+#else
   for (int u = 0; u < nk; ++u) {
     const char* bp = smem + (u & 1) * G2_BUF;
     const bool pre1 = (u + 1 < nk), pre2 = (u + 2 < nk);
@@ -462,6 +566,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
     MFMA_Q(1, 0)
     PHASE_END()
   }
+#endif
   if constexpr (STAG) {
     if (wm == 0) { PHASE_END() }   // barrier counts match again; nobody touches the epilogue LDS before everyone is out
   }

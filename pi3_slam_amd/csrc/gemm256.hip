@@ -58,7 +58,11 @@ __device__ __forceinline__ float g2_sum_rows4(float s) {
   return __uint_as_float(b[0]) + __uint_as_float(b[1]);
 }
 
-// stage one half-tile (128 rows x 128 B) of a row-major bf16 matrix: 16 segments of 1 KiB, 2 per wave
+// stage one half-tile (128 rows x 128 B) of a row-major bf16 matrix: 16 segments of 1 KiB, 2 per wave.
+// (Round 3 also tried the attention kernel's remedy here - the LDS-DMA issued from inline asm with a scalar base and a
+// 32-bit lane offset, so that hipcc's waitcnt pass cannot put s_waitcnt vmcnt(0) in front of fragment reads: the K loop
+// came out without any compiler-placed vmcnt wait and was NOT faster (block GEMMs 1.788 against 1.749 ms): this loop is
+// bound by LDS bandwidth, not by prefetch latency.)
 __device__ __forceinline__ void g2_stage_half(const char* gbase, long ld_bytes, int row0, int rows, long k_bytes,
                                               char* lds_half, int wave, int lane) {
 #pragma unroll

@@ -253,6 +253,10 @@ def main() -> None:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
+    if rank == 0 and os.environ.get("PI3_BENCH_STEPLOG"):      # per-step stage times on stderr (diagnostic)
+        for i, st in enumerate(stats):
+            print(f"[bench step {i}] " + " ".join(f"{k}={1e3 * st[k]:.2f}ms" for k in ("stage_in_s", "infer_s", "post_s", "align_host_s")
+                                                   if k in st), file=sys.stderr)
     if rank == 0:
         T = (H // 14) * (W // 14) + cfg.n_dec_reg
         S = CL * T

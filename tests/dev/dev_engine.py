@@ -4,7 +4,7 @@ import os
 import sys
 import time
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import torch
 
@@ -50,7 +50,7 @@ def full():
     eng = Pi3Engine(cfg, "cuda:0")
     torch.cuda.synchronize()
     print(f"engine init (recipe weights on device): {time.time() - t0:.1f}s")
-    gdir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+    gdir = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests", "golden")
     for name, (B, N, H, W) in CASES.items():
         g = np.load(os.path.join(gdir, name + ".npz"))
         imgs = golden_images(name, B, N, H, W)

@@ -1,6 +1,6 @@
 """Developer check of the MoGe engine on a GPU box against the golden vectors + stage-by-stage vs the CPU oracle."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from oracle import moge_ref
 from oracle.gen_golden_moge import CASES, moge_image

@@ -27,7 +27,7 @@ extern "C" {
 #define PI3_ERR_WORKSPACE (-3)
 
 const char* pi3_last_error(void);
-int pi3_abi_version(void);   /* 2 */
+int pi3_abi_version(void);   /* 3 */
 int pi3_device_count(void);
 
 /* ---- transformer blocks -------------------------------------------------------------------------------------- */

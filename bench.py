@@ -203,7 +203,10 @@ def main() -> None:
     def run(cr, src, n_steps: int, timed: bool, kind: str = "u8"):
         """n_steps chunks through the pipelined product path + alignment; returns the per-chunk _metrics."""
         state = {"prev": None, "G_last": torch.eye(4, dtype=torch.float64), "prev_tail": None, "wave": 0}
-        cr.model = _EventedModel(engine, attn_events) if timed else engine
+        # the warm-up goes through the same (plain-launch, evented) forward as the timed steps: warmed up through the
+        # hipGraph replay instead, the first timed step paid for the plain path's first-use allocations (20-85 ms, i.e. up
+        # to 4 % of a 5-step measurement)
+        cr.model = _EventedModel(engine, attn_events if timed else [])
         items = ({"frames": src, "kind": kind, "paths": paths, "meta": {"chunk_index": i}} for i in range(n_steps))
         stats = []
         for meta, chunk in cr.process_chunks(items):

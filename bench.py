@@ -129,8 +129,8 @@ def cpu_baseline(engine_cfg, n_frames: int):
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=10)     # 10 x 0.4 s: the pipeline's fill + drain (~14 ms) is 0.35 % of the region
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=8, help="frames of the CPU baseline sample (8: ~30 s; 32 = BASELINE configs[0])")
     ap.add_argument("--no-extras", action="store_true", help="skip the 378x504 / K=400 / from-disk extras")

@@ -132,9 +132,11 @@ __device__ __forceinline__ void g2_epilogue_lds(const GemmParams& p, f32x4 (&acc
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni) bias4[ni] = *(const f32x4*)(p.bias + n_base + ni * 16 + nq);
   }
-  if (p.gamma) {
+  if constexpr (!QK) {      // (the fused-qkv instance has no LayerScale: pi3_gemm256_try refuses it; 16 registers less there)
+    if (p.gamma) {
 #pragma unroll
-    for (int ni = 0; ni < 4; ++ni) gamma4[ni] = *(const f32x4*)(p.gamma + n_base + ni * 16 + nq);
+      for (int ni = 0; ni < 4; ++ni) gamma4[ni] = *(const f32x4*)(p.gamma + n_base + ni * 16 + nq);
+    }
   }
   constexpr int PITCH = OUT_BF16 ? 144 : 272;
   constexpr int ROWS_PER_PASS = OUT_BF16 ? 128 : 64;
@@ -244,7 +246,7 @@ __device__ __forceinline__ void g2_epilogue_lds(const GemmParams& p, f32x4 (&acc
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
         }
-        v *= gamma4[ni];
+        if constexpr (!QK) v *= gamma4[ni];
         if constexpr (OUT_BF16) {
           u32x2 o;
           o[0] = pack_bf16x2(v[0], v[1]);

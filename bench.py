@@ -1,7 +1,10 @@
 """Headline benchmark of the hot path (BASELINE.json): frames/s end-to-end for chunk creation + overlap alignment at
 chunk_length=100, overlap=20, 512x384 input (-> 308x406 by the reference's calculate_target_size rule).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]        (N > 1: launched by torch.distributed.run, one rank/GPU)
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+N > 1 runs one rank per GPU over RCCL either way: under `python -m torch.distributed.run --nproc-per-node N bench.py
+--gpus N ...` (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment), or started as a plain process, in which
+case this file launches its own N ranks BEFORE anything touches the GPU (launch_ranks below) and relays rank 0's line.
 
 One "step" = one chunk of 100 synthetic frames through the PRODUCT path (OfflineChunkCreator.process_chunks), starting
 from the decoded uint8 frames in pinned host memory, as SURVEY.md §8(d) defines the metric:
@@ -43,6 +46,9 @@ ATTN_TRAFFIC_SOURCE = "profiles/r03_attention_pmc.csv"
 # cores, fp32 eager) with tools/cpu_reference_timing.py; profiles/r03_cpu_reference.json.  /root/reference does not exist
 # on the GPU box, so the live cpu_baseline below is the oracle port on that box's host cores; these two figures are the
 # reference's own and are quoted beside it.
+# N = 1 figure of this bench on one MI355X (driver record BENCH_r03.json: 409.33 ms per step, 244.3 frames/s; cards of
+# the pool differ by +-4 %), quoted in the N > 1 line so weak scaling can be read against it
+N1_REFERENCE = {"ms_per_step": 409.33, "frames_per_s": 244.3, "source": "BENCH_r03.json (driver run, 1 x MI355X)"}
 REFERENCE_CPU = {"source": "profiles/r03_cpu_reference.json", "cores": 8,
                  "frames_32": {"wall_s": 176.33, "frames_per_s": 0.1815},
                  "frames_100": {"wall_s": 993.05, "frames_per_s": 0.1007}}
@@ -126,7 +132,7 @@ def cpu_baseline(engine_cfg, n_frames: int):
                         f"in the frame count, so the 100-frame CPU rate is lower still (BASELINE.md)"}
 
 
-def main() -> None:
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)     # 10 x 0.4 s: the pipeline's fill + drain (~14 ms) is 0.35 % of the region
@@ -136,13 +142,118 @@ def main() -> None:
     ap.add_argument("--no-extras", action="store_true", help="skip the 378x504 / K=400 / from-disk extras")
     ap.add_argument("--no-moge", action="store_true", help="diagnostic only: leave the MoGe metric scale out (the line then says "
                     "moge_metric_scale_in_timed_region: false and is not the headline workload)")
-    args = ap.parse_args()
+    ap.add_argument("--launch-check", action="store_true",
+                    help="rendezvous only: every rank joins the process group, one all-gather, rank 0 prints the comm "
+                         "record; no chunk is processed (with PI3_DIST_BACKEND=gloo it needs no GPU)")
+    return ap.parse_args(argv)
 
+
+def launch_ranks(n: int, argv) -> int:
+    """`python bench.py --gpus N` started as a PLAIN process: start the N ranks as child processes (RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT set, one rank per GPU) and relay rank 0's JSON line.  The parent
+    never initialises the GPU - it imports torch, nothing more (no HIP call, no torch.cuda.is_available()) - and never
+    replaces itself (no exec): it waits for its children and returns non-zero if any of them failed, stopping the others
+    (by their exact PIDs) as soon as one does, so a crashed rank cannot leave the rest blocked in a collective."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    base = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE",
+                                                              "GROUP_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    base.update(WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), PI3_BENCH_LAUNCHER="self")
+    procs = []
+    for r in range(n):
+        env = dict(base, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env, cwd=ROOT,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    import threading
+    out0 = []
+    reader = threading.Thread(target=lambda: out0.extend(procs[0].stdout), daemon=True)   # drain rank 0's pipe as it fills
+    reader.start()
+    failed = 0
+    live = set(range(n))
+    while live and not failed:
+        for r in sorted(live):
+            rc = procs[r].poll()
+            if rc is not None:
+                live.discard(r)
+                if rc != 0:
+                    failed = rc
+                    print(f"[bench launcher] rank {r} exited with code {rc}; stopping the other ranks", file=sys.stderr)
+        time.sleep(0.05)
+    for r in sorted(live):                   # only reached with ranks alive when one failed
+        procs[r].terminate()
+    for r in sorted(live):
+        try:
+            procs[r].wait(timeout=20)
+        except subprocess.TimeoutExpired:
+            procs[r].kill()
+            procs[r].wait()
+    reader.join(timeout=10)
+    for ln in out0:
+        if ln.startswith("{"):
+            sys.stdout.write(ln if ln.endswith("\n") else ln + "\n")
+    sys.stdout.flush()
+    return failed
+
+
+def comm_record(backend: str, world: int, dev, boundary_bytes=None):
+    """Evidence that the collective library saw `world` ranks: what torch.distributed itself reports, every rank's
+    device (gathered THROUGH the process group), and the bytes the alignment moves per wave."""
+    import torch.distributed as dist
+    mine = {"rank": dist.get_rank(), "pid": os.getpid(), "local_rank": int(os.environ.get("LOCAL_RANK", "0")),
+            "device": str(dev), "device_name": torch.cuda.get_device_name(dev) if dev is not None else "cpu (launch check)"}
+    ranks = [None] * world
+    dist.all_gather_object(ranks, mine)
+    rec = {"backend": dist.get_backend(), "requested_backend": backend, "world_size": dist.get_world_size(),
+           "launcher": os.environ.get("PI3_BENCH_LAUNCHER", "torch.distributed.run"), "ranks": ranks,
+           "collective_library": "RCCL (torch.distributed backend 'nccl' on ROCm) over xGMI" if backend == "nccl"
+                                 else "gloo over TCP loopback: a rehearsal of the N > 1 logic, not a scaling measurement"}
+    if backend == "nccl":
+        try:
+            rec["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception as e:  # noqa: BLE001
+            rec["rccl_version"] = f"unavailable ({e})"
+    if boundary_bytes is not None:
+        rec["allgather_bytes_per_wave"] = {"boundary_blocks": boundary_bytes * world, "sim3_records": 17 * 8 * world,
+                                           "per_rank_boundary_block": boundary_bytes}
+    return rec
+
+
+def launch_check(args) -> None:
+    """--launch-check: the rendezvous and nothing else (tests the plain-process launcher without a GPU under gloo)."""
+    import torch.distributed as dist
+    backend = os.environ.get("PI3_DIST_BACKEND", "nccl")
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dev = None
+    if backend == "nccl":
+        dev = torch.device(f"cuda:{int(os.environ.get('LOCAL_RANK', '0'))}")
+        torch.cuda.set_device(dev)
+        dist.init_process_group("nccl", device_id=dev)
+    else:
+        dist.init_process_group(backend)
+    t = torch.full((1,), float(dist.get_rank()), device=dev if dev is not None else "cpu")
+    got = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(got, t)
+    assert [int(g.item()) for g in got] == list(range(world))
+    rec = comm_record(backend, world, dev)
+    if dist.get_rank() == 0:
+        _REAL_STDOUT.write(json.dumps({"launch_check": True, "n_gpus": world, "comm": rec}) + "\n")
+        _REAL_STDOUT.flush()
+    dist.destroy_process_group()
+
+
+def main(args) -> None:
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus}")
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: start bench.py as a plain process (it launches its own "
+                         f"ranks) or under torch.distributed.run with --nproc-per-node {args.gpus}")
+    if args.launch_check:
+        return launch_check(args)
     ndev = torch.cuda.device_count()
     backend = os.environ.get("PI3_DIST_BACKEND", "nccl")   # "gloo" only to rehearse the N > 1 logic on a 1-GPU box
     dev = torch.device(f"cuda:{local_rank % max(1, ndev) if backend == 'gloo' else local_rank}")
@@ -250,11 +361,21 @@ def main() -> None:
         stats = run(creator, frames_u8, args.steps, True)
         sync_all()
         dt = time.perf_counter() - t0
+    comm = None
     if world > 1:
         import torch.distributed as dist
+        from pi3_slam_amd.dist import boundary_numel
+        own_dt = dt
         tt = torch.tensor([dt], device=comm_dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+        comm = comm_record(backend, world, dev, boundary_numel(OV, KP) * 4)
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, {
+            "rank": rank, "ms_per_step": own_dt / args.steps * 1e3,
+            "pi3_forward_ms": 1e3 * sum(s.get("infer_s", 0.0) for s in stats) / max(1, len(stats)),
+            "align_host_wait_ms": 1e3 * sum(s.get("align_host_s", 0.0) for s in stats) / max(1, len(stats))})
+        comm["per_rank"] = per_rank
 
     if rank == 0 and os.environ.get("PI3_BENCH_STEPLOG"):      # per-step stage times on stderr (diagnostic)
         for i, st in enumerate(stats):
@@ -302,6 +423,11 @@ def main() -> None:
                           "note": "GPU-event times per chunk (copy stream / compute stream); stages of consecutive chunks "
                                   "overlap, so they do not add up to ms_per_step"},
         }
+        if comm is not None:
+            line["comm"] = comm
+            # what ONE GPU takes for the same step, to cross-check this N-rank line against the N = 1 line: the committed
+            # N = 1 record and, live, every rank's own wall time per step and forward time by GPU events (comm.per_rank)
+            line["n1_reference_ms_per_step"] = N1_REFERENCE
         line["second_metric"] = {"metric": "7-Scenes APE", "value": None,
                                  "note": "not measurable offline: needs the released pi3 / MoGe weights, the dataset and evo "
                                          "(BASELINE.json; SURVEY.md §8d)"}
@@ -529,11 +655,15 @@ def extras(engine, moge, make_creator, run, dev):
 
 
 if __name__ == "__main__":
+    _args = parse_args()
+    if _args.gpus > 1 and int(os.environ.get("WORLD_SIZE", "1")) == 1 and "RANK" not in os.environ:
+        # plain `python bench.py --gpus N`: become the launcher.  Nothing above has touched the GPU (module imports only).
+        sys.exit(launch_ranks(_args.gpus, sys.argv[1:]))
     # stdout carries exactly ONE line, the JSON record of rank 0; the pipeline's progress prints (per-chunk inference
     # FPS etc., on every rank) go to stderr
     _REAL_STDOUT = sys.stdout
     sys.stdout = sys.stderr
     try:
-        main()
+        main(_args)
     finally:
         sys.stdout = _REAL_STDOUT

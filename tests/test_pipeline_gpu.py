@@ -372,21 +372,26 @@ def test_reconstruct_with_bundle_adjust_under_torchrun_equals_single_process(tmp
     assert np.array_equal(t1, t2), np.abs(t1 - t2).max()          # the same arithmetic on the same data: 6-decimal text equal
 
 
-def test_bench_two_ranks_rehearsal(tmp_path, built_lib):
-    """`bench.py --gpus 2` exactly as the driver launches it (torch.distributed.run, one rank per process), with gloo
-    standing in for RCCL because both ranks share this box's one GPU: the N > 1 branch (one chunk per rank per step,
-    boundary all-gather, own solve, 136-byte all-gather, prefix product, max-over-ranks timing) runs end to end and
-    prints ONE JSON line with the whole-job aggregate."""
+@pytest.mark.parametrize("launcher", ["plain", "torchrun"])
+def test_bench_two_ranks_rehearsal(tmp_path, built_lib, launcher):
+    """`bench.py --gpus 2` both ways the driver may start it - as a PLAIN process (bench.py launches its own ranks before
+    any GPU call and relays rank 0's line) and under torch.distributed.run - with gloo standing in for RCCL because both
+    ranks share this box's one GPU: the N > 1 branch (one chunk per rank per step, boundary all-gather, own solve,
+    136-byte all-gather, prefix product, max-over-ranks timing) runs end to end and prints ONE JSON line with the
+    whole-job aggregate and the comm record (what torch.distributed saw)."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, PI3_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "PI3_BENCH_LAUNCHER"):
         env.pop(k, None)
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                        "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(root, "bench.py"),
-                        "--gpus", "2", "--steps", "2", "--warmup", "1"], env=env, capture_output=True, text=True,
-                       timeout=600, cwd=root)
+    bench = [os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"]
+    if launcher == "plain":
+        cmd = [sys.executable] + bench
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+               "--master-addr", "127.0.0.1", "--master-port", str(_free_port())] + bench
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=root)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
@@ -395,6 +400,14 @@ def test_bench_two_ranks_rehearsal(tmp_path, built_lib):
     assert rec["value"] > 0 and abs(rec["value"] - 2 * 100 * 2 / (rec["ms_per_step"] * 2 / 1e3)) < 1e-6 * rec["value"]
     assert rec["roofline"]["bound"] == "mfma" and 0 < rec["roofline"]["frac"] < 1
     assert "cpu_baseline" not in rec            # rank 0 at N = 1 only
+    comm = rec["comm"]
+    assert comm["backend"] == "gloo" and comm["world_size"] == 2
+    assert comm["launcher"] == ("self" if launcher == "plain" else "torch.distributed.run")
+    assert [x["rank"] for x in comm["ranks"]] == [0, 1] and len({x["pid"] for x in comm["ranks"]}) == 2
+    assert all("MI3" in x["device_name"] or "Instinct" in x["device_name"] for x in comm["ranks"])
+    assert comm["allgather_bytes_per_wave"]["per_rank_boundary_block"] == (1 + 2 * 20 * 200 * 6 + 16) * 4
+    assert len(comm["per_rank"]) == 2 and all(p["ms_per_step"] <= rec["ms_per_step"] * (1 + 1e-9) for p in comm["per_rank"])
+    assert rec["n1_reference_ms_per_step"]["ms_per_step"] > 0
 
 
 def test_rccl_branch_with_a_one_rank_group(tmp_path, built_lib):

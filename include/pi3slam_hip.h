@@ -27,7 +27,7 @@ extern "C" {
 #define PI3_ERR_WORKSPACE (-3)
 
 const char* pi3_last_error(void);
-int pi3_abi_version(void);   /* 3 */
+int pi3_abi_version(void);   /* 4 */
 int pi3_device_count(void);
 
 /* ---- transformer blocks -------------------------------------------------------------------------------------- */
@@ -213,6 +213,15 @@ int pi3_sim3_match_keypoints(const void* kp_ref, const void* kp_qry, int ov, int
 int pi3_sim3_umeyama(const void* pts_ref, const void* pts_qry, const int* idx, const unsigned char* w_ref,
                      const unsigned char* w_qry, int ov, int K, const float* last_ref_pose, int use_filter,
                      double* out33, void* stream);
+
+/* The same solve with real-valued weights w_*: f32 [ov][K] (either may be null = 1): the "weighted Umeyama" of the
+ * north star (w = mask * sigmoid(conf)).  Pair weight = w_ref[ref track] * w_qry[qry keypoint];
+ * pairs whose weight is not in (0, inf) do not take part; W = sum w, weighted means / covariance / variance / rms; the
+ * near-half filter is the reference's unweighted median over the pairs that take part.  The reference itself passes
+ * unweighted points (utils/reconstruction_alignment.py:97), so the host code keeps this off by default. */
+int pi3_sim3_umeyama_weighted(const void* pts_ref, const void* pts_qry, const int* idx, const float* w_ref,
+                              const float* w_qry, int ov, int K, const float* last_ref_pose, int use_filter,
+                              double* out33, void* stream);
 
 /* TransformReconstruction4 (:105): points f32 [n][3] and cam->world poses f32 [F][16] in place by the f64 4x4. */
 int pi3_sim3_apply(const double* M4_dev, float* pts, long n, float* poses, int F, void* stream);

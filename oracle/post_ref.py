@@ -206,13 +206,24 @@ def match_keypoints(kp_ref: np.ndarray, kp_qry: np.ndarray) -> np.ndarray:
     return idx
 
 
-def umeyama(x: np.ndarray, y: np.ndarray):
-    """Closed-form similarity y ~ s R x + t (Umeyama 1991), float64.  Returns s, R, t, 4x4."""
+def umeyama(x: np.ndarray, y: np.ndarray, w: Optional[np.ndarray] = None):
+    """Closed-form similarity y ~ s R x + t (Umeyama 1991), float64.  Returns s, R, t, 4x4.
+    w: optional positive weights, the minimiser of sum w |y - (s R x + t)|^2 (W = sum w,
+    weighted means, Sigma = sum w (y - my)(x - mx)^T / W, var_x = sum w |x - mx|^2 / W).  The reference passes
+    unweighted points (reconstruction_alignment.py:97)."""
     x, y = np.asarray(x, np.float64), np.asarray(y, np.float64)
-    mx, my = x.mean(0), y.mean(0)
-    xc, yc = x - mx, y - my
-    Sg = yc.T @ xc / len(x)
-    varx = (xc ** 2).sum() / len(x)
+    if w is None:
+        mx, my = x.mean(0), y.mean(0)
+        xc, yc = x - mx, y - my
+        Sg = yc.T @ xc / len(x)
+        varx = (xc ** 2).sum() / len(x)
+    else:
+        w = np.asarray(w, np.float64)
+        Wt = w.sum()
+        mx, my = (w[:, None] * x).sum(0) / Wt, (w[:, None] * y).sum(0) / Wt
+        xc, yc = x - mx, y - my
+        Sg = (w[:, None] * yc).T @ xc / Wt
+        varx = (w * (xc ** 2).sum(1)).sum() / Wt
     U, D, Vt = np.linalg.svd(Sg)
     S = np.diag([1.0, 1.0, np.sign(np.linalg.det(U) * np.linalg.det(Vt))])
     R = U @ S @ Vt
@@ -255,12 +266,18 @@ def horn_sim3(x: np.ndarray, y: np.ndarray):
 
 def align_chunks(pts_ref: np.ndarray, pts_qry: np.ndarray, kp_ref: np.ndarray, kp_qry: np.ndarray,
                  last_ref_pose: np.ndarray, use_filter: bool = True,
-                 w_ref: Optional[np.ndarray] = None, w_qry: Optional[np.ndarray] = None):
+                 w_ref: Optional[np.ndarray] = None, w_qry: Optional[np.ndarray] = None,
+                 weights_ref: Optional[np.ndarray] = None, weights_qry: Optional[np.ndarray] = None):
     """Steps 1-3 of align_and_refine_reconstructions (reconstruction_alignment.py:74-105) on chunk-file data:
-    pts_* (ov, K, 3) float16 world points of the overlap views, kp_* (ov, K, 2) float16, last_ref_pose (4,4) float32."""
+    pts_* (ov, K, 3) float16 world points of the overlap views (float32 for bundle-adjusted chunks), kp_* (ov, K, 2)
+    float16, last_ref_pose (4,4) float32.  w_*: optional validity (a pair takes part or not); weights_*: optional
+    real-valued float32 weights (ov, K), pair weight = weights_ref[ref track] * weights_qry[qry keypoint] formed in
+    float64, pairs whose weight is not in (0, inf) do not take part; the near-half filter stays the reference's
+    unweighted strict median over the pairs that take part."""
     idx = match_keypoints(kp_ref, kp_qry)
     ov, K = idx.shape
-    ref, qry = [], []
+    weighted = weights_ref is not None or weights_qry is not None
+    ref, qry, wts = [], [], []
     for v in range(ov):
         for j in range(K):
             r = idx[v, j]
@@ -270,9 +287,17 @@ def align_chunks(pts_ref: np.ndarray, pts_qry: np.ndarray, kp_ref: np.ndarray, k
                 continue
             if w_ref is not None and not w_ref[v, r]:
                 continue
+            w = 1.0
+            if weights_qry is not None:
+                w *= float(np.float32(weights_qry[v, j]))
+            if weights_ref is not None:
+                w *= float(np.float32(weights_ref[v, r]))
+            if not (w > 0.0) or not (w < np.inf):
+                continue
             ref.append(pts_ref[v, r].astype(np.float64))
             qry.append(pts_qry[v, j].astype(np.float64))
-    ref, qry = np.array(ref).reshape(-1, 3), np.array(qry).reshape(-1, 3)
+            wts.append(w)
+    ref, qry, wts = np.array(ref).reshape(-1, 3), np.array(qry).reshape(-1, 3), np.array(wts, np.float64)
     n_common = len(ref)
     med = np.inf
     if use_filter and n_common:
@@ -280,9 +305,13 @@ def align_chunks(pts_ref: np.ndarray, pts_qry: np.ndarray, kp_ref: np.ndarray, k
         dist = np.linalg.norm(ref - cam, axis=1)
         med = np.median(dist)
         keep = dist < med
-        ref, qry = ref[keep], qry[keep]
-    s, R, t, M = umeyama(qry, ref)
-    rms = np.sqrt((((s * (R @ qry.T)).T + t - ref) ** 2).sum(1).mean())
+        ref, qry, wts = ref[keep], qry[keep], wts[keep]
+    if len(ref) < 3:          # the kernel's (and alignment.sim3_accepted's) rejection: identity + the counts
+        return dict(idx=idx, s=1.0, R=np.eye(3), t=np.zeros(3), M=np.eye(4), n_used=len(ref), n_common=n_common,
+                    median=med, rms=0.0)
+    s, R, t, M = umeyama(qry, ref, wts if weighted else None)
+    e2 = (((s * (R @ qry.T)).T + t - ref) ** 2).sum(1)
+    rms = np.sqrt((wts * e2).sum() / wts.sum()) if weighted else np.sqrt(e2.mean())
     return dict(idx=idx, s=s, R=R, t=t, M=M, n_used=len(ref), n_common=n_common, median=med, rms=rms)
 
 

@@ -58,12 +58,24 @@ def _overlap_block(chunk: Dict[str, torch.Tensor], frames: List[int], device) ->
     return out
 
 
+def keypoint_weights(chunk: Dict, frames: List[int]) -> torch.Tensor:
+    """w = mask * sigmoid(conf) at the keypoints of the given views, float32 [len(frames), K] on the host (SURVEY.md §7
+    step 7).  conf is stored as logits (offline_chunk_creator.py:233), masks as bool (:234)."""
+    idx = torch.tensor(frames, dtype=torch.long)
+    conf = chunk["conf"][idx.to(chunk["conf"].device)].to(torch.float32).cpu().reshape(len(frames), -1)
+    mask = chunk["masks"][idx.to(chunk["masks"].device)].cpu().reshape(len(frames), -1)
+    return (torch.sigmoid(conf) * mask.to(torch.float32)).contiguous()
+
+
 def estimate_sim3(chunk_ref: Dict, chunk_qry: Dict, view_graph_matches: List[Tuple[int, int]], device="cuda:0",
-                  use_masks: bool = False, use_filter: bool = True) -> torch.Tensor:
+                  use_masks: bool = False, use_filter: bool = True, weights: Optional[str] = None) -> torch.Tensor:
     """Relative similarity qry -> ref from the overlap views (steps 1-3), BOTH chunks taken in their own (chunk-file)
     frames.  Returns the f64 device vector of pi3_sim3_umeyama: s, R(9), t(3), M(16), n_used, n_common, median, rms.
-    use_masks=True weights the pairs by both chunks' validity masks (the 'weighted' variant; the reference passes all
-    common points, reconstruction_alignment.py:97)."""
+    The reference passes all common points unweighted (reconstruction_alignment.py:97) - the default here.
+    use_masks=True lets only pairs take part whose keypoints are valid in both chunks' masks; weights='conf' is the
+    weighted Umeyama with w = mask * sigmoid(conf) per keypoint (pi3_sim3_umeyama_weighted)."""
+    if weights not in (None, "conf"):
+        raise ValueError(f"weights={weights!r}: None or 'conf'")
     n_ref = int(chunk_ref["points"].shape[0])
     n_qry = int(chunk_qry["points"].shape[0])
     pairs = [(r, q) for (r, q) in view_graph_matches if r < n_ref and q < n_qry]
@@ -78,6 +90,9 @@ def estimate_sim3(chunk_ref: Dict, chunk_qry: Dict, view_graph_matches: List[Tup
     w_qry = qry["masks"].reshape(len(pairs), -1).to(torch.uint8).contiguous() if use_masks else None
     # chunk-file points are fp16 and go in as they are; bundle-adjusted chunks carry refined fp32 points
     dt = torch.float16 if ref["points"].dtype == torch.float16 and qry["points"].dtype == torch.float16 else torch.float32
+    if weights == "conf":
+        w_ref = upload(keypoint_weights(chunk_ref, [r for r, _ in pairs]), device).contiguous()
+        w_qry = upload(keypoint_weights(chunk_qry, [q for _, q in pairs]), device).contiguous()
     return ops.sim3_umeyama(ref["points"].to(dt), qry["points"].to(dt), idx, last_pose, w_ref, w_qry, use_filter)
 
 
@@ -126,7 +141,8 @@ def transform_chunk(chunk: Dict, M4: torch.Tensor, device="cuda:0", absolute: bo
 
 def align_and_refine_reconstructions(chunk_ref: Dict, chunk_qry: Dict, view_graph_matches: List[Tuple[int, int]],
                                      use_inverse_depth: bool = False, device="cuda:0",
-                                     use_masks: bool = False, bundle_adjust: Optional[Dict] = None) -> Tuple[bool, Dict]:
+                                     use_masks: bool = False, bundle_adjust: Optional[Dict] = None,
+                                     weights: Optional[str] = None) -> Tuple[bool, Dict]:
     """Same contract as the reference (returns (False, {"error": ...}) instead of raising): chunk_qry is transformed
     in place into chunk_ref's frame.
 
@@ -139,7 +155,7 @@ def align_and_refine_reconstructions(chunk_ref: Dict, chunk_qry: Dict, view_grap
     if use_inverse_depth:
         raise NotImplementedError(INVERSE_DEPTH_MESSAGE)
     try:
-        out = estimate_sim3(chunk_ref, chunk_qry, view_graph_matches, device, use_masks)
+        out = estimate_sim3(chunk_ref, chunk_qry, view_graph_matches, device, use_masks, weights=weights)
         o = out.cpu()
         n_used = int(o[29].item())
         if not sim3_accepted(o):

@@ -63,16 +63,24 @@ struct PairSrc {
   const int* idx;         // [ov][K] ref keypoint index per qry keypoint or -1
   const uint8_t* w_ref;   // optional validity [ov][K] (e.g. masks) or null
   const uint8_t* w_qry;
+  const float* wf_ref;    // optional real-valued weights [ov][K] (e.g. mask * sigmoid(conf)) or null
+  const float* wf_qry;
   int ov, K;
 };
 
-__device__ __forceinline__ bool pair_get(const PairSrc& s, int i, double x[3], double y[3]) {
+// One pair (qry keypoint i, its ref track): false when it does not take part (no common track, validity 0, weight
+// <= 0 or not finite).  w = the pair's weight: 1 unless real-valued weights were given (then w_ref[r] * w_qry[i]).
+__device__ __forceinline__ bool pair_get(const PairSrc& s, int i, double x[3], double y[3], double& w) {
   const int j = s.idx[i];
   if (j < 0) return false;
   const int v = i / s.K;
   const int r = v * s.K + j;
   if (s.w_qry && !s.w_qry[i]) return false;
   if (s.w_ref && !s.w_ref[r]) return false;
+  w = 1.0;
+  if (s.wf_qry) w *= (double)s.wf_qry[i];
+  if (s.wf_ref) w *= (double)s.wf_ref[r];
+  if (!(w > 0.0) || !(w < INFINITY)) return false;
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
     if (s.f32) {
@@ -96,8 +104,8 @@ __device__ double select_rank(const PairSrc& s, const double cam[3], int M, unsi
     __syncthreads();
     const unsigned long long prefix = *s_prefix;
     for (int i = tid; i < M; i += 1024) {
-      double x[3], y[3];
-      if (!pair_get(s, i, x, y)) continue;
+      double x[3], y[3], w;
+      if (!pair_get(s, i, x, y, w)) continue;
       const double dx = y[0] - cam[0], dy = y[1] - cam[1], dz = y[2] - cam[2];
       const unsigned long long key = (unsigned long long)__double_as_longlong(sqrt(dx * dx + dy * dy + dz * dz));
       if ((key & pmask) == prefix) atomicAdd(&hist[(key >> (8 * pass)) & 255ull], 1u);
@@ -120,7 +128,11 @@ __device__ double select_rank(const PairSrc& s, const double cam[3], int M, unsi
 }
 
 // out (doubles): [0] s, [1..9] R row-major, [10..12] t, [13..28] 4x4 row-major, [29] pairs used, [30] common pairs,
-//                [31] median distance, [32] rms alignment error over the used pairs
+//                [31] median distance, [32] (weighted) rms alignment error over the used pairs
+// With weights w_i: W = sum w, mx = sum w x / W, my = sum w y / W,
+// Sigma = sum w (y - my)(x - mx)^T / W, var_x = sum w |x - mx|^2 / W; the near-half filter stays the reference's
+// (unweighted median over the pairs that take part, strict '<').  Unweighted: w = 1 and every expression below is the
+// plain one bit for bit (x * 1.0 is exact).
 __global__ __launch_bounds__(1024) void sim3_umeyama_kernel(PairSrc s, const float* __restrict__ last_ref_pose,
                                                             int use_filter, double* __restrict__ out) {
   __shared__ double red[16];
@@ -134,8 +146,8 @@ __global__ __launch_bounds__(1024) void sim3_umeyama_kernel(PairSrc s, const flo
 
   double cnt = 0.0;
   for (int i = tid; i < M; i += 1024) {
-    double x[3], y[3];
-    if (pair_get(s, i, x, y)) cnt += 1.0;
+    double x[3], y[3], w;
+    if (pair_get(s, i, x, y, w)) cnt += 1.0;
   }
   const double ncommon = block_sum(cnt, red, tid);
   double med = INFINITY;
@@ -146,28 +158,30 @@ __global__ __launch_bounds__(1024) void sim3_umeyama_kernel(PairSrc s, const flo
     med = 0.5 * (lo + hi);  // np.median
   }
 
-  // pass A: count + means over kept pairs
-  double a[7] = {0, 0, 0, 0, 0, 0, 0};
+  // pass A: count, weight sum + weighted means over kept pairs
+  double a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   for (int i = tid; i < M; i += 1024) {
-    double x[3], y[3];
-    if (!pair_get(s, i, x, y)) continue;
+    double x[3], y[3], w;
+    if (!pair_get(s, i, x, y, w)) continue;
     const double dx = y[0] - cam[0], dy = y[1] - cam[1], dz = y[2] - cam[2];
     if (use_filter && !(sqrt(dx * dx + dy * dy + dz * dz) < med)) continue;
     a[0] += 1.0;
-    for (int c = 0; c < 3; ++c) { a[1 + c] += x[c]; a[4 + c] += y[c]; }
+    a[7] += w;
+    for (int c = 0; c < 3; ++c) { a[1 + c] += w * x[c]; a[4 + c] += w * y[c]; }
   }
-  for (int c = 0; c < 7; ++c) {
+  for (int c = 0; c < 8; ++c) {
     const double v = block_sum(a[c], red, tid);
     if (tid == 0) sh[c] = v;
   }
   __syncthreads();
-  const double n = sh[0];
-  if (n < 3.0) {  // not enough pairs: report failure through the count, identity transform
+  const double npairs = sh[0];
+  const double n = sh[7];          // W = sum of weights (= the pair count when unweighted)
+  if (npairs < 3.0) {  // not enough pairs: report failure through the count, identity transform
     if (tid == 0) {
       for (int i = 0; i < 33; ++i) out[i] = 0.0;
       out[0] = 1.0; out[1] = out[5] = out[9] = 1.0;
       out[13] = out[18] = out[23] = out[28] = 1.0;
-      out[29] = n; out[30] = ncommon; out[31] = med;
+      out[29] = npairs; out[30] = ncommon; out[31] = med;
     }
     return;
   }
@@ -176,15 +190,15 @@ __global__ __launch_bounds__(1024) void sim3_umeyama_kernel(PairSrc s, const flo
   // pass B: centred second moments  Sigma = 1/n sum (y - my)(x - mx)^T,  var_x = 1/n sum |x - mx|^2
   double cm[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   for (int i = tid; i < M; i += 1024) {
-    double x[3], y[3];
-    if (!pair_get(s, i, x, y)) continue;
+    double x[3], y[3], w;
+    if (!pair_get(s, i, x, y, w)) continue;
     const double dx = y[0] - cam[0], dy = y[1] - cam[1], dz = y[2] - cam[2];
     if (use_filter && !(sqrt(dx * dx + dy * dy + dz * dz) < med)) continue;
     const double xc[3] = {x[0] - mx[0], x[1] - mx[1], x[2] - mx[2]};
     const double yc[3] = {y[0] - my[0], y[1] - my[1], y[2] - my[2]};
     for (int r = 0; r < 3; ++r)
-      for (int c = 0; c < 3; ++c) cm[3 * r + c] += yc[r] * xc[c];
-    cm[9] += xc[0] * xc[0] + xc[1] * xc[1] + xc[2] * xc[2];
+      for (int c = 0; c < 3; ++c) cm[3 * r + c] += w * yc[r] * xc[c];
+    cm[9] += w * (xc[0] * xc[0] + xc[1] * xc[1] + xc[2] * xc[2]);
   }
   for (int c = 0; c < 10; ++c) {
     const double v = block_sum(cm[c], red, tid);
@@ -211,7 +225,7 @@ __global__ __launch_bounds__(1024) void sim3_umeyama_kernel(PairSrc s, const flo
       out[13 + 4 * r + 3] = t[r];
     }
     out[25] = 0.0; out[26] = 0.0; out[27] = 0.0; out[28] = 1.0;
-    out[29] = n; out[30] = ncommon; out[31] = med;
+    out[29] = npairs; out[30] = ncommon; out[31] = med;
     sh[10] = sc;
     for (int c = 0; c < 9; ++c) sh[c] = R[c];  // reuse for the residual pass
     sh[11] = t[0]; sh[12] = t[1]; sh[13] = t[2];
@@ -219,34 +233,56 @@ __global__ __launch_bounds__(1024) void sim3_umeyama_kernel(PairSrc s, const flo
   __syncthreads();
   double err = 0.0;
   for (int i = tid; i < M; i += 1024) {
-    double x[3], y[3];
-    if (!pair_get(s, i, x, y)) continue;
+    double x[3], y[3], w;
+    if (!pair_get(s, i, x, y, w)) continue;
     const double dx = y[0] - cam[0], dy = y[1] - cam[1], dz = y[2] - cam[2];
     if (use_filter && !(sqrt(dx * dx + dy * dy + dz * dz) < med)) continue;
+    double e2 = 0.0;
     for (int r = 0; r < 3; ++r) {
       const double p = sh[10] * (sh[3 * r] * x[0] + sh[3 * r + 1] * x[1] + sh[3 * r + 2] * x[2]) + sh[11 + r] - y[r];
-      err += p * p;
+      e2 += p * p;
     }
+    err += w * e2;
   }
   const double tot = block_sum(err, red, tid);
   if (tid == 0) out[32] = sqrt(tot / n);
 }
 
-extern "C" int pi3_sim3_umeyama(const void* pts_ref, const void* pts_qry, const int* idx, const unsigned char* w_ref,
-                                const unsigned char* w_qry, int ov, int K, const float* last_ref_pose,
-                                int use_filter, double* out33, void* stream) {
-  if (!pts_ref || !pts_qry || !idx || !last_ref_pose || !out33 || ov <= 0 || K <= 0) {
-    pi3_set_error("pi3_sim3_umeyama: bad arguments");
+static int launch_sim3(const char* who, const void* pts_ref, const void* pts_qry, const int* idx,
+                       const unsigned char* w_ref, const unsigned char* w_qry, const float* wf_ref, const float* wf_qry,
+                       int ov, int K, const float* last_ref_pose, int use_filter, double* out33, void* stream) {
+  if (!pts_ref || !pts_qry || !idx || !last_ref_pose || !out33 || ov <= 0 || K <= 0 || (use_filter & ~3)) {
+    pi3_set_error(who);
     return PI3_ERR_ARG;
   }
   PairSrc s;
   s.pts_ref = pts_ref; s.pts_qry = pts_qry; s.idx = idx;
   s.f32 = (use_filter & 2) ? 1 : 0;
   use_filter &= 1;
-  s.w_ref = w_ref; s.w_qry = w_qry; s.ov = ov; s.K = K;
+  s.w_ref = w_ref; s.w_qry = w_qry; s.wf_ref = wf_ref; s.wf_qry = wf_qry; s.ov = ov; s.K = K;
   hipLaunchKernelGGL(sim3_umeyama_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, s, last_ref_pose, use_filter,
                      out33);
   return pi3_check_launch("sim3_umeyama");
+}
+
+extern "C" int pi3_sim3_umeyama(const void* pts_ref, const void* pts_qry, const int* idx, const unsigned char* w_ref,
+                                const unsigned char* w_qry, int ov, int K, const float* last_ref_pose,
+                                int use_filter, double* out33, void* stream) {
+  return launch_sim3("pi3_sim3_umeyama: bad arguments", pts_ref, pts_qry, idx, w_ref, w_qry, nullptr, nullptr, ov, K,
+                     last_ref_pose, use_filter, out33, stream);
+}
+
+// The weighted Umeyama of SURVEY.md §7 step 7: real-valued per-keypoint weights (e.g. mask * sigmoid(conf)); the pair
+// weight is w_ref[ref track] * w_qry[qry keypoint], pairs with a weight that is not in (0, inf) do not take part.
+extern "C" int pi3_sim3_umeyama_weighted(const void* pts_ref, const void* pts_qry, const int* idx, const float* w_ref,
+                                         const float* w_qry, int ov, int K, const float* last_ref_pose, int use_filter,
+                                         double* out33, void* stream) {
+  if (!w_ref && !w_qry) {
+    pi3_set_error("pi3_sim3_umeyama_weighted: no weights given (use pi3_sim3_umeyama)");
+    return PI3_ERR_ARG;
+  }
+  return launch_sim3("pi3_sim3_umeyama_weighted: bad arguments", pts_ref, pts_qry, idx, nullptr, nullptr, w_ref, w_qry,
+                     ov, K, last_ref_pose, use_filter, out33, stream);
 }
 
 // ---- 4. apply a 4x4 similarity (row-major doubles, device memory) to fp32 points [n][3] and cam->world poses [F][16]

@@ -50,6 +50,7 @@ SIGNATURES = {
     "pi3_moge_depth": [_vp, _vp, _vp, _vp, _l, _vp, _vp],
     "pi3_sim3_match_keypoints": [_vp, _vp, _i, _i, _vp, _vp],
     "pi3_sim3_umeyama": [_vp] * 5 + [_i, _i, _vp, _i, _vp, _vp],
+    "pi3_sim3_umeyama_weighted": [_vp] * 5 + [_i, _i, _vp, _i, _vp, _vp],
     "pi3_sim3_apply": [_vp, _vp, _l, _vp, _i, _vp],
     "pi3_sim3_compose_prefix": [_vp, _vp, _i, _vp],
     "pi3_project_observations": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp],

@@ -277,7 +277,9 @@ def sim3_match_keypoints(kp_ref: torch.Tensor, kp_qry: torch.Tensor) -> torch.Te
 def sim3_umeyama(pts_ref: torch.Tensor, pts_qry: torch.Tensor, idx: torch.Tensor, last_ref_pose: torch.Tensor,
                  w_ref: Optional[torch.Tensor] = None, w_qry: Optional[torch.Tensor] = None,
                  use_filter: bool = True) -> torch.Tensor:
-    """-> f64 device tensor [33]: s, R(9), t(3), M(16), n_used, n_common, median, rms."""
+    """-> f64 device tensor [33]: s, R(9), t(3), M(16), n_used, n_common, median, rms.
+    w_ref / w_qry [ov, K]: uint8 validity (a pair takes part or not) or float32 weights (the weighted Umeyama:
+    pair weight = w_ref[ref track] * w_qry[qry keypoint]); both of one kind."""
     lib = _L.load()
     assert pts_ref.dtype == pts_qry.dtype and pts_ref.dtype in (torch.float16, torch.float32) and idx.dtype == torch.int32
     pts_ref, pts_qry, idx = pts_ref.contiguous(), pts_qry.contiguous(), idx.contiguous()
@@ -285,10 +287,17 @@ def sim3_umeyama(pts_ref: torch.Tensor, pts_qry: torch.Tensor, idx: torch.Tensor
     assert last_ref_pose.dtype == torch.float32
     last_ref_pose = last_ref_pose.contiguous()
     ov, K = idx.shape
+    assert pts_ref.numel() == pts_qry.numel() == ov * K * 3
+    kinds = {w.dtype for w in (w_ref, w_qry) if w is not None}
+    assert kinds <= {torch.uint8} or kinds <= {torch.float32}, "w_ref / w_qry: both uint8 validity or both float32 weights"
+    for w in (w_ref, w_qry):
+        assert w is None or (w.is_contiguous() and w.numel() == ov * K and w.device == idx.device)
     out = torch.empty(33, device=idx.device, dtype=torch.float64)
-    rc = lib.pi3_sim3_umeyama(pts_ref.data_ptr(), pts_qry.data_ptr(), idx.data_ptr(), _L.ptr(w_ref), _L.ptr(w_qry),
-                              ov, K, last_ref_pose.data_ptr(), flags, out.data_ptr(), _L.stream_ptr())
-    _L.check(rc, "pi3_sim3_umeyama")
+    fn, name = ((lib.pi3_sim3_umeyama_weighted, "pi3_sim3_umeyama_weighted") if torch.float32 in kinds
+                else (lib.pi3_sim3_umeyama, "pi3_sim3_umeyama"))
+    rc = fn(pts_ref.data_ptr(), pts_qry.data_ptr(), idx.data_ptr(), _L.ptr(w_ref), _L.ptr(w_qry),
+            ov, K, last_ref_pose.data_ptr(), flags, out.data_ptr(), _L.stream_ptr())
+    _L.check(rc, name)
     return out
 
 

@@ -189,8 +189,8 @@ def test_fused_qkv_epilogue_at_chunk_rows(dev, attn_B, attn_S):
     print(f"fused qkv epilogue at M={M}: worst max-rel {worst:.2e}")
 
 
-@pytest.mark.parametrize("H,W", [(308, 406), (280, 448)])
-def test_post_processing_full_chunk_vs_oracle(dev, H, W):
+@pytest.mark.parametrize("H,W,KP", [(308, 406, 200), (308, 406, 400), (280, 448, 200)])
+def test_post_processing_full_chunk_vs_oracle(dev, H, W, KP):
     """masks / ratio median / per-frame focal-shift LM / keypoint gather + colours over a whole 100-frame chunk at the
     two shipped map sizes, against oracle/post_ref on the CPU (pinned to the reference's own functions by
     tests/golden/post_*.npz).  Bit-exact where the small fixtures are: masks, median, nearest samples, fp16 bilinear
@@ -199,7 +199,7 @@ def test_post_processing_full_chunk_vs_oracle(dev, H, W):
     from oracle.gen_golden_post import synthetic_chunk
     from pi3_slam_amd import ops
     from pi3_slam_amd.chunk_creator import _uv_tables
-    N, KP = 100, 200
+    N = 100                    # KP: SURVEY §8d S2's two keypoint counts (spacing 22: 234 -> 200; spacing 16: 432 -> 400)
     d = synthetic_chunk(f"full_{H}x{W}", N, H, W)
     lp, conf, pts, imgs = d["local_points"], d["conf"], d["points"], d["images"]
     masks_ref = post_ref.compute_masks(conf, lp)
@@ -221,6 +221,7 @@ def test_post_processing_full_chunk_vs_oracle(dev, H, W):
     # keypoints: the per-frame random subset of the grid, gather + fp16 pack + colours
     kp = post_ref.grid_keypoints(N, H, W, KP, torch.Generator().manual_seed(11))
     assert kp.shape == (N, KP, 2)
+    assert not torch.equal(kp[0], kp[1])                                    # per-frame random subsets of the grid
     out = ops.gather_keypoints(ptsd, lpd, confd, masks, imgs.to(dev), kp.to(dev))
     exp = post_ref.interpolate_at_keypoints(pts, lp, conf, masks_ref, kp, H, W)
     assert torch.equal(out["masks"].bool().cpu().reshape(N, KP), exp["masks"].reshape(N, KP))

@@ -89,6 +89,49 @@ def test_umeyama_known_answers():
     assert abs(np.linalg.det(Rp) - 1.0) < 1e-9
 
 
+def test_weighted_umeyama_known_answers():
+    """The weighted closed form: integer weights equal repeated points; it is the minimiser of the
+    weighted cost (scipy on the 7 similarity parameters cannot do better); uniform weights change nothing; and in
+    align_chunks pairs of weight 0 drop out while the near-half filter stays the unweighted median."""
+    from scipy.optimize import least_squares
+    from scipy.spatial.transform import Rotation
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal((40, 3)) * [2.0, 1.0, 0.5] + [0, 0, 4.0]
+    R = Rotation.from_rotvec([0.2, -0.4, 0.1]).as_matrix()
+    y = 1.4 * x @ R.T + [0.3, 0.1, -0.7] + 0.05 * rng.standard_normal(x.shape)
+    w = rng.integers(1, 5, 40).astype(np.float64)
+    s1, R1, t1, M1 = post_ref.umeyama(x, y, w)
+    rep = np.repeat(np.arange(40), w.astype(int))
+    s2, R2, t2, M2 = post_ref.umeyama(x[rep], y[rep])
+    np.testing.assert_allclose(M1, M2, atol=1e-12)
+    np.testing.assert_allclose(post_ref.umeyama(x, y, np.full(40, 0.37))[3], post_ref.umeyama(x, y)[3], atol=1e-12)
+    wr = rng.random(40) + 0.05
+
+    def res(p):
+        Rm = Rotation.from_rotvec(p[:3]).as_matrix()
+        return (np.sqrt(wr)[:, None] * (np.exp(p[3]) * x @ Rm.T + p[4:7] - y)).ravel()
+    s3, R3, t3, _ = post_ref.umeyama(x, y, wr)
+    p0 = np.concatenate([Rotation.from_matrix(R3).as_rotvec(), [np.log(s3)], t3])
+    sol = least_squares(res, p0, xtol=1e-14, ftol=1e-14, gtol=1e-14)
+    assert np.abs(sol.x - p0).max() < 1e-6 and (res(p0) ** 2).sum() <= (res(sol.x) ** 2).sum() * (1 + 1e-9)
+    # align_chunks: zero weights drop pairs, the filter is the unweighted strict median over what is left
+    ov, K = 3, 30
+    kp = (rng.random((ov, K, 2)) * 300).astype(np.float16)
+    pr = (rng.standard_normal((ov, K, 3)) + [0, 0, 5]).astype(np.float16)
+    pq = ((pr.astype(np.float64) - [0.1, 0.2, 0.3]) / 1.1).astype(np.float16)
+    wq = rng.random((ov, K)).astype(np.float32)
+    wq[:, ::3] = 0.0
+    pose = np.eye(4, dtype=np.float32)
+    a = post_ref.align_chunks(pr, pq, kp, kp, pose, True, weights_qry=wq)
+    assert a["n_common"] == ov * K - ov * len(range(0, K, 3))
+    valid = (wq > 0)
+    b = post_ref.align_chunks(pr, pq, kp, kp, pose, True, w_qry=valid)
+    assert a["median"] == b["median"] and a["n_used"] == b["n_used"]
+    assert np.abs(a["M"] - b["M"]).max() > 1e-9                   # the weights do enter the solve
+    few = post_ref.align_chunks(pr[:1, :2], pq[:1, :2], kp[:1, :2], kp[:1, :2], pose, False)
+    assert few["n_used"] == 2 and np.array_equal(few["M"], np.eye(4))
+
+
 @pytest.mark.parametrize("name", ["moge_small", "moge_chunk", "moge_pinhole_small", "moge_pinhole_chunk",
                                   "moge_var_pixelshuffle", "moge_var_interp", "moge_var_elu", "moge_vitl",
                                   "moge_vitb_reg"])

@@ -173,8 +173,9 @@ def align_and_refine_reconstructions(chunk_ref: Dict, chunk_qry: Dict, view_grap
             # chunk, 50 LM iterations with Huber 3.0, outlier tracks; the refined values become the chunk's new frame
             from .bundle_adjust import AFTER_ALIGNMENT, bundle_adjust_chunk, overlap_priors
             priors = overlap_priors(chunk_ref, view_graph_matches)
+            settings = dict(AFTER_ALIGNMENT, **bundle_adjust.get("settings", {}))
             ba = bundle_adjust_chunk(chunk_qry, bundle_adjust["width"], bundle_adjust["height"],
-                                     bundle_adjust.get("max_observations_per_track", 5), device, AFTER_ALIGNMENT, priors,
+                                     bundle_adjust.get("max_observations_per_track", 5), device, settings, priors,
                                      release_observations=True)     # a chunk's last adjustment: free ~18 MB of HBM
             info["priors_set"] = len(priors)
             info["bundle_adjustment"] = ba
@@ -183,6 +184,10 @@ def align_and_refine_reconstructions(chunk_ref: Dict, chunk_qry: Dict, view_grap
                       f"removed {ba['removed_tracks']} tracks")
                 chunk_qry["_chunk_frame"] = {"points": chunk_qry["points"], "camera_poses": chunk_qry["camera_poses"]}
                 chunk_qry["_sim3_global"] = torch.eye(4, dtype=torch.float64)
+            else:    # rejected by the sanity gate or failed numerically: the chunk keeps its closed-form alignment
+                     # (points / poses untouched, frame bookkeeping unchanged); the caller sees it in the info dict
+                print(f"   ⚠️  prior-constrained bundle adjustment NOT applied "
+                      f"({ba.get('rejected') or ba.get('reason') or 'numerical failure'}); closed-form alignment kept")
         return True, info
     except Exception as e:  # noqa: BLE001 - the reference swallows and reports (reconstruction_alignment.py:194-198)
         print(f"❌ Complete reconstruction alignment failed: {e}")

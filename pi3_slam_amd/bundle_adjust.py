@@ -19,8 +19,14 @@ import torch
 
 from . import ops
 
-PER_CHUNK = dict(max_iters=10, huber_width=2.0, max_reprojection_px=2.0, min_triangulation_angle_deg=0.25)
-AFTER_ALIGNMENT = dict(max_iters=50, huber_width=3.0, max_reprojection_px=3.0, min_triangulation_angle_deg=0.25)
+# The last three keys configure the sanity gate below, which has NO counterpart in the reference (Theia applies whatever
+# Ceres returns): sanity_gate=False switches it off for reference-parity runs (OfflineReconstructor(ba_sanity_gate=False),
+# `cli reconstruct --no-ba-sanity-gate`); max_camera_move_extents = how many scene extents a camera centre may move;
+# min_surviving_tracks = how many of the tracks that took part must still be estimated.
+PER_CHUNK = dict(max_iters=10, huber_width=2.0, max_reprojection_px=2.0, min_triangulation_angle_deg=0.25,
+                 sanity_gate=True, max_camera_move_extents=1.0, min_surviving_tracks=3)
+AFTER_ALIGNMENT = dict(max_iters=50, huber_width=3.0, max_reprojection_px=3.0, min_triangulation_angle_deg=0.25,
+                       sanity_gate=True, max_camera_move_extents=1.0, min_surviving_tracks=3)
 PRIOR_SQRT_INFO_ROT = (1.0 / 2.0) ** 0.5        # orientation prior covariance 2 I (reconstruction_alignment.py:123)
 PRIOR_SQRT_INFO_POS = (1.0 / 25.0) ** 0.5       # position prior covariance 25 I (:127)
 
@@ -69,8 +75,18 @@ def build_observations(chunk: Dict, W: int, H: int, max_observations_per_track: 
     return uv.contiguous(), valid.contiguous(), intr
 
 
+def ba_summary(infos: List[Optional[Dict]]) -> Dict[str, int]:
+    """Counts over a run's adjustments: ran / applied / rejected by the sanity gate / failed numerically."""
+    infos = [i for i in infos if i]
+    rejected = sum(1 for i in infos if i.get("rejected"))
+    applied = sum(1 for i in infos if i.get("success"))
+    return {"ran": len(infos), "applied": applied, "rejected_by_sanity_gate": rejected,
+            "failed": len(infos) - applied - rejected}
+
+
 def sanity_gate(pts0: torch.Tensor, rc0: torch.Tensor, pts1: torch.Tensor, rc1: torch.Tensor,
-                est: torch.Tensor, est_before: Optional[torch.Tensor]) -> Optional[str]:
+                est: torch.Tensor, est_before: Optional[torch.Tensor], max_camera_move_extents: float = 1.0,
+                min_surviving_tracks: int = 3) -> Optional[str]:
     """Why a finished adjustment must NOT be taken over, or None.  Ceres reports success for any run that ends
     without a numerical failure, and so does ba.hip; on geometry the chunk's own projections contradict (e.g. recipe
     weights) LM walks the cameras away by many scene extents and every track ends up an outlier.  Two plain facts are
@@ -78,13 +94,13 @@ def sanity_gate(pts0: torch.Tensor, rc0: torch.Tensor, pts1: torch.Tensor, rc1: 
     camera centre moved further than the extent of the scene (bounding-box diagonal of the input points and centres)."""
     took_part = est_before if est_before is not None else torch.ones_like(est)
     left = int((est & took_part).sum())
-    if int(took_part.sum()) >= 3 and left < 3:
+    if int(took_part.sum()) >= min_surviving_tracks and left < min_surviving_tracks:
         return f"{left} of {int(took_part.sum())} tracks survived the outlier test"
     finite = torch.isfinite(pts0).all(dim=1)
     cloud = torch.cat([pts0[finite], rc0[:, 9:]], dim=0)
     extent = float((cloud.max(dim=0).values - cloud.min(dim=0).values).norm())
     moved = float((rc1[:, 9:] - rc0[:, 9:]).norm(dim=1).max())
-    if not moved <= extent:
+    if not moved <= max_camera_move_extents * extent:
         return f"a camera moved {moved:.3g} units, the scene extent is {extent:.3g}"
     return None
 
@@ -137,7 +153,9 @@ def bundle_adjust_chunk(chunk: Dict, W: int, H: int, max_observations_per_track:
     ok = bool(torch.isfinite(s[0])) and bool(torch.isfinite(pts).all()) and bool(torch.isfinite(rc).all())
     info = {"success": ok, "initial_cost": float(s[8]), "final_cost": float(s[0]), "iterations": int(s[5]),
             "accepted_steps": int(s[6]), "removed_tracks": int((~est).sum().item())}
-    why = sanity_gate(pts0, rc0, pts, rc, est, est_before) if ok else None
+    why = (sanity_gate(pts0, rc0, pts, rc, est, est_before, settings.get("max_camera_move_extents", 1.0),
+                       settings.get("min_surviving_tracks", 3))
+           if ok and settings.get("sanity_gate", True) else None)
     if why is not None:
         print(f"   ⚠️  bundle adjustment not applied: {why}")
         info.update(success=False, rejected=why)

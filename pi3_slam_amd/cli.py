@@ -50,7 +50,10 @@ RECON_SWITCHES = (("--save-per-chunk", "per-chunk ply files as well"),
                   ("--save-observations", "also write the projected track observations"),
                   ("--no-bundle-adjust", "closed-form Sim(3) chain only: skip the per-chunk and the prior-constrained "
                                          "bundle adjustment (utils/chunk_reconstruction.py:188-219, "
-                                         "utils/reconstruction_alignment.py:107-171)"))
+                                         "utils/reconstruction_alignment.py:107-171)"),
+                  ("--no-ba-sanity-gate", "apply every bundle adjustment that ends without a numerical failure, as the "
+                                          "reference does (default: keep the input when fewer than 3 tracks survive or a "
+                                          "camera moved by more than the scene extent)"))
 
 
 def list_images(root: str) -> List[str]:
@@ -104,7 +107,8 @@ def run_reconstruct(a: argparse.Namespace) -> None:
     OfflineReconstructor(chunk_dir=a.chunks, output_dir=a.output, chunk_length=a.chunk_length, overlap=a.overlap,
                          max_observations_per_track=a.max_observations_per_track, save_per_chunk=a.save_per_chunk,
                          use_inverse_depth=a.use_inverse_depth, device=a.device,
-                         save_observations=a.save_observations, bundle_adjust=not a.no_bundle_adjust).run()
+                         save_observations=a.save_observations, bundle_adjust=not a.no_bundle_adjust,
+                         ba_sanity_gate=not a.no_ba_sanity_gate).run()
 
 
 def main(argv=None) -> None:

@@ -23,6 +23,22 @@ int pi3_check_launch(const char* what) {
   return PI3_OK;
 }
 
+int pi3_lds_optin(const void* kern, int bytes, unsigned long long* done_mask, const char* what) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+  const unsigned long long bit = 1ull << (dev & 63);
+  if (__atomic_load_n(done_mask, __ATOMIC_RELAXED) & bit) return PI3_OK;
+  hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    pi3_set_error("%s: hipFuncSetAttribute(MaxDynamicSharedMemorySize = %d) on device %d: %s", what, bytes, dev,
+                  hipGetErrorString(e));
+    return PI3_ERR_LAUNCH;
+  }
+  __atomic_fetch_or(done_mask, bit, __ATOMIC_RELAXED);
+  return PI3_OK;
+}
+
 extern "C" const char* pi3_last_error(void) { return g_err; }
 
 extern "C" int pi3_abi_version(void) { return 4; }   // 4: pi3_sim3_umeyama_weighted (real-valued pair weights); 2: caller-provided workspaces (attention, group-norm statistics); 3: narrow-N GEMM / conv forms, pi3_cast_rows_pad, 4-channel granularity of the MoGe staging kernels

@@ -27,6 +27,10 @@ enum {
 
 void pi3_set_error(const char* fmt, ...);
 int pi3_check_launch(const char* what);
+// Opt `kern` into `bytes` of dynamic LDS (above the 64 KB default) on the CURRENT device, once per device: the attribute
+// is per device, so `done_mask` (one function-local static per kernel instance) carries one bit per device ordinal.
+// Returns PI3_OK or PI3_ERR_LAUNCH with the runtime's message in pi3_last_error().
+int pi3_lds_optin(const void* kern, int bytes, unsigned long long* done_mask, const char* what);
 
 __device__ __forceinline__ float bf16_bits_to_f32(uint16_t b) {
   return __uint_as_float(((uint32_t)b) << 16);

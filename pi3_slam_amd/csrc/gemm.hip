@@ -159,11 +159,8 @@ template <bool IS_BF16, bool OUT_BF16, int ACT, bool CONV = false>
 static int launch_gemm(const GemmParams& p, hipStream_t stream) {
   const int nbm = (p.M + BM - 1) / BM, nbn = p.N / BN;
   auto kern = gemm_tn_kernel<IS_BF16, OUT_BF16, ACT, CONV>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES);
-    attr_set = true;
-  }
+  static unsigned long long optin = 0;
+  if (int rc = pi3_lds_optin((const void*)kern, 4 * TILE_BYTES, &optin, "gemm_tn")) return rc;
   hipLaunchKernelGGL(kern, dim3(nbm * nbn), dim3(256), 4 * TILE_BYTES, stream, p);
   return pi3_check_launch("gemm_tn");
 }
@@ -287,20 +284,14 @@ static int launch_narrow(const GemmParams& p, hipStream_t stream) {
   if (p.N % 64 == 0) {
     auto kern = gemm_narrow_kernel<4, OUT_BF16, ACT, CONV>;
     constexpr int lds = 2 * (NBM * 128 + 64 * 128);
-    static bool attr_set = false;
-    if (!attr_set) {
-      (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-      attr_set = true;
-    }
+    static unsigned long long optin = 0;
+    if (int rc = pi3_lds_optin((const void*)kern, lds, &optin, "gemm_narrow")) return rc;
     hipLaunchKernelGGL(kern, dim3(nbm * (p.N / 64)), dim3(256), lds, stream, p);
   } else {
     auto kern = gemm_narrow_kernel<2, OUT_BF16, ACT, CONV>;
     constexpr int lds = 2 * (NBM * 128 + 32 * 128);
-    static bool attr_set = false;
-    if (!attr_set) {
-      (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-      attr_set = true;
-    }
+    static unsigned long long optin = 0;
+    if (int rc = pi3_lds_optin((const void*)kern, lds, &optin, "gemm_narrow")) return rc;
     hipLaunchKernelGGL(kern, dim3(nbm * (p.N / 32)), dim3(256), lds, stream, p);
   }
   return pi3_check_launch("gemm_narrow");

@@ -601,12 +601,9 @@ template <bool OUT_BF16, int ACT, bool NOEPI = false, bool STAG = false, bool QK
 static int launch256(const GemmParams& p, hipStream_t stream) {
   const int nbm = (p.M + G2_BM - 1) / G2_BM, nbn = p.N / G2_BN;
   auto kern = gemm256_kernel<OUT_BF16, ACT, NOEPI, STAG, QK>;
-  static bool attr_set = false;
+  static unsigned long long optin = 0;
   constexpr int LDS_BYTES = QK ? G2_LDS_QK : G2_LDS_TOTAL;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-    attr_set = true;
-  }
+  if (int rc = pi3_lds_optin((const void*)kern, LDS_BYTES, &optin, "gemm256")) return rc;
   static int persist = -1, ncu = 0;     // PI3_GEMM_PERSIST: 1 (default) one workgroup per CU walking tiles | 0 a workgroup per tile
   if (persist < 0) {
     const char* e = getenv("PI3_GEMM_PERSIST");
@@ -748,11 +745,8 @@ template <bool OUT_BF16, int ACT, bool QK = false>
 static int launch3(const GemmParams& p, hipStream_t stream) {
   const int nbm = (p.M + G3_BM - 1) / G3_BM, nbn = p.N / G3_BN;
   auto kern = gemm3_kernel<OUT_BF16, ACT, QK>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, G3_LDS);
-    attr_set = true;
-  }
+  static unsigned long long optin = 0;
+  if (int rc = pi3_lds_optin((const void*)kern, G3_LDS, &optin, "gemm3")) return rc;
   hipLaunchKernelGGL(kern, dim3(nbm * nbn), dim3(256), G3_LDS, stream, p);
   return pi3_check_launch("gemm3");
 }

@@ -146,11 +146,28 @@ extern "C" int pi3_compute_masks(const float* conf, const float* local_points, i
     pi3_set_error("pi3_compute_masks: bad arguments (W <= %d, 4-byte aligned maps)", MK_MAXW);
     return PI3_ERR_ARG;
   }
-  // sigmoid(c) > conf_thr, i.e. fl(1 / fl(1 + e)) > conf_thr with e = expf(-c): the set of such e is an interval
-  // [0, estar]; bisect estar over the bit patterns of the non-negative floats (they order like the values) with the
-  // same two correctly rounded fp32 operations the kernel used to do per pixel
-  float estar = -1.0f;
-  {
+  // environment knobs (A/B only; read once per process like the GEMM / attention knobs) and the per-threshold constants
+  // (memoised for the last conf_thr: the chunk creator always passes the same one) - no getenv / bisection / log() on
+  // the per-chunk launch path
+  struct Knobs { int exact_only, rows; size_t budget; };
+  static const Knobs knobs = [] {
+    Knobs k;
+    k.exact_only = getenv("PI3_MASKS_EXACT_ONLY") ? 1 : 0;
+    const char* e = getenv("PI3_MASKS_ROWS");
+    k.rows = (e && atoi(e) > 0) ? atoi(e) : 16;
+    long kb = MK_LDS_BUDGET / 1024;
+    if (const char* b = getenv("PI3_MASKS_LDS_KB")) kb = atol(b);
+    kb = kb < 1 ? 1 : (kb > 64 ? 64 : kb);          // [1 KB, 64 KB]: the kernel does not opt into more dynamic LDS
+    k.budget = (size_t)kb * 1024;
+    return k;
+  }();
+  struct ThrConsts { float thr, estar, clo, chi; int valid; };
+  static thread_local ThrConsts memo = {0.0f, 0.0f, 0.0f, 0.0f, 0};
+  if (!memo.valid || memcmp(&memo.thr, &conf_thr, 4) != 0) {
+    // sigmoid(c) > conf_thr, i.e. fl(1 / fl(1 + e)) > conf_thr with e = expf(-c): the set of such e is an interval
+    // [0, estar]; bisect estar over the bit patterns of the non-negative floats (they order like the values) with the
+    // same two correctly rounded fp32 operations the kernel used to do per pixel
+    float es = -1.0f;
     auto pass = [&](uint32_t bits) {
       float e;
       memcpy(&e, &bits, 4);
@@ -165,28 +182,34 @@ extern "C" int pi3_compute_masks(const float* conf, const float* local_points, i
         const uint32_t mid = lo + (hi - lo) / 2u;
         if (pass(mid)) lo = mid; else hi = mid;
       }
-      memcpy(&estar, &lo, 4);
+      memcpy(&es, &lo, 4);
     }
+    memo.thr = conf_thr;
+    memo.estar = es;
+    memo.clo = -INFINITY;                          // "never decided without the expf" unless the bracket is sound
+    memo.chi = INFINITY;
+    if (es > 1e-30f && es < 1e30f) {
+      const double c0 = -log((double)es), band = 1e-5 * (1.0 + fabs(c0));
+      memo.clo = (float)(c0 - band);
+      memo.chi = (float)(c0 + band);
+    }
+    memo.valid = 1;
   }
+  const float estar = memo.estar;
   MaskFast mf;
-  mf.ok = (rtol >= 0.0f && rtol < FLT_MAX && !getenv("PI3_MASKS_EXACT_ONLY")) ? 1 : 0;
+  mf.ok = (rtol >= 0.0f && rtol < FLT_MAX && !knobs.exact_only) ? 1 : 0;
   mf.rlo = (float)((double)rtol * (1.0 - 1e-5));
   mf.rhi = (float)((double)rtol * (1.0 + 1e-5));
-  mf.clo = -INFINITY;                              // "never decided without the expf" unless the bracket is sound
-  mf.chi = INFINITY;
-  if (estar > 1e-30f && estar < 1e30f) {
-    const double c0 = -log((double)estar), band = 1e-5 * (1.0 + fabs(c0));
-    mf.clo = (float)(c0 - band);
-    mf.chi = (float)(c0 + band);
-  }
+  mf.clo = memo.clo;
+  mf.chi = memo.chi;
   // strip height: the tallest whose staged rows + confidences (worst-case 3 floats of lead each) fit the budget
-  int R = 16;
-  if (const char* e = getenv("PI3_MASKS_ROWS")) R = atoi(e) > 0 ? atoi(e) : R;
-  R = R < H ? R : H;
+  int R = knobs.rows < H ? knobs.rows : H;
   auto lds_bytes = [&](int r) { return (size_t)(mk_lds_floats(3, 3 * (r + 2) * W) + mk_lds_floats(3, r * W)) * sizeof(float); };
-  size_t budget = MK_LDS_BUDGET;
-  if (const char* e = getenv("PI3_MASKS_LDS_KB")) budget = (size_t)atoi(e) * 1024;
-  while (R > 1 && lds_bytes(R) > budget) --R;
+  while (R > 1 && lds_bytes(R) > knobs.budget) --R;
+  if (lds_bytes(R) > 64 * 1024) {
+    pi3_set_error("pi3_compute_masks: one row strip of W = %d needs %zu bytes of LDS (> 64 KB)", W, lds_bytes(R));
+    return PI3_ERR_ARG;
+  }
   const int zfloats = mk_lds_floats(3, 3 * (R + 2) * W);
   const long nwg = (long)F * ((H + R - 1) / R);
   hipLaunchKernelGGL(masks_kernel, dim3((unsigned)((nwg + 7) / 8 * 8)), dim3(256), lds_bytes(R), (hipStream_t)stream, conf, local_points,

@@ -120,6 +120,24 @@ def unpack_boundary(flat: torch.Tensor, overlap: int, K: int, n_frames: Optional
                 last_pose=flat[1 + 2 * sz: 1 + 2 * sz + 16].reshape(4, 4))
 
 
+def repad_tail(block: Dict, K: int) -> Dict:
+    """The carried block of the previous wave re-padded to a wider keypoint count K (only its TAIL is ever read again):
+    keypoints that cannot match, zero points, mask 0 - the same padding pack_boundary() writes."""
+    tail = block["tail"]
+    ov, K0 = tail["keypoints"].shape[:2]
+    if K0 == K:
+        return block
+    if K0 > K:
+        raise ValueError(f"carried block holds {K0} keypoints per view, cannot shrink to {K}")
+    kp = torch.full((ov, K, 2), PAD_KEYPOINT_TAIL, dtype=tail["keypoints"].dtype, device=tail["keypoints"].device)
+    kp[:, :K0] = tail["keypoints"]
+    pt = torch.zeros((ov, K, 3), dtype=tail["points"].dtype, device=tail["points"].device)
+    pt[:, :K0] = tail["points"]
+    mk = torch.zeros((ov, K, 1), dtype=tail["masks"].dtype, device=tail["masks"].device)
+    mk[:, :K0] = tail["masks"]
+    return dict(block, tail=dict(keypoints=kp, points=pt, masks=mk), head=None)
+
+
 def allgather_boundaries(local: torch.Tensor, device) -> List[torch.Tensor]:
     """One all-gather of the per-rank boundary blocks (RCCL on GPUs; gloo in the CPU tests)."""
     world = dist.get_world_size()
@@ -196,11 +214,17 @@ def align_wave(rank: int, world: int, w0: int, n_chunks: int, blocks: List[Dict]
     from .alignment import upload
     c = w0 + rank
     pred = blocks[rank - 1] if rank > 0 else prev_tail
+    eye = torch.eye(4, dtype=torch.float64).reshape(16)
     if c < n_chunks and pred is not None:
-        mine = upload(solve(pred, blocks[rank]), comm_device)
+        try:
+            mine = upload(solve(pred, blocks[rank]), comm_device)
+        except Exception as e:  # noqa: BLE001 - a rank that raised here would skip the collective below and every
+            # other rank would block in it until the RCCL timeout: the failure becomes a 'rejected' record instead
+            # (the reference reports and carries on, offline_reconstructor.py:100-102)
+            print(f"❌ rank {rank}: Sim(3) solve of chunk {c} failed ({type(e).__name__}: {e}); chunk left unaligned")
+            mine = upload(torch.cat([torch.zeros(1, dtype=torch.float64), eye]), comm_device)
     else:
-        mine = upload(torch.cat([torch.ones(1, dtype=torch.float64), torch.eye(4, dtype=torch.float64).reshape(16)]),
-                      comm_device)
+        mine = upload(torch.cat([torch.ones(1, dtype=torch.float64), eye]), comm_device)
     rel = [torch.empty_like(mine) for _ in range(world)]
     dist.all_gather(rel, mine.contiguous())
     n_wave = min(world, n_chunks - w0)
@@ -260,6 +284,7 @@ class WaveAligner:
         self.solve, self.compose = solve, compose
         self.G_last = torch.eye(4, dtype=torch.float64)
         self.prev_tail: Optional[Dict] = None
+        self.K_run = 0
 
     def step(self, chunk: Optional[Dict], w0: int, n_chunks: int) -> Tuple[List[torch.Tensor], List[bool]]:
         """chunk: this rank's chunk dict (chunk index w0 + rank) or None.  Collectives: sizes (2 ints per rank), boundary
@@ -270,7 +295,13 @@ class WaveAligner:
         szs = [torch.zeros_like(sz) for _ in range(self.world)]
         dist.all_gather(szs, sz)
         szs = torch.stack(szs).cpu().tolist()          # one device -> host copy for the whole wave
-        K = max(k for k, _ in szs)
+        # K is run-wide: the widest keypoint count seen so far (every rank computes the same value from the gathered
+        # sizes).  The block carried over from the previous wave was packed with THAT wave's K; with ragged keypoint
+        # counts (low-texture frames, a short last wave) the two differ and the solver's shape check would raise on
+        # rank 0 only - so the wave never shrinks below the carried block and the carried block is widened to the wave
+        self.K_run = K = max(max(k for k, _ in szs), self.K_run)
+        if self.prev_tail is not None:
+            self.prev_tail = repad_tail(self.prev_tail, K)
         if chunk is not None:
             local = pack_boundary(chunk, self.overlap, K, device=self.comm_dev)
         else:   # ragged last wave: an empty block (n_frames = 0)

@@ -192,7 +192,8 @@ class Pi3Engine:
         qkv = self._buffer("qkv", (S, 3 * D), torch.bfloat16)
         ao = self._buffer("ao", (S, D), torch.bfloat16)
         hid = self._buffer("hid", (S, 4 * D), torch.bfloat16)
-        bufs = (xn, qkv, ao, hid)
+        k2 = self._buffer("k2max", (max(F, B) * cfg.heads,), torch.float32)    # max |k|^2 per (frame or batch, head)
+        bufs = (xn, qkv, ao, hid, k2)
 
         # ---- patch embed (+ cls / registers / interpolated pos-embed): vision_transformer.py:215-234
         patches = self._buffer("patches", (F * P, 640), torch.bfloat16)

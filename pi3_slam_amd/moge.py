@@ -550,7 +550,7 @@ class MoGeEngine:
                  bias=w["encoder.backbone.patch_embed.proj.bias"], rpg=P, gstride=T, goff=1 + nreg, addtab=pos_patch)
         ops.fill_tokens(x, 1, T, 0, special)
         bufs = (self._new(T, D, torch.bfloat16), self._new(T, 3 * D, torch.bfloat16), self._new(T, D, torch.bfloat16),
-                self._new(T, 4 * D, torch.bfloat16))
+                self._new(T, 4 * D, torch.bfloat16), self._new(1, heads, torch.float32).view(-1))
         n_int = cfg["encoder"]["intermediate_layers"]
         take = list(range(bb["depth"] - n_int, bb["depth"])) if isinstance(n_int, int) else list(n_int)
         Cenc = cfg["encoder"]["dim_out"]

@@ -50,7 +50,7 @@ class OfflineReconstructor:
     def __init__(self, chunk_dir: str, output_dir: str, chunk_length: Optional[int] = None,
                  overlap: Optional[int] = None, max_observations_per_track: int = 5, save_per_chunk: bool = False,
                  use_inverse_depth: bool = False, device: str = "cuda", save_observations: bool = False,
-                 bundle_adjust: bool = True):
+                 bundle_adjust: bool = True, ba_sanity_gate: bool = True):
         self.chunk_dir, self.output_dir = chunk_dir, output_dir
         loaded_cl = loaded_ov = None
         try:  # offline_reconstructor.py:32-46
@@ -78,7 +78,12 @@ class OfflineReconstructor:
         # alignment with pose priors: utils/reconstruction_alignment.py:107-171) on the device (csrc/ba.hip, parity
         # unpinned); False = closed-form Sim(3) chain only
         self.bundle_adjust = bool(bundle_adjust)
+        # ba_sanity_gate: keep the input when an adjustment "succeeds" on contradictory geometry (bundle_adjust.sanity_gate;
+        # not in the reference, which applies whatever Ceres returns) - False for reference-parity runs.  Rejections are
+        # counted in refinement_summary and printed at the end of run().
+        self.ba_sanity_gate = bool(ba_sanity_gate)
         self.ba_infos: List[Dict] = []
+        self.refinement_summary: Dict[str, Dict[str, int]] = {}
         # save_observations: also write, per chunk, the track observations the reference builds for its bundle adjuster
         # (ChunkPTRecon.create_recon_from_chunk, utils/chunk_reconstruction.py:162-185) as observations_%06d.pt
         self.save_observations = save_observations
@@ -110,7 +115,22 @@ class OfflineReconstructor:
             return None
         # offline_reconstructor.py:66-67: 1920x1080 when a chunk file does not carry its size
         return {"width": int(data.get("original_width", 1920)), "height": int(data.get("original_height", 1080)),
-                "max_observations_per_track": self.max_observations_per_track}
+                "max_observations_per_track": self.max_observations_per_track,
+                "settings": {"sanity_gate": self.ba_sanity_gate}}
+
+    def _summarise_refinement(self) -> None:
+        """Which adjustments ran, were applied, or were kept out by the sanity gate - `refinement_stages` alone lists a
+        stage even when every one of its adjustments was rejected."""
+        if not self.bundle_adjust:
+            return
+        from .bundle_adjust import ba_summary
+        self.refinement_summary = {
+            "per_chunk_bundle_adjust": ba_summary(self.ba_infos),
+            "prior_constrained_bundle_adjust": ba_summary([(a or {}).get("bundle_adjustment") for a in self.alignment_infos])}
+        for stage, c in self.refinement_summary.items():
+            print(f"   {stage}: {c['applied']} of {c['ran']} applied"
+                  + (f", {c['rejected_by_sanity_gate']} rejected by the sanity gate" if c["rejected_by_sanity_gate"] else "")
+                  + (f", {c['failed']} failed" if c["failed"] else ""))
 
     def _bundle_adjust_new_chunk(self, data: Dict, idx: int) -> None:
         """The refinement inside ChunkPTRecon.create_recon_from_chunk (chunk_reconstruction.py:188-219)."""
@@ -120,7 +140,7 @@ class OfflineReconstructor:
         try:
             from .bundle_adjust import PER_CHUNK, bundle_adjust_chunk
             info = bundle_adjust_chunk(data, args["width"], args["height"], args["max_observations_per_track"],
-                                       self.device, PER_CHUNK)
+                                       self.device, dict(PER_CHUNK, **args["settings"]))
             self.ba_infos.append(info)
             if info.get("success"):
                 print(f"   Removed {info['removed_tracks']} tracks after initial bundle adjustment "
@@ -148,6 +168,9 @@ class OfflineReconstructor:
             if idx > 0:
                 print("   🔗 Aligning with previous reconstruction...")
                 self.alignment_infos.append(self._align_last_two())
+            # the cached observation arrays (~18 MB of device memory per chunk) are released by the chunk's last
+            # adjustment; chunk 0 has none after this point and a chunk whose alignment failed never reaches it
+            data.pop("_observations", None)
             dt = max(1e-6, time.time() - t0)
             n = int(data["camera_poses"].shape[0])
             print(f"   ⏱️ Reconstruction: {dt:.3f}s for {n} frames  ->  {n / dt:.2f} FPS")
@@ -157,6 +180,7 @@ class OfflineReconstructor:
                 self._save_observations(data, idx)
         if not self.reconstructions:
             return
+        self._summarise_refinement()
         self._write_outputs()
 
     def _write_outputs(self) -> None:
@@ -244,18 +268,28 @@ class OfflineReconstructor:
         self.refinement_stages = ["per_chunk_bundle_adjust", "closed_form_sim3", "prior_constrained_bundle_adjust"]
         print(f"🔄 Reconstructing {n_chunks} chunks from {self.chunk_dir} on {world} ranks (rank {rank}), sequential "
               f"refinement chain (bundle adjustment on)")
+        keep = ("points", "colors", "keypoints", "masks", "camera_poses", "image_paths", "chunk_order", "alignment_ok")
         own: Dict[int, Dict] = {}
-        for c in range(rank, n_chunks, world):          # independent per chunk: every rank works on its own
-            data = torch.load(files[c], map_location="cpu", weights_only=False)
-            self._bundle_adjust_new_chunk(data, c)
-            own[c] = data
+        done: List[Dict] = []
+
+        def prepare(c: int) -> None:
+            # load + the independent per-chunk adjustment of this rank's chunk c.  Done ONE chunk ahead of the chain (the
+            # first before the chain starts, the next right after this rank's turn, while the other ranks take theirs):
+            # a chunk carries ~18 MB of device-resident observation arrays between its two adjustments, so preparing
+            # every chunk up front grew HBM and host memory linearly with the chunks per rank
+            if c < n_chunks:
+                data = torch.load(files[c], map_location="cpu", weights_only=False)
+                self._bundle_adjust_new_chunk(data, c)
+                own[c] = data
+
+        prepare(rank)
         matches = create_view_graph_matches(self.chunk_length, self.overlap)
         prev: Optional[Dict] = None
         for c in range(n_chunks):
             owner = c % world
             payload = None
             if rank == owner:
-                data = own[c]
+                data = own.pop(c)
                 ok = True
                 if c > 0:
                     ok, info = align_and_refine_reconstructions(prev, data, matches, device=self.device,
@@ -263,15 +297,19 @@ class OfflineReconstructor:
                     self.alignment_infos.append(info if ok else None)
                     if not ok:
                         print(f"   ❌ Alignment failed for chunk {c}")
+                data.pop("_observations", None)      # chunk 0 / a failed alignment: no later adjustment releases them
                 data["chunk_order"], data["alignment_ok"] = c, bool(ok)
                 payload = chain_payload(data)
                 if self.save_per_chunk:
                     self._save_chunk(data, c)
                 if self.save_observations:
                     self._save_observations(data, c)
+                done.append({k: data[k] for k in keep if k in data})
             prev = chain_step(payload, owner)
-        keep = ("points", "colors", "keypoints", "masks", "camera_poses", "image_paths", "chunk_order", "alignment_ok")
-        parts = gather_objects([{k: d[k] for k in keep if k in d} for d in own.values()])
+            if rank == owner:
+                prepare(c + world)
+        self._summarise_refinement()
+        parts = gather_objects(done)
         if rank == 0:
             self.reconstructions = sorted((d for part in parts for d in part), key=lambda d: d["chunk_order"])
             self._write_outputs()

@@ -1,6 +1,8 @@
 """One pre-LN transformer block as a sequence of C-ABI launches, shared by the pi3 network (encoder / decoder / heads,
 pi3/models/layers/block.py:310-335, pi3/models/dinov2/layers/block.py:88-113) and the MoGe DINOv2 encoder
-(moge/model/dinov2/layers/block.py).  Buffers: xn bf16 [S, D], qkv bf16 [S, 3D], ao bf16 [S, D], hid bf16 [S, 4D]."""
+(moge/model/dinov2/layers/block.py).  Buffers: xn bf16 [S, D], qkv bf16 [S, 3D], ao bf16 [S, D], hid bf16 [S, 4D] and,
+optionally, k2 f32 [>= attn_B * heads]: max |k|^2 per (batch, head), written by the qkv epilogue and read by the
+attention of the same block (one buffer per engine serves every block: same stream, launch order)."""
 from __future__ import annotations
 
 from typing import Dict, Optional
@@ -16,7 +18,8 @@ def run_block(w: Dict[str, torch.Tensor], prefix: str, x: torch.Tensor, S: int, 
               attn_events: Optional[list] = None) -> None:
     """x (fp32 residual stream [S, D]) is updated in place."""
     D = heads * 64
-    xn, qkv, ao, hid = bufs
+    xn, qkv, ao, hid = bufs[:4]
+    k2buf = bufs[4] if len(bufs) > 4 else None
     ops.layernorm(x, w[f"{prefix}.norm1.weight"], w[f"{prefix}.norm1.bias"], xn, eps, rows=S)
     fused = rope or qk_norm
     # encoder blocks (no q/k norm, no RoPE; pi3/models/dinov2/layers/block.py:88-113) take the fused epilogue as well where
@@ -28,7 +31,11 @@ def run_block(w: Dict[str, torch.Tensor], prefix: str, x: torch.Tensor, S: int, 
         # q/k LayerNorm(64) + RoPE-2D + softmax scale (+ max |k|^2 per (batch, head) for the attention's bounded-score loop) ride in the qkv
         # epilogue: one launch, no second pass over the packed qkv buffer
         if attn_S >= 256:        # both the long-sequence and the frame-wise kernel take the bounded-score loop with it
-            k2max = torch.empty(attn_B * heads, device=x.device, dtype=torch.float32)
+            if k2buf is not None:        # the engine's pre-allocated buffer: no allocator call on the launch path
+                assert k2buf.dtype == torch.float32 and k2buf.numel() >= attn_B * heads and k2buf.is_contiguous()
+                k2max = k2buf[: attn_B * heads]
+            else:
+                k2max = torch.empty(attn_B * heads, device=x.device, dtype=torch.float32)
         ops.gemm_qkv(xn, w[f"{prefix}.attn.qkv.weight"], qkv[:S], M=S, H=heads, bias=w[f"{prefix}.attn.qkv.bias"], T=T,
                      pos=pos if rope else None, cs=cs if rope else None,
                      qw=w.get(f"{prefix}.attn.q_norm.weight") if qk_norm else None,

@@ -61,7 +61,7 @@ def test_allgather_boundaries_world2():
 
 
 # ------------------------------------------------------------------------------------------------ wave alignment
-def _synthetic_chunks(n_chunks, cl, ov, K, bad_chunk=None, last_n=None, few_kp_chunk=None):
+def _synthetic_chunks(n_chunks, cl, ov, K, bad_chunk=None, last_n=None, few_kp_chunk=None, kp_map=None):
     """Chunk dicts (chunk-file layout) cut from one world: chunk c = S_c^-1 (world).  bad_chunk's keypoints are shifted
     so that it shares no track with its predecessor (its alignment must fail and restart the chain)."""
     import numpy as np
@@ -84,6 +84,8 @@ def _synthetic_chunks(n_chunks, cl, ov, K, bad_chunk=None, last_n=None, few_kp_c
             k[:ov] = (k[:ov].astype(np.float32) + 1000).astype(np.float16)     # only its head: the tail still pairs
         if c == few_kp_chunk:       # a chunk with fewer keypoints per view than the rest of its wave
             pts, k = pts[:, : K - 7], k[:, : K - 7]
+        if kp_map and c in kp_map:  # ragged keypoint counts per chunk (ALIKED on low-texture frames)
+            pts, k = pts[:, : kp_map[c]], k[:, : kp_map[c]]
         chunks.append(dict(points=torch.from_numpy(pts), keypoints=torch.from_numpy(k),
                            masks=torch.ones(n, pts.shape[1], 1, dtype=torch.bool), camera_poses=torch.from_numpy(poses)))
         M = np.eye(4); M[:3, :3] = s * R; M[:3, 3] = t
@@ -117,16 +119,31 @@ def _oracle_solver(ov, cl):
     return solve
 
 
-def _wave_worker(rank, world, port, n_chunks, cl, ov, K, bad, q, last_n=None, few_kp=None):
+def _shape_checking(solve, raise_on_chunk_with_kp=None):
+    """The device solver's preconditions (ops.sim3_match_keypoints asserts kp_ref.shape == kp_qry.shape) on top of the
+    oracle solver; optionally a solver that raises for one chunk (recognised by its keypoint count)."""
+    def checked(prev, cur):
+        assert prev["tail"]["keypoints"].shape == cur["head"]["keypoints"].shape, \
+            (prev["tail"]["keypoints"].shape, cur["head"]["keypoints"].shape)
+        if raise_on_chunk_with_kp is not None and int((cur["head"]["keypoints"][0, :, 0] > -0.5).sum()) == raise_on_chunk_with_kp:
+            raise RuntimeError("solver failure injected by the test")
+        return solve(prev, cur)
+    return checked
+
+
+def _wave_worker(rank, world, port, n_chunks, cl, ov, K, bad, q, last_n=None, few_kp=None, kp_map=None, raise_kp=None):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     torch.set_num_threads(1)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from pi3_slam_amd.dist import WaveAligner
-    chunks, _ = _synthetic_chunks(n_chunks, cl, ov, K, bad, last_n, few_kp)
+    chunks, _ = _synthetic_chunks(n_chunks, cl, ov, K, bad, last_n, few_kp, kp_map)
     # the product's wave driver (sizes all-gather, boundary all-gather, own solve, 136-byte all-gather, prefix product)
     # with the CPU oracle standing in for the HIP solver
-    aligner = WaveAligner(rank, world, ov, cl, "cpu", solve=_oracle_solver(ov, cl))
+    solve = _oracle_solver(ov, cl)
+    if kp_map is not None:
+        solve = _shape_checking(solve, raise_kp)
+    aligner = WaveAligner(rank, world, ov, cl, "cpu", solve=solve)
     Gall, okall = [], []
     for w0 in range(0, n_chunks, world):
         c = w0 + rank
@@ -213,6 +230,63 @@ def test_align_wave_world8_two_waves_restart_on_wave_boundary_and_ragged_keypoin
     for c in range(n_chunks):
         want = sims[c] if c < bad else np.linalg.inv(sims[bad]) @ sims[c]
         np.testing.assert_allclose(G[c], want, atol=3e-2)
+
+
+@pytest.mark.parametrize("kp_map,raise_kp", [({2: 20, 3: 20, 4: 26}, None), ({2: 40, 3: 36}, None), ({2: 20, 3: 21, 4: 22}, 21)])
+def test_wave_keypoint_count_changes_between_waves(kp_map, raise_kp):
+    """ADVICE r3 (dist.py:268): the block carried from wave w into wave w + 1 was packed with wave w's K.  With ragged
+    keypoint counts the next wave's K differs - smaller ({2: 20, 3: 20}: the wave must not shrink below the carried
+    block) or larger ({2: 40, ...}: the carried block must be widened) - and the device solver's shape check raised on
+    rank 0 only, BEFORE the 136-byte all-gather, leaving every other rank blocked in it.  K is now run-wide and the
+    carried block is re-padded; a solver that still raises (third case: injected for chunk 3) yields a 'rejected'
+    record instead of a missing collective.  Results equal the sequential composition."""
+    import numpy as np
+    world, n_chunks, cl, ov, K = 2, 5, 8, 3, 30
+    kmax = max(K, max(kp_map.values()))
+    full = {c: K for c in range(n_chunks)}
+    full.update(kp_map)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_wave_worker, args=(r, world, port, n_chunks, cl, ov, kmax, None, q, None, None, full, raise_kp))
+             for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=180) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert np.array_equal(res[0][1], res[1][1]) and res[0][2] == res[1][2]
+    G, oks = res[0][1], res[0][2]
+    from pi3_slam_amd.dist import pack_boundary, unpack_boundary
+    chunks, sims = _synthetic_chunks(n_chunks, cl, ov, kmax, kp_map=full)
+    assert [int(ch["keypoints"].shape[1]) for ch in chunks] == [full[c] for c in range(n_chunks)]
+    solve = _oracle_solver(ov, cl)
+    blocks = [unpack_boundary(pack_boundary(ch, ov, kmax), ov, kmax) for ch in chunks]
+    bad = [c for c in range(n_chunks) if raise_kp is not None and full[c] == raise_kp]
+    Gseq = [np.eye(4)]
+    for c in range(1, n_chunks):
+        r = solve(blocks[c - 1], blocks[c])
+        Gseq.append(Gseq[-1] @ r[1:].numpy().reshape(4, 4) if (r[0] > 0.5 and c not in bad) else np.eye(4))
+    np.testing.assert_allclose(G, np.stack(Gseq), rtol=1e-12, atol=1e-12)
+    assert oks == [c not in bad for c in range(n_chunks)]
+
+
+def test_repad_tail():
+    from pi3_slam_amd.dist import pack_boundary, repad_tail, unpack_boundary
+    g = torch.Generator().manual_seed(1)
+    n, K, ov = 6, 5, 3
+    ch = dict(points=torch.randn(n, K, 3, generator=g).half(), keypoints=(torch.rand(n, K, 2, generator=g) * 300).half(),
+              masks=torch.ones(n, K, 1, dtype=torch.bool), camera_poses=torch.randn(n, 4, 4, generator=g))
+    b = unpack_boundary(pack_boundary(ch, ov, K), ov, K)
+    wide = repad_tail(b, 9)
+    want = unpack_boundary(pack_boundary(ch, ov, 9), ov, 9)
+    for k in ("keypoints", "points", "masks"):
+        assert torch.equal(wide["tail"][k], want["tail"][k]), k
+    assert wide["n_frames"] == b["n_frames"] and torch.equal(wide["last_pose"], b["last_pose"])
+    assert repad_tail(b, K) is b
+    with pytest.raises(ValueError):
+        repad_tail(b, K - 1)
 
 
 def test_pack_boundary_pads_a_chunk_with_fewer_keypoints():

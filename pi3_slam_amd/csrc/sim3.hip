@@ -94,6 +94,17 @@ __device__ __forceinline__ bool pair_get(const PairSrc& s, int i, double x[3], d
   return true;
 }
 
+// Distance of a ref point from the last ref camera, with the reference's rounding points: np.linalg.norm(x, axis=1)
+// (reconstruction_alignment.py:80,83) is sqrt(add.reduce(x * x, axis=1)) - three rounded squares, then the sequential
+// sum (x0^2 + x1^2) + x2^2, no fused multiply-add.  The library is built with -ffp-contract=fast, which turned this into
+// fma(dz, dz, fma(dy, dy, dx * dx)): distances, and with them the median, differed from numpy's in the last bit on
+// about one pair in a few hundred (found by the shipping-size tests, round 4: 4 of 32 medians off by one ulp) - and a
+// strict '<' against the median can then keep or drop a different pair.
+__device__ __forceinline__ double ref_cam_dist(const double y[3], const double cam[3]) {
+  const double dx = y[0] - cam[0], dy = y[1] - cam[1], dz = y[2] - cam[2];
+  return sqrt(__dadd_rn(__dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy)), __dmul_rn(dz, dz)));
+}
+
 // k-th smallest (0-based) of the non-negative doubles dist(i), by 8-pass radix select on their bit patterns
 __device__ double select_rank(const PairSrc& s, const double cam[3], int M, unsigned k, unsigned* hist,
                               unsigned long long* s_prefix, unsigned* s_k, int tid) {
@@ -106,8 +117,7 @@ __device__ double select_rank(const PairSrc& s, const double cam[3], int M, unsi
     for (int i = tid; i < M; i += 1024) {
       double x[3], y[3], w;
       if (!pair_get(s, i, x, y, w)) continue;
-      const double dx = y[0] - cam[0], dy = y[1] - cam[1], dz = y[2] - cam[2];
-      const unsigned long long key = (unsigned long long)__double_as_longlong(sqrt(dx * dx + dy * dy + dz * dz));
+      const unsigned long long key = (unsigned long long)__double_as_longlong(ref_cam_dist(y, cam));
       if ((key & pmask) == prefix) atomicAdd(&hist[(key >> (8 * pass)) & 255ull], 1u);
     }
     __syncthreads();
@@ -163,8 +173,7 @@ __global__ __launch_bounds__(1024) void sim3_umeyama_kernel(PairSrc s, const flo
   for (int i = tid; i < M; i += 1024) {
     double x[3], y[3], w;
     if (!pair_get(s, i, x, y, w)) continue;
-    const double dx = y[0] - cam[0], dy = y[1] - cam[1], dz = y[2] - cam[2];
-    if (use_filter && !(sqrt(dx * dx + dy * dy + dz * dz) < med)) continue;
+    if (use_filter && !(ref_cam_dist(y, cam) < med)) continue;
     a[0] += 1.0;
     a[7] += w;
     for (int c = 0; c < 3; ++c) { a[1 + c] += w * x[c]; a[4 + c] += w * y[c]; }
@@ -192,8 +201,7 @@ __global__ __launch_bounds__(1024) void sim3_umeyama_kernel(PairSrc s, const flo
   for (int i = tid; i < M; i += 1024) {
     double x[3], y[3], w;
     if (!pair_get(s, i, x, y, w)) continue;
-    const double dx = y[0] - cam[0], dy = y[1] - cam[1], dz = y[2] - cam[2];
-    if (use_filter && !(sqrt(dx * dx + dy * dy + dz * dz) < med)) continue;
+    if (use_filter && !(ref_cam_dist(y, cam) < med)) continue;
     const double xc[3] = {x[0] - mx[0], x[1] - mx[1], x[2] - mx[2]};
     const double yc[3] = {y[0] - my[0], y[1] - my[1], y[2] - my[2]};
     for (int r = 0; r < 3; ++r)
@@ -235,8 +243,7 @@ __global__ __launch_bounds__(1024) void sim3_umeyama_kernel(PairSrc s, const flo
   for (int i = tid; i < M; i += 1024) {
     double x[3], y[3], w;
     if (!pair_get(s, i, x, y, w)) continue;
-    const double dx = y[0] - cam[0], dy = y[1] - cam[1], dz = y[2] - cam[2];
-    if (use_filter && !(sqrt(dx * dx + dy * dy + dz * dz) < med)) continue;
+    if (use_filter && !(ref_cam_dist(y, cam) < med)) continue;
     double e2 = 0.0;
     for (int r = 0; r < 3; ++r) {
       const double p = sh[10] * (sh[3 * r] * x[0] + sh[3 * r + 1] * x[1] + sh[3 * r + 2] * x[2]) + sh[11 + r] - y[r];

@@ -96,7 +96,11 @@ def test_full_model_mid_size_through_the_shipped_kernels(full_engine):
     assert (out["local_points"][..., 2] > 0).all()
 
 
-MASK_FLIPS_MEASURED = 0.015      # placeholder until the first round-4 GPU run prints the figure
+# Measured on MI355X (round 4, gpurun_out/r4a/new_tests.log): 0 of the 13 160 keypoint masks of chunk_mid differ from the
+# reference's fp32 run.  The gate allows 2x the measured figure with a floor of 0.1 % (13 keypoints): a mask flips when a
+# bf16-perturbed confidence or depth ratio crosses its threshold, which another card or a kernel change may produce
+MASK_FLIPS_MEASURED = 0.0
+MASK_FLIPS_FLOOR = 1e-3
 
 
 def test_chunk_dictionary_against_the_reference_chunk_creator(full_engine):
@@ -142,9 +146,8 @@ def test_chunk_dictionary_against_the_reference_chunk_creator(full_engine):
     assert d.mean().item() <= 2.0 * anchors["bf16err_camera_poses"][0] and d.max().item() <= 2.0 * anchors["bf16err_camera_poses"][1]
     mism = (res["masks"] != torch.from_numpy(g["masks"])).float().mean().item()
     print(f"chunk_mid mask flips vs the reference's fp32 run: {mism:.5f} of {res['masks'].numel()} keypoints")
-    # sigmoid(conf) > 0.1 and the 3 % depth-edge test threshold bf16-perturbed maps.  Measured on MI355X (round 4,
-    # gpurun_out/r4a): MASK_FLIPS_MEASURED of the 13 160 keypoint masks differ; the gate is 2x that.
-    assert mism <= 2.0 * MASK_FLIPS_MEASURED, mism
+    # sigmoid(conf) > 0.1 and the 3 % depth-edge test threshold bf16-perturbed maps (round 3 allowed 3 %)
+    assert mism <= max(2.0 * MASK_FLIPS_MEASURED, MASK_FLIPS_FLOOR), mism
     K_ref, K_got = torch.from_numpy(g["intrinsics"]), res["intrinsics"]
     assert torch.equal(K_got[:, [0, 1], 2], K_ref[:, [0, 1], 2])                       # cx = W // 2, cy = H // 2
     # fx, fy come from a least-squares focal / shift fit of each frame's point map.  A recipe-weight map is not what a

@@ -3,6 +3,7 @@
 #include "common.h"
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 static thread_local char g_err[512] = "";
@@ -36,6 +37,59 @@ int pi3_lds_optin(const void* kern, int bytes, unsigned long long* done_mask, co
     return PI3_ERR_LAUNCH;
   }
   __atomic_fetch_or(done_mask, bit, __ATOMIC_RELAXED);
+  return PI3_OK;
+}
+
+// Run-time A/B knobs (all of them select CORRECT variants; speed only).  A knob's value is what pi3_set_knob() last
+// stored, else the environment variable PI3_<NAME IN UPPER CASE> read once, else the caller's default.  The tools under
+// tools/ use pi3_set_knob to interleave variants inside one process (perf deltas of a few per cent are only resolvable
+// that way: the cards of the pool differ by +-4 %).
+namespace {
+struct Knob { char name[32]; long value; int state; };   // state 0: free, 1: resolved "unset" (use the default), 2: has a value
+Knob g_knobs[64];
+int g_knob_lock = 0;
+struct KnobGuard {
+  KnobGuard() { while (__atomic_exchange_n(&g_knob_lock, 1, __ATOMIC_ACQUIRE)) {} }
+  ~KnobGuard() { __atomic_store_n(&g_knob_lock, 0, __ATOMIC_RELEASE); }
+};
+Knob* knob_slot(const char* name) {
+  for (auto& k : g_knobs) {
+    if (k.state && strncmp(k.name, name, sizeof(k.name)) == 0) return &k;
+    if (!k.state) {
+      strncpy(k.name, name, sizeof(k.name) - 1);
+      char env[48] = "PI3_";
+      size_t i = 4;
+      for (const char* c = name; *c && i + 1 < sizeof(env); ++c, ++i) env[i] = (*c >= 'a' && *c <= 'z') ? *c - 32 : *c;
+      env[i] = 0;
+      const char* e = getenv(env);
+      k.state = e ? 2 : 1;
+      k.value = e ? atol(e) : 0;
+      return &k;
+    }
+  }
+  return nullptr;
+}
+}  // namespace
+
+long pi3_knob(const char* name, long dflt) {
+  KnobGuard g;
+  Knob* k = knob_slot(name);
+  return (k && k->state == 2) ? k->value : dflt;
+}
+
+extern "C" int pi3_set_knob(const char* name, long value) {
+  if (!name || !*name || strlen(name) >= sizeof(Knob::name)) {
+    pi3_set_error("pi3_set_knob: bad knob name");
+    return PI3_ERR_ARG;
+  }
+  KnobGuard g;
+  Knob* k = knob_slot(name);
+  if (!k) {
+    pi3_set_error("pi3_set_knob: knob table full");
+    return PI3_ERR_ARG;
+  }
+  k->value = value;
+  k->state = 2;
   return PI3_OK;
 }
 

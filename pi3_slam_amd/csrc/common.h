@@ -30,6 +30,7 @@ int pi3_check_launch(const char* what);
 // Opt `kern` into `bytes` of dynamic LDS (above the 64 KB default) on the CURRENT device, once per device: the attribute
 // is per device, so `done_mask` (one function-local static per kernel instance) carries one bit per device ordinal.
 // Returns PI3_OK or PI3_ERR_LAUNCH with the runtime's message in pi3_last_error().
+long pi3_knob(const char* name, long dflt);   // run-time A/B knob (api.hip): pi3_set_knob value, else env PI3_<NAME>, else dflt
 int pi3_lds_optin(const void* kern, int bytes, unsigned long long* done_mask, const char* what);
 
 __device__ __forceinline__ float bf16_bits_to_f32(uint16_t b) {
@@ -69,20 +70,61 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   return base + idx;
 }
 
-// GELU(erf) = 0.5 x (1 + erf(x / sqrt 2)) (nn.GELU default, pi3/models/dinov2/layers/mlp.py:36).  erf by Abramowitz-Stegun
-// 7.1.26 (|abs error| <= 1.5e-7, far below the bf16 / fp32-accumulate noise of the GEMM feeding it): one v_rcp, one
-// v_exp and five FMAs instead of the ~40-instruction branchy libm erff, which made the fc1 epilogue cost 70 % of its GEMM.
+// GELU(erf) = 0.5 x (1 + erf(x / sqrt 2)) = x Phi(x) (nn.GELU default, pi3/models/dinov2/layers/mlp.py:36).
+//
+// Round-4 form: with q = Phi(-|x|) the function is  relu(x) - |x| q  on both sides of zero, and log2 q is smooth, so
+//   q = exp2(P8(|x|)),   P8 = degree-8 minimax fit of log2 Phi(-t) on [0, 5]  (max error 1.85e-6 in log2, i.e. 1.3e-6
+//   RELATIVE in q: no 1 + erf cancellation in the negative tail, where fp32 erf formulas lose all digits)
+// 8 FMAs + one v_exp_f32 + max + fma: no v_rcp, and the FMAs pack (v_pk_fma_f32) - 9.5 issue slots per element where
+// the Abramowitz-Stegun form below takes 14.5; the fc1 epilogue runs with the matrix pipe idle, so VALU issue is its
+// critical path.  Beyond t = 5 the polynomial keeps falling (leading coefficient < 0; checked to t = 40,
+// then -inf), so q -> 0 and y -> relu(x) with no clamp; NaN in -> NaN out; +inf -> NaN (inf * 0), the erf form gives inf.
+// Accuracy (tools/dev_gelu.py, 1e7 samples, bf16(y) against bf16 of the fp64 truth x Phi(x)): 9.6e-5 of N(0, 1) samples
+// differ (torch's own fp32 gelu: 9.3e-5 - the floor set by fp32 rounding), 1.1e-3 of N(0, 2) samples (torch fp32: 1.8e-2,
+// the A-S form: 1.4e-2); against bf16(torch fp32 gelu) on N(0, 1): 1.8e-4 (A-S form 1.3e-4), i.e. 99.98 % identical.
+// Two elements at a time: written on <2 x float> so that the eight Horner steps and the final step are v_pk_fma_f32
+// (hipcc's SLP pass packs the Abramowitz-Stegun form's independent multiplies by itself but leaves a chain of fmaf()
+// calls scalar: 1 024 v_fma_f32 per tile instead of 512 v_pk_fma_f32).
+__device__ __forceinline__ f32x2 gelu_erf2(f32x2 x) {
+  const f32x2 t = __builtin_elementwise_abs(x);
+  f32x2 p = (f32x2)(-2.927687888e-07f);
+  p = __builtin_elementwise_fma(p, t, (f32x2)(4.067300779e-06f));
+  p = __builtin_elementwise_fma(p, t, (f32x2)(1.347436773e-05f));
+  p = __builtin_elementwise_fma(p, t, (f32x2)(-7.274326053e-04f));
+  p = __builtin_elementwise_fma(p, t, (f32x2)(8.036931977e-03f));
+  p = __builtin_elementwise_fma(p, t, (f32x2)(-5.337347835e-02f));
+  p = __builtin_elementwise_fma(p, t, (f32x2)(-4.588178992e-01f));
+  p = __builtin_elementwise_fma(p, t, (f32x2)(-1.151171446e+00f));
+  p = __builtin_elementwise_fma(p, t, (f32x2)(-9.999981523e-01f));
+  f32x2 q, r;
+  q[0] = __builtin_amdgcn_exp2f(p[0]);
+  q[1] = __builtin_amdgcn_exp2f(p[1]);
+  r[0] = fmaxf(x[0], 0.0f);
+  r[1] = fmaxf(x[1], 0.0f);
+  return __builtin_elementwise_fma(t, -q, r);        // the negation folds into the instruction's neg modifiers
+}
+__device__ __forceinline__ f32x4 gelu_erf4(f32x4 v) {
+  const f32x2 a = gelu_erf2((f32x2){v[0], v[1]}), b = gelu_erf2((f32x2){v[2], v[3]});
+  return (f32x4){a[0], a[1], b[0], b[1]};
+}
 __device__ __forceinline__ float gelu_erf(float x) {
-#ifdef PI3_GELU_OLD_FORM
-  const float ax = fabsf(x) * 0.70710678118654752440f;
-  const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * ax);
-  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
-  const float e = __builtin_amdgcn_exp2f(-ax * ax * 1.44269504088896340736f);
-  const float erf_abs = 1.0f - poly * e;
-  return 0.5f * x * (1.0f + copysignf(erf_abs, x));
-#else
-  // the same formula with the constants folded and the sign handled by x * erf(x / sqrt 2) = |x| erf(|x| / sqrt 2):
-  // 0.5 x (1 + erf) = hx + |hx| erf_abs with hx = x / 2 - no copysign, 11 regular vector operations instead of 14
+  const float t = fabsf(x);
+  float p = -2.927687888e-07f;
+  p = fmaf(p, t, 4.067300779e-06f);
+  p = fmaf(p, t, 1.347436773e-05f);
+  p = fmaf(p, t, -7.274326053e-04f);
+  p = fmaf(p, t, 8.036931977e-03f);
+  p = fmaf(p, t, -5.337347835e-02f);
+  p = fmaf(p, t, -4.588178992e-01f);
+  p = fmaf(p, t, -1.151171446e+00f);
+  p = fmaf(p, t, -9.999981523e-01f);
+  const float q = __builtin_amdgcn_exp2f(p);
+  return fmaf(-t, q, fmaxf(x, 0.0f));
+}
+
+// The round 1-3 form (Abramowitz-Stegun 7.1.26, |abs error of erf| <= 1.5e-7; one v_rcp, one v_exp and 11 regular vector
+// operations): kept as the A/B partner of the form above (knob gelu_form = 1 in gemm256.hip; both are correct GELUs).
+__device__ __forceinline__ float gelu_erf_as(float x) {
   const float ax = fabsf(x);
   const float t = __builtin_amdgcn_rcpf(fmaf(ax, 0.3275911f * 0.70710678118654752440f, 1.0f));
   const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
@@ -90,5 +132,4 @@ __device__ __forceinline__ float gelu_erf(float x) {
   const float e = __builtin_amdgcn_exp2f(-z * z);
   const float hx = 0.5f * x;
   return fmaf(fabsf(hx), 1.0f - poly * e, hx);
-#endif
 }

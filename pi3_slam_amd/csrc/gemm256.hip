@@ -238,10 +238,14 @@ __device__ __forceinline__ void g2_epilogue_lds(const GemmParams& p, f32x4 (&acc
 #pragma unroll
       for (int ni = 0; ni < 4; ++ni) {
         f32x4 v = acc[ni][mi] + bias4[ni];
-        if (n_base + ni * 16 + nq < p.qcols) v *= p.qscale;
+        // qcols is a multiple of 64 (whole heads of q), so the test is the same for every lane of the wave: a scalar
+        // branch instead of a compare + four selects + two packed multiplies per tile in every bf16 epilogue
+        if (n_base + ni * 16 < p.qcols) v *= p.qscale;
         if constexpr (ACT == 1) {
+          v = gelu_erf4(v);
+        } else if constexpr (ACT == 3) {      // the round 1-3 GELU form (A/B partner, knob gelu_form = 1)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+          for (int r = 0; r < 4; ++r) v[r] = gelu_erf_as(v[r]);
         } else if constexpr (ACT == 2) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
@@ -367,6 +371,16 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
       }
       __syncthreads();
     }
+  }
+
+  // Start stagger (knob gemm_stagger_ns, default 0): workgroup b begins b * stagger_ns late, so that the workgroups'
+  // epilogues (HBM-rate store / read-modify-write bursts with the matrix pipe idle) do not all fall into the same
+  // window.  The persistent grid walks tiles b, b + grid, ...: the highest-numbered workgroups have one tile fewer, so
+  // a delay of up to one tile time on them costs nothing at the tail.
+  if (p.stagger_ns > 0) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();               // 100 MHz
+    const unsigned long long ticks = (unsigned long long)blockIdx.x * (unsigned)p.stagger_ns / 10ull;
+    while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(4);
   }
 
   // Persistent form: the grid is one workgroup per CU (a multiple of 8, so a workgroup stays on its XCD) and every
@@ -512,6 +526,23 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
   }
 #elif G2_TWO_PHASE == 1
   // (simple form: the four-phase staging schedule with phases a+b and c+d merged)
+  // Residual touch (knob gemm_rpref, f32 output + residual, no row remap): the epilogue's residual read is the one
+  // HBM stream of this kernel that does not depend on the accumulators.  During K tiles nk-6 .. nk-3 every lane loads
+  // ONE dword of one 128-byte line of the wave's 128 x 64 residual block (256 lines = 4 instructions per wave) into a
+  // register nobody reads, which pulls the lines into L2 / the memory-side cache while HBM is idle under the MFMAs.  The
+  // loads are issued right AFTER phase cd's counted wait, so the next counted wait (vmcnt(4) one K tile later, which
+  // must retire the act halves issued after them) finds them a whole K tile old; the register stays reserved ("+v")
+  // until the last tile's vmcnt(0).
+  unsigned pf_sink = 0;
+  const char* pf_ptr = nullptr;
+  if constexpr (!OUT_BF16 && !NOEPI) {
+    if (p.rpref && p.resid && p.rpg == 0) {
+      int prow = bm * G2_BM + wm * 128 + (lane >> 1);
+      prow = prow < p.M ? prow : p.M - 1;
+      pf_ptr = (const char*)(p.resid + (long)prow * p.ldr + bn * G2_BN + wn * 64 + (lane & 1) * 32);
+    }
+  }
+  const long pf_step = 32l * p.ldr * 4;       // instruction i covers rows 32 i .. 32 i + 31 of the wave's block
   for (int u = 0; u < nk; ++u) {
     const char* bp = smem + (u & 1) * G2_BUF;
     const bool pre1 = (u + 1 < nk), pre2 = (u + 2 < nk);
@@ -532,12 +563,21 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
+    if constexpr (!OUT_BF16 && !NOEPI) {
+      const int pi = u - (nk - 6);
+      if (pf_ptr && pi >= 0 && pi < 4) {       // wave-uniform
+        long off = pi * pf_step;
+        if (bm * G2_BM + wm * 128 + pi * 32 + 31 >= p.M) off = 0;    // last row panel: stay inside the matrix
+        asm volatile("global_load_dword %0, %1, off" : "+v"(pf_sink) : "v"(pf_ptr + off) : "memory");
+      }
+    }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     PHASE_MID()
     MFMA_Q(1, 1)
     MFMA_Q(1, 0)
     PHASE_END()
   }
+  asm volatile("" ::"v"(pf_sink));
 #else
   for (int u = 0; u < nk; ++u) {
     const char* bp = smem + (u & 1) * G2_BUF;
@@ -754,6 +794,7 @@ static int launch3(const GemmParams& p, hipStream_t stream) {
 // Used by pi3_gemm (gemm.hip) for bf16 operands when N % 256 == 0 and M is large.  Returns 1 if not applicable.
 int pi3_gemm256_try(const GemmParams& p, int out_dtype, int act, hipStream_t stream) {
   if ((p.N % G2_BN) != 0 || (p.K % 64) != 0 || p.M < 1024) return 1;
+  if (p.qcols % 16) return 1;          // the bf16 epilogue tests n < qcols per 16-column tile (wave-uniform)
   if (out_dtype == 0 && (p.resid || p.addtab)) return 1;   // the bf16 streaming pass carries no residual / table add
   static int gm_knob = -1;   // PI3_GEMM_GM: m-tiles per scheduling group (A/B knob; any value gives the same results)
   if (gm_knob < 0) {
@@ -771,6 +812,10 @@ int pi3_gemm256_try(const GemmParams& p, int out_dtype, int act, hipStream_t str
     order_knob = e ? atoi(e) : -1;
   }
   const_cast<GemmParams&>(p).tile_order = order_knob >= 0 ? order_knob : (p.N / G2_BN <= 4 ? 1 : 0);
+  // run-time knobs (pi3_set_knob / PI3_GEMM_STAGGER_NS, PI3_GEMM_RPREF, PI3_GELU_FORM): see the kernel
+  const_cast<GemmParams&>(p).stagger_ns = (int)pi3_knob("gemm_stagger_ns", 0);
+  const_cast<GemmParams&>(p).rpref = (int)pi3_knob("gemm_rpref", 0);
+  if (act == 1 && pi3_knob("gelu_form", 0) == 1) act = 3;
   static int impl3 = -1;     // PI3_GEMM_IMPL=3: the two-workgroups-per-CU 128x256 kernel for every large GEMM (A/B knob)
   if (impl3 < 0) {
     const char* e = getenv("PI3_GEMM_IMPL");
@@ -785,7 +830,7 @@ int pi3_gemm256_try(const GemmParams& p, int out_dtype, int act, hipStream_t str
   }
   if (impl3 && (p.K % 32) == 0) {
     if (out_dtype == 0 && act == 0) return launch3<true, 0>(p, stream);
-    if (out_dtype == 0 && act == 1) return launch3<true, 1>(p, stream);
+    if (out_dtype == 0 && (act == 1 || act == 3)) return launch3<true, 1>(p, stream);
     if (out_dtype == 1 && act == 0) return launch3<false, 0>(p, stream);
   }
 #ifdef PI3_DEV_ABLATIONS   // timing-only variant that writes NOTHING: development builds only
@@ -806,10 +851,11 @@ int pi3_gemm256_try(const GemmParams& p, int out_dtype, int act, hipStream_t str
   if (stag) {
     if (out_dtype == 0 && act == 0) return launch256<true, 0, false, true>(p, stream);
     if (out_dtype == 0 && act == 1) return launch256<true, 1, false, true>(p, stream);
+    if (out_dtype == 0 && act == 3) return launch256<true, 3, false, true>(p, stream);
     if (out_dtype == 1 && act == 0) return launch256<false, 0, false, true>(p, stream);
   }
   if (out_dtype == 0 && act == 0) return launch256<true, 0>(p, stream);
-  if (out_dtype == 0 && act == 1) return launch256<true, 1>(p, stream);
+  if (out_dtype == 0 && (act == 1 || act == 3)) return launch256<true, 1>(p, stream);
   if (out_dtype == 1 && act == 0) return launch256<false, 0>(p, stream);
   return 1;
 }

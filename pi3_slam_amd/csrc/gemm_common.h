@@ -18,6 +18,8 @@ struct GemmParams {
   int cH, cW, cC;
   int tile_gm;               // gemm256: m-tiles per scheduling group (0 = default 8); consecutive ids walk a group's m-tiles
   int tile_order;            // gemm256: 0 = m-tiles first inside a group, 1 = column tiles first
+  int stagger_ns;            // gemm256 (persistent form): workgroup b starts b * stagger_ns later (0 = all at once)
+  int rpref;                 // gemm256, f32 output with a residual: touch the tile's residual lines during the last K tiles
   // fused q/k epilogue of the packed qkv projection (gemm256 only; FlashAttentionRope.forward,
   // pi3/models/layers/attention.py:323-334): columns [0, H*64) = q, [H*64, 2*H*64) = k, rest = v.  For q and k heads:
   // per-head LayerNorm(64) (optional: qk_w != null), RoPE-2D (optional), softmax scale folded into q, and max_s |k|^2
@@ -84,8 +86,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
       f32x4 v = acc[ni][mi] + bias4[ni];
       if (n0 < p.qcols) v *= p.qscale;
       if constexpr (ACT == 1) {
+        v = gelu_erf4(v);
+      } else if constexpr (ACT == 3) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+        for (int r = 0; r < 4; ++r) v[r] = gelu_erf_as(v[r]);
       } else if constexpr (ACT == 2) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);

@@ -59,7 +59,13 @@ SIGNATURES = {
     "pi3_remap_bilinear_u8": [_vp, _i, _i, _i, _vp, _vp, _i, _i, _vp, _vp],
     "pi3_bundle_adjust": [_vp] * 7 + [_i, _i, _d, _i, _vp, _vp, _vp, _d, _d, _vp, _vp, _l, _vp],
     "pi3_ba_outlier_tracks": [_vp] * 5 + [_i, _i, _d, _d, _vp, _vp],
+    "pi3_set_knob": [C.c_char_p, _l],
 }
+
+
+def set_knob(name: str, value: int) -> None:
+    """Run-time A/B knob of the kernel library (speed only; tools/ interleave variants in one process with it)."""
+    check(load(False).pi3_set_knob(name.encode(), int(value)), "pi3_set_knob")
 
 _lib: Optional[C.CDLL] = None
 

@@ -102,7 +102,14 @@ __device__ __forceinline__ bool pair_get(const PairSrc& s, int i, double x[3], d
 // strict '<' against the median can then keep or drop a different pair.
 __device__ __forceinline__ double ref_cam_dist(const double y[3], const double cam[3]) {
   const double dx = y[0] - cam[0], dy = y[1] - cam[1], dz = y[2] - cam[2];
-  return sqrt(__dadd_rn(__dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy)), __dmul_rn(dz, dz)));
+  // HIP's __dmul_rn / __dadd_rn are plain operators and get contracted again, and so does a local `#pragma clang fp
+  // contract(off)` once inlined into a contract=fast caller (checked in the ISA): the products pass through an empty asm,
+  // which the optimiser cannot look through, so each is rounded on its own
+  double a = dx * dx, b = dy * dy, c = dz * dz;
+  asm volatile("" : "+v"(a), "+v"(b), "+v"(c));
+  double s = a + b;
+  asm volatile("" : "+v"(s));
+  return sqrt(s + c);
 }
 
 // k-th smallest (0-based) of the non-negative doubles dist(i), by 8-pass radix select on their bit patterns

@@ -791,6 +791,204 @@ static int launch3(const GemmParams& p, hipStream_t stream) {
   return pi3_check_launch("gemm3");
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Four-wave form (round 4 experiment, knob gemm_4w = 1): the same 256 x 256 x 64 tile, LDS image, swizzle and persistent
+// tile walk, but ONE wave per SIMD, each owning a 128 (m) x 128 (n) block = 8 x 8 MFMA tiles = 256 accumulator registers
+// (the wave may use 512: accumulators in AGPRs).  Why: gemm256_kernel is bound by the LDS port - per K tile its eight
+// waves read 8 x 24 KB of fragments beside the 64 KB the LDS-DMA writes, 2 048 cycles of the 128 B/clk port against 2 048
+// cycles of MFMA.  A 128 x 128 wave block reads (128 + 128) rows x 128 B = 32 KB per wave and K tile: 4 x 32 + 64 = 192 KB
+// per K tile, 1 536 port cycles against the same 2 048 MFMA cycles.  Price: no partner wave to cover a wave's waits, so
+// the K loop is software-pipelined inside the wave: a K tile is two 32-deep halves, the fragments of the NEXT half are
+// read while the 64 MFMAs of the current one run, one barrier per K tile:
+//   half A(u): read frags (u, kk=1);   64 MFMAs on (u, kk=0);   vmcnt(0) [DMA(u+1) landed], lgkmcnt(0);   s_barrier
+//   half B(u): read frags (u+1, kk=0) from the other buffer;   LDS-DMA of tile u+2 into this buffer;   64 MFMAs on (u, kk=1)
+// Hazards: buffer (u & 1) is re-staged after the barrier that follows every wave's last read of it (its kk=1 fragments,
+// returned: lgkmcnt(0) before the barrier); DMA(u+1) is waited for by the issuing wave before the same barrier and read
+// after it.  The LDS-DMA is issued from inline asm (M0 = wave-uniform LDS base), so hipcc's waitcnt pass puts no
+// vmcnt(0) in front of later ds_reads; the only vmcnt waits are the ones written here.
+// ---------------------------------------------------------------------------------------------------------------
+// LDS-DMA with a scalar base and a 32-bit lane offset: one VGPR per staged segment instead of a 64-bit pointer (with
+// 16 segments per wave and K tile the 64-bit pointers were hoisted out of the K loop, spilled, and their scratch reloads
+// brought vmcnt(0) waits in front of every DMA)
+__device__ __forceinline__ void g4_glds16(const char* sbase, unsigned voff, unsigned lds_dst) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_dst)
+               : "memory", "m0");
+}
+
+template <bool OUT_BF16, int ACT, bool QK = false>
+__global__ __launch_bounds__(256) void gemm4w_kernel(GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: LDS-DMA destinations (M0) are SALU arithmetic
+  const int wm = wave >> 1, wn = wave & 1;
+  const int nbm = (p.M + G2_BM - 1) / G2_BM, nbn = p.N / G2_BN;
+  const int nwg = nbm * nbn;
+  const char* Ab = (const char*)p.A;
+  const char* Wb = (const char*)p.W;
+  const long lda_b = p.lda * 2, ldw_b = p.ldw * 2;
+  const int nk = p.K >> 6;
+  const int GM = p.tile_gm > 0 ? p.tile_gm : 8;
+  const int per_group = GM * nbn;
+
+  const int* pos_l = nullptr;
+  const float* cs_l = nullptr;
+  if constexpr (QK) {      // RoPE tables -> LDS once per workgroup (as gemm256_kernel)
+    if (p.qk_pos && p.qk_T * 8 + 16 <= G2_TAB_BYTES) {
+      int* scratch = (int*)(smem + G2_LDS_TOTAL);
+      int* pl = scratch + 4;
+      if (tid == 0) scratch[0] = 0;
+      __syncthreads();
+      int mx = 0;
+      for (int i = tid; i < 2 * p.qk_T; i += 256) {
+        const int v = p.qk_pos[i];
+        pl[i] = v;
+        mx = max(mx, v);
+      }
+      mx = (int)wave_max((float)mx);
+      if (lane == 0) atomicMax(scratch, mx);
+      __syncthreads();
+      const int npos = scratch[0] + 1;
+      const int tab0 = 16 + ((p.qk_T * 8 + 15) & ~15);
+      if (tab0 + npos * 128 <= G2_TAB_BYTES) {
+        float* cl = (float*)(smem + G2_LDS_TOTAL + tab0);
+        for (int i = tid; i < npos * 32; i += 256) cl[i] = p.qk_cs[i];
+        pos_l = pl;
+        cs_l = cl;
+      }
+      __syncthreads();
+    }
+  }
+
+  const int frow = lane & 15;
+  const int swz = (lane >> 1) & 7;
+  const int cq = lane >> 4;
+  const int off0 = ((cq) ^ swz) << 4, off1 = ((cq + 4) ^ swz) << 4;
+  const int a_base = wm * G2_HALF + frow * 128;
+  const int w_base = (2 + wn) * G2_HALF + frow * 128;
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane(
+      (unsigned)(__UINTPTR_TYPE__)((__attribute__((address_space(3))) void*)(smem)));
+
+  for (int vb = blockIdx.x; vb < nwg; vb += gridDim.x) {
+    const int id = xcd_remap(vb, nwg);
+    const int g = id / per_group;
+    const int gm = min(GM, nbm - g * GM);
+    const int rem = id - g * per_group;
+    const int bm = p.tile_order ? g * GM + rem / nbn : g * GM + rem % gm;
+    const int bn = p.tile_order ? rem % nbn : rem / gm;
+
+    f32x4 acc[8][8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // staging offsets of this tile: segment (half h, i) = rows h * 128 + (wave * 4 + i) * 8 .. + 7, lane -> (row, 16-byte chunk)
+    unsigned aoff[8], woff[8];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = (wave * 4 + i) * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((row >> 1) & 7);
+        int ga = bm * G2_BM + h * 128 + row, gw = bn * G2_BN + h * 128 + row;
+        ga = ga < p.M ? ga : p.M - 1;
+        gw = gw < p.N ? gw : p.N - 1;
+        aoff[h * 4 + i] = (unsigned)((long)ga * lda_b + c * 16);
+        woff[h * 4 + i] = (unsigned)((long)gw * ldw_b + c * 16);
+      }
+#define G4_STAGE(U)                                                                                     \
+  {                                                                                                     \
+    const unsigned sb = lds0 + ((U) & 1) * G2_BUF + wave * 4096;                                        \
+    const char* sa = Ab + (long)(U) * 128;                                                              \
+    const char* sw = Wb + (long)(U) * 128;                                                              \
+    _Pragma("unroll") for (int h = 0; h < 2; ++h)                                                       \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                     \
+      g4_glds16(sa, aoff[h * 4 + i], sb + h * G2_HALF + i * 1024);                                      \
+      g4_glds16(sw, woff[h * 4 + i], sb + (2 + h) * G2_HALF + i * 1024);                                \
+    }                                                                                                   \
+  }
+#define G4_READ(FA, FW, BUFP, OFF)                                                         \
+  _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                           \
+    FW[i] = *(const bf16x8*)((BUFP) + w_base + i * 2048 + (OFF));                           \
+    FA[i] = *(const bf16x8*)((BUFP) + a_base + i * 2048 + (OFF));                           \
+  }
+// MFMAs from inline asm with the accumulators constrained to AGPRs ("+a"): left to the builtin, hipcc treats the 512
+// registers as one pool, parks fragments and addresses in AGPRs and shuttles accumulators through v_accvgpr_read / mov in
+// the K loop (seen in the ISA).  With the constraint the 256 accumulators stay in a0-a255 and the 256 VGPRs hold the two
+// fragment sets (128), the staging offsets and the addressing.
+#define G4_MFMA(FA, FW)                                                                     \
+  _Pragma("unroll") for (int i = 0; i < 8; ++i)                                             \
+  _Pragma("unroll") for (int j = 0; j < 8; ++j)                                             \
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[i][j]) : "v"(FW[i]), "v"(FA[j]));
+#define G4_BARRIER()                  \
+  asm volatile("" ::: "memory");      \
+  __builtin_amdgcn_s_barrier();       \
+  asm volatile("" ::: "memory");
+
+    bf16x8 fa0[8], fw0[8], fa1[8], fw1[8];
+    // prologue: tile 0 landed (16 DMA per wave and K tile), tile 1 in flight
+    G4_STAGE(0)
+    if (nk > 1) {
+      G4_STAGE(1)
+      asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    G4_BARRIER()
+    G4_READ(fa0, fw0, smem, off0)
+    for (int u = 0; u < nk; ++u) {
+      const char* bp = smem + (u & 1) * G2_BUF;
+      const char* bq = smem + ((u + 1) & 1) * G2_BUF;
+      // ---- half A
+      G4_READ(fa1, fw1, bp, off1)
+      G4_MFMA(fa0, fw0)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      G4_BARRIER()
+      // ---- half B
+      if (u + 1 < nk) { G4_READ(fa0, fw0, bq, off0) }
+      if (u + 2 < nk) { G4_STAGE(u + 2) }
+      G4_MFMA(fa1, fw1)
+    }
+    // the hazard recogniser does not see into the asm MFMAs: let the last ones retire before the epilogue reads AGPRs
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+    // nobody reads the pipeline buffers after the last barrier: the epilogue may reuse them at once
+    const int m_base = bm * G2_BM + wm * 128, n_base = bn * G2_BN + wn * 128;
+    if constexpr (OUT_BF16) {
+      char* wl = smem + wave * G2_EPI_WAVE;
+      g2_epilogue_lds<OUT_BF16, ACT, QK>(p, *(f32x4(*)[4][8]) & acc[0], m_base, n_base, wl, lane, pos_l, cs_l);
+      g2_epilogue_lds<OUT_BF16, ACT, QK>(p, *(f32x4(*)[4][8]) & acc[4], m_base, n_base + 64, wl, lane, pos_l, cs_l);
+    } else {
+      gemm_epilogue<OUT_BF16, ACT, 8, 8>(p, acc, m_base, n_base, lane);
+    }
+    if (vb + (int)gridDim.x < nwg) { G4_BARRIER() }
+#undef G4_STAGE
+#undef G4_READ
+#undef G4_MFMA
+#undef G4_BARRIER
+  }
+}
+
+template <bool OUT_BF16, int ACT, bool QK = false>
+static int launch4w(const GemmParams& p, hipStream_t stream) {
+  const int nbm = (p.M + G2_BM - 1) / G2_BM, nbn = p.N / G2_BN;
+  auto kern = gemm4w_kernel<OUT_BF16, ACT, QK>;
+  static unsigned long long optin = 0;
+  constexpr int LDS_BYTES = QK ? G2_LDS_QK : G2_LDS_TOTAL;
+  if (int rc = pi3_lds_optin((const void*)kern, LDS_BYTES, &optin, "gemm4w")) return rc;
+  static int ncu = 0;
+  if (!ncu) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+      ncu = prop.multiProcessorCount & ~7;
+    if (ncu <= 0) ncu = 256;
+  }
+  const int nwg = nbm * nbn;
+  hipLaunchKernelGGL(kern, dim3(nwg > ncu ? ncu : nwg), dim3(256), LDS_BYTES, stream, p);
+  return pi3_check_launch("gemm4w");
+}
+
 // Used by pi3_gemm (gemm.hip) for bf16 operands when N % 256 == 0 and M is large.  Returns 1 if not applicable.
 int pi3_gemm256_try(const GemmParams& p, int out_dtype, int act, hipStream_t stream) {
   if ((p.N % G2_BN) != 0 || (p.K % 64) != 0 || p.M < 1024) return 1;
@@ -821,12 +1019,20 @@ int pi3_gemm256_try(const GemmParams& p, int out_dtype, int act, hipStream_t str
     const char* e = getenv("PI3_GEMM_IMPL");
     impl3 = (e && atoi(e) == 3) ? 1 : 0;
   }
+  // the four-wave 128 x 128-per-wave form (round 4 experiment); its LDS-DMA uses 32-bit offsets from the matrix bases
+  const int impl4 = (int)pi3_knob("gemm_4w", 0) && (long)p.M * p.lda * 2 < (1l << 32) && (long)p.N * p.ldw * 2 < (1l << 32);
   if (p.qk_mode) {   // fused q/k head epilogue: bf16 output, no activation, one head per wave column block
     if (out_dtype != 0 || act != 0 || p.gamma || p.rpg || p.N != 3 * p.qk_H * 64 ||
         (p.qk_k2max && p.qk_attnS < 128))
       return 1;
+    if (impl4) return launch4w<true, 0, true>(p, stream);
     if (impl3 && (p.K % 32) == 0) return launch3<true, 0, true>(p, stream);
     return launch256<true, 0, false, true, true>(p, stream);
+  }
+  if (impl4) {
+    if (out_dtype == 0 && act == 0) return launch4w<true, 0>(p, stream);
+    if (out_dtype == 0 && (act == 1 || act == 3)) return launch4w<true, 1>(p, stream);
+    if (out_dtype == 1 && act == 0) return launch4w<false, 0>(p, stream);
   }
   if (impl3 && (p.K % 32) == 0) {
     if (out_dtype == 0 && act == 0) return launch3<true, 0>(p, stream);

@@ -6,8 +6,9 @@ block at M = 64 300, R rounds of N launches per variant, median and min of the p
 Variants (every one computes the same result; the check at the start compares each against variant 0):
   base               shipped defaults
   gelu_as            gelu_form = 1: the round 1-3 Abramowitz-Stegun GELU (fc1 only)
-  stag<N>            gemm_stagger_ns = N: workgroup b starts b * N ns late
-  rpref              gemm_rpref = 1: residual lines touched during the last K tiles (proj, fc2)
+  4w                 gemm_4w = 1: four waves per workgroup, 128 x 128 block per wave, accumulators in AGPRs
+  stag<N>            gemm_stagger_ns = N: workgroup b starts b * N ns late                      (AB_ALL=1)
+  rpref              gemm_rpref = 1: residual lines touched during the last K tiles (proj, fc2) (AB_ALL=1)
 """
 import math
 import os
@@ -23,10 +24,10 @@ torch.manual_seed(0)
 R = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 NL = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 M = 64300
-KNOBS = ("gelu_form", "gemm_stagger_ns", "gemm_rpref")
-VARIANTS = [("base", {}), ("gelu_as", {"gelu_form": 1}), ("stag15", {"gemm_stagger_ns": 15}),
-            ("stag30", {"gemm_stagger_ns": 30}), ("stag60", {"gemm_stagger_ns": 60}), ("stag120", {"gemm_stagger_ns": 120}),
-            ("rpref", {"gemm_rpref": 1}), ("rpref+stag30", {"gemm_rpref": 1, "gemm_stagger_ns": 30})]
+KNOBS = ("gelu_form", "gemm_stagger_ns", "gemm_rpref", "gemm_4w")
+VARIANTS = [("base", {}), ("gelu_as", {"gelu_form": 1}), ("4w", {"gemm_4w": 1})]
+if os.environ.get("AB_ALL"):      # the round-4 experiments that found nothing (profiles/EXPERIMENTS.md)
+    VARIANTS += [("stag30", {"gemm_stagger_ns": 30}), ("stag120", {"gemm_stagger_ns": 120}), ("rpref", {"gemm_rpref": 1})]
 
 
 def set_variant(kn):

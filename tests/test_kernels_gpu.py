@@ -461,3 +461,52 @@ def test_gemm256_repeatable_bitwise(dev, M, N, K, reps):
             assert rel(x, ref)[0] < 1e-4
         else:
             assert torch.equal(o16, first16) and torch.equal(x, first32)
+
+
+@pytest.mark.parametrize("M,N,K", [(5000, 1024, 1024), (3333, 768, 2048)])
+def test_gemm_four_wave_variant_is_bit_identical(dev, M, N, K):
+    """The round-4 four-wave form of the 256 x 256 kernel (knob gemm_4w: one wave per SIMD, 128 x 128 block per wave,
+    accumulators in AGPRs, inline-asm MFMAs and LDS-DMA, one barrier per K tile; slower than the eight-wave form and
+    not the default - profiles/EXPERIMENTS.md) adds the same products in the same order, so every epilogue must give
+    the shipped kernel's bits: bf16, bf16 + GELU, fp32 + LayerScale + residual, the fused q/k epilogue with max|k|^2;
+    repeated launches agree bit for bit (race screen of its hand-placed waits), partial last row tile included."""
+    from pi3_slam_amd import lib, ops
+    a = torch.randn(M, K, device=dev).bfloat16()
+    w = (torch.randn(N, K, device=dev) / math.sqrt(K)).bfloat16()
+    bias, gamma, x0 = torch.randn(N, device=dev), torch.rand(N, device=dev), torch.randn(M, N, device=dev)
+    H, T = N // 192, 643
+    pos = torch.zeros(T, 2, dtype=torch.int32)
+    pos[5:, 0] = (torch.arange(T - 5) // 29 + 1).int()
+    pos[5:, 1] = (torch.arange(T - 5) % 29 + 1).int()
+    pos = pos.to(dev)
+    inv = 1.0 / (100.0 ** (torch.arange(0, 32, 2).float() / 32))
+    cs = torch.stack([(torch.arange(30).float()[:, None] * inv[None]).cos(),
+                      (torch.arange(30).float()[:, None] * inv[None]).sin()], -1).contiguous().to(dev)
+    qw, qb, kw, kb = [(torch.randn(64) * 0.2 + (1 if i % 2 == 0 else 0)).to(dev) for i in range(4)]
+
+    def run_all():
+        o1 = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+        ops.gemm(a, w, o1, bias=bias)
+        o2 = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+        ops.gemm(a, w, o2, bias=bias, act=ops.ACT_GELU)
+        x = x0.clone()
+        ops.gemm(a, w, x, bias=bias, gamma=gamma, resid=x)
+        outs = [o1, o2, x]
+        if N % 192 == 0:
+            qkv = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+            k2 = torch.empty(H, device=dev)
+            ops.gemm_qkv(a, w, qkv, M=M, H=H, bias=bias, T=T, pos=pos, cs=cs, qw=qw, qb=qb, kw=kw, kb=kb, k2max=k2,
+                         attn_B=1, attn_S=M)
+            outs += [qkv, k2]
+        torch.cuda.synchronize()
+        return outs
+    try:
+        lib.set_knob("gemm_4w", 0)
+        base = run_all()
+        lib.set_knob("gemm_4w", 1)
+        for rep in range(3):
+            got = run_all()
+            for i, (g, b) in enumerate(zip(got, base)):
+                assert torch.equal(g, b), (rep, i, (g.float() - b.float()).abs().max().item())
+    finally:
+        lib.set_knob("gemm_4w", 0)

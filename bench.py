@@ -126,6 +126,10 @@ def cpu_baseline(engine_cfg, n_frames: int):
     total = per_frames + per_chunk * n_frames / CL
     return {"reference_in_build_container": REFERENCE_CPU,
             "value": n_frames / total, "unit": "frames/s", "cores": threads, "kind": "port",
+            "like_for_like": "value (this box's host cores, the oracle port over the whole path, measured now) is the figure to "
+                             "set beside the GPU number of the same run; reference_in_build_container is the REAL "
+                             "reference's own code, measured once on the build container's 8 cores - same workload, "
+                             "different host, quoted for scale",
             "sample": f"oracle whole path on {n_frames} frames {H}x{W}, fp32 torch CPU with flash SDPA, {threads} threads: "
                       + ", ".join(f"{k} {v:.2f} s" for k, v in t.items())
                       + f"; per-chunk stages (moge, align) charged x {n_frames}/{CL}; the global attention is quadratic "

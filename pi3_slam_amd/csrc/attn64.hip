@@ -176,7 +176,7 @@ __device__ __forceinline__ void a64_softmax(f32x16 (&sc)[2], float& m, f32x16 (&
 // NW = waves per workgroup (4 or 8): NW * 64 query rows share one staged K/V tile.
 // GLDS: stage K/V with LDS-DMA (global_load_lds, swizzle on the source address) instead of registers + ds_write.
 template <int NW, bool GLDS = false, bool MSUM = false>
-__global__ __launch_bounds__(NW * 64, 2) void attn_fwd64_kernel(Attn64Params p) {
+__global__ __launch_bounds__(NW * 64, (NW == 2 ? 4 : 2)) void attn_fwd64_kernel(Attn64Params p) {
   __shared__ __attribute__((aligned(16))) char lds[32768];  // K ring [2][64][128 B] then V ring [2][64][128 B]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
@@ -246,7 +246,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd64_kernel(Attn64Params p) 
   // 64-bit add each) instead of rebuilding them from the tile index (~17 vector instructions per tile): -5 % on
   // 100 x 643 tokens.  The same change makes the eight-wave kernel 1.3 % SLOWER at S = 64 300 (measured in one
   // process, interleaved: 15.04 against 14.85 ms), so that one keeps the branch-free index form.
-  constexpr bool CARRY = (NW == 4);
+  constexpr bool CARRY = (NW <= 4);
   const long tile_bytes = (long)A64_KT * p.tok_stride * 2;
   const char* kp[CPT];
   const char* vp[CPT];
@@ -286,6 +286,12 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd64_kernel(Attn64Params p) 
       *(u32x4*)(lds + buf * 8192 + vw[i]) = vr[i];
     }
   };
+#ifdef PI3_ATTN_STAMPS
+  // phase stamps of a sample of workgroups (every 37th): [0] entry, [1] tile 0 staged + barrier, [2] key sweep done, [3] stores issued
+  const bool st_on = p.dbg && (blockIdx.x % 37) == 5 && tid == 0 && blockIdx.x / 37 < 100;
+  unsigned long long* st = p.dbg + 1100 + (blockIdx.x / 37) * 4;
+  if (st_on) st[0] = a64_realtime();
+#endif
   if constexpr (GLDS) {
     glds_tile(0, true, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the asm-issued DMA is invisible to the compiler's own waits
@@ -294,6 +300,9 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd64_kernel(Attn64Params p) 
     write_tile(0);
   }
   __syncthreads();
+#ifdef PI3_ATTN_STAMPS
+  if (st_on) st[1] = a64_realtime();
+#endif
 
   const int kswz = (r >> 1) & 7;
   const int krow_off = r * 128;
@@ -403,9 +412,9 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd64_kernel(Attn64Params p) 
 #endif
   // the last tile holds S - 64 (nt - 1) keys: when that is <= 32 its second 32-key half is skipped (frame-wise
   // sequences: 643 = 10 x 64 + 3); long sequences keep one code path (their last tile is one of a thousand)
-  const bool half_last = (NW == 4) && p.tailopt && (S - (nt - 1) * A64_KT <= 32);
+  const bool half_last = (NW <= 4) && p.tailopt && (S - (nt - 1) * A64_KT <= 32);
   // query blocks this wave owns (see A64_TILE); long sequences (NW == 8) keep the single two-block path
-  const int nb = (NW == 4 && p.tailopt) ? (q0 >= S ? 0 : (q0 + 32 >= S ? 1 : 2)) : 2;
+  const int nb = (NW <= 4 && p.tailopt) ? (q0 >= S ? 0 : (q0 + 32 >= S ? 1 : 2)) : 2;
   // bounded-score test (see header): wave-uniform
   bool fast = false;
   if (p.k2max && nb > 0) {
@@ -437,6 +446,9 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd64_kernel(Attn64Params p) 
 #ifdef PI3_ATTN_STAMPS
   if (p.dbg && blockIdx.x == 8 && tid == 0) { p.dbg[1002] = a64_stamp(); p.dbg[1003] = a64_realtime(); p.dbg[1004] = fast; }
 #endif
+#ifdef PI3_ATTN_STAMPS
+  if (st_on) st[2] = a64_realtime();
+#endif
   // finalize both blocks
 #pragma unroll
   for (int blk = 0; blk < 2; ++blk) {
@@ -457,6 +469,9 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd64_kernel(Attn64Params p) 
         }
     }
   }
+#ifdef PI3_ATTN_STAMPS
+  if (st_on) st[3] = a64_realtime();
+#endif
 }
 
 // max over keys of |k|^2 per (batch, head) for the bounded-score test; out must be zeroed (non-negative floats order
@@ -529,8 +544,11 @@ int pi3_attention64_launch(const void* q, const void* k, const void* v, long tok
     nw_knob = e ? atoi(e) : 8;
   }
   // nw_req = 4: the caller (short, frame-wise sequences) wants 256-row workgroups whatever the knob says
-  const int nw = nw_req == 4 ? 4 : nw_knob;
-  const int qrows = nw == 8 ? 512 : 256;
+  // frame-wise sequences (nw_req = 4): knob attn_frame_nw picks four-wave (256 rows, default) or two-wave (128 rows)
+  // workgroups.  643 tokens are 10 full 64-row wave blocks + 3 rows: three four-wave workgroups give 12 wave slots of
+  // which the third workgroup's (2, 2, 1, 0 blocks) last half idles; six two-wave workgroups end in a short one
+  const int nw = nw_req == 4 ? ((int)pi3_knob("attn_frame_nw", 4) == 2 ? 2 : 4) : nw_knob;
+  const int qrows = nw * 64;
   p.S = S; p.H = H; p.B = B; p.nqb = (S + qrows - 1) / qrows;
   const long nwg = (long)p.nqb * H * B;
   static int glds = -1;   // PI3_ATTN_GLDS: 1 = LDS-DMA staging (A/B knob)
@@ -562,6 +580,7 @@ int pi3_attention64_launch(const void* q, const void* k, const void* v, long tok
   static unsigned long long* dbgbuf = nullptr;
   if (!dbgbuf) hipMalloc((void**)&dbgbuf, 2048 * 8);
   hipMemsetAsync(dbgbuf, 0, 2048 * 8, stream);
+  static_assert(1100 + 100 * 4 <= 2048, "phase stamps fit the debug buffer");
   p.dbg = dbgbuf;
 #endif
   if (nomax && k2max_ws) {
@@ -592,6 +611,8 @@ int pi3_attention64_launch(const void* q, const void* k, const void* v, long tok
     hipLaunchKernelGGL((attn_fwd64_kernel<8, true>), dim3((unsigned)nwg), dim3(512), 0, stream, p);
   else if (nw == 8)
     hipLaunchKernelGGL(attn_fwd64_kernel<8>, dim3((unsigned)nwg), dim3(512), 0, stream, p);
+  else if (nw == 2)
+    hipLaunchKernelGGL((attn_fwd64_kernel<2, true, true>), dim3((unsigned)nwg), dim3(128), 0, stream, p);
   else if (glds && msum)   // 4 waves: two independent workgroups per CU, the two waves of a SIMD drift out of phase
     hipLaunchKernelGGL((attn_fwd64_kernel<4, true, true>), dim3((unsigned)nwg), dim3(256), 0, stream, p);
   else
@@ -605,7 +626,13 @@ int pi3_attention64_launch(const void* q, const void* k, const void* v, long tok
       hipMemcpy(hb, dbgbuf, sizeof(hb), hipMemcpyDeviceToHost);
       fprintf(stderr, "STAMPS kernel: cycles %llu realtime(100MHz) %llu fast %llu -> clock %.1f MHz\n", hb[1002] - hb[1000],
               hb[1003] - hb[1001], hb[1004], 100.0 * (double)(hb[1002] - hb[1000]) / (double)(hb[1003] - hb[1001]));
-      for (int w = 0; w < 8; ++w)
+      if (nw <= 4)     // frame-wise launches: per-workgroup phases in 10 ns ticks (s_memrealtime), sampled workgroups
+        for (int k = 0; k < 100 && (long)(37 * k + 5) < nwg; ++k) {
+          const unsigned long long* e = hb + 1100 + 4 * k;
+          fprintf(stderr, "PHASES wg %d start %llu prologue %llu sweep %llu tail %llu (x10 ns)\n", 37 * k + 5, e[0] - hb[1100],
+                  e[1] - e[0], e[2] - e[1], e[3] - e[2]);
+        }
+      for (int w = 0; w < 8 && nw == 8; ++w)
         for (int t = 0; t < 8; ++t) {
           const unsigned long long* e = hb + (w * 8 + t) * 8;
           fprintf(stderr, "STAMPS w%d t%d start %llu qk %llu smpv %llu wait %llu barrier %llu\n", w, t, e[0] - hb[0], e[1] - e[0],

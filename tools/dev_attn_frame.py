@@ -4,7 +4,7 @@ knobs via PI3_ATTN_* (e.g. PI3_ATTN_PRIO=1).  Interleaved rounds in ONE process,
 import math, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from pi3_slam_amd import ops
+from pi3_slam_amd import lib, ops
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
 
@@ -31,6 +31,14 @@ for (B, S, H) in [(100, 643, 16), (100, 645, 16)]:
     print("check", (B, S, H), ((out[:3 * S].float() - r).abs().max() / r.abs().max()).item())
     cases[f"frame S={S} k2max"] = (lambda qkv=qkv, out=out, B=B, S=S, H=H, k2=k2: ops.attention(qkv, out, B, S, H, k2max=k2), 4.0 * B * H * S * S * 64)
     cases[f"frame S={S} online"] = (lambda qkv=qkv, out=out, B=B, S=S, H=H: ops.attention(qkv, out, B, S, H), 4.0 * B * H * S * S * 64)
+
+    def nw2(qkv=qkv, out=out, B=B, S=S, H=H, k2=k2):        # two-wave workgroups (knob attn_frame_nw), same launch otherwise
+        lib.set_knob("attn_frame_nw", 2)
+        ops.attention(qkv, out, B, S, H, k2max=k2)
+        lib.set_knob("attn_frame_nw", 4)
+    nw2()
+    print("check nw2", (B, S, H), ((out[:3 * S].float() - r).abs().max() / r.abs().max()).item())
+    cases[f"frame S={S} k2max nw2"] = (nw2, 4.0 * B * H * S * S * 64)
 B, S, H = 1, 64300, 16
 qkvg = torch.randn(S, 3 * H * 64, device=dev); qkvg[:, :H * 64] *= ops.QSCALE * 2; qkvg = qkvg.bfloat16()
 outg = torch.empty(S, H * 64, device=dev, dtype=torch.bfloat16)

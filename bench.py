@@ -35,11 +35,11 @@ sys.path.insert(0, ROOT)
 CL, OV, SRC_H, SRC_W, H, W, KP = 100, 20, 384, 512, 308, 406, 200
 PEAK_BF16_DENSE_TFLOPS = 2500.0   # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md)
 # HBM-side bytes of ONE global-attention launch, from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this
-# kernel (profiles/r03_attention_pmc.csv, unchanged since profiles/r01c_attention_pmc.csv; tools/pmc_summary.py): FETCH_SIZE 643 128 KB (x2: gfx950 reports half of a
-# wide coalesced read stream) + WRITE_SIZE 128 600 KB.  PMC counters cannot be read from inside this process, so the
+# kernel (profiles/r04_attention_pmc.csv, unchanged since profiles/r01c_attention_pmc.csv; tools/pmc_summary.py): FETCH_SIZE 643 121 KB (x2: gfx950 reports half of a
+# wide coalesced read stream) + WRITE_SIZE 128 601 KB.  PMC counters cannot be read from inside this process, so the
 # JSON cites the committed profile; algorithmic bytes are 527 MB (q, k, v read once + o written), L2 hit rate 95.8 %.
-ATTN_TRAFFIC_BYTES = (2 * 643127.9 + 128600.3) * 1024.0
-ATTN_TRAFFIC_SOURCE = "profiles/r03_attention_pmc.csv"
+ATTN_TRAFFIC_BYTES = (2 * 643120.9 + 128601.3) * 1024.0
+ATTN_TRAFFIC_SOURCE = "profiles/r04_attention_pmc.csv"
 
 
 # the REAL reference (sdpa_kernel context not entered) timed once in the build container (8 Xeon
@@ -432,9 +432,8 @@ def main(args) -> None:
             # what ONE GPU takes for the same step, to cross-check this N-rank line against the N = 1 line: the committed
             # N = 1 record and, live, every rank's own wall time per step and forward time by GPU events (comm.per_rank)
             line["n1_reference_ms_per_step"] = N1_REFERENCE
-        line["second_metric"] = {"metric": "7-Scenes APE", "value": None,
-                                 "note": "not measurable offline: needs the released pi3 / MoGe weights, the dataset and evo "
-                                         "(BASELINE.json; SURVEY.md §8d)"}
+        line["second_metric"] = second_metric(dev) if world == 1 else {
+            "metric": "7-Scenes APE", "value": None, "note": "reported by the N = 1 run"}
         if world == 1 and not args.no_extras:
             with contextlib.redirect_stdout(sys.stderr):
                 line["extras"] = extras(engine, moge, make_creator, run, dev)

@@ -19,7 +19,7 @@ bad = []
 for name, argt in lib.SIGNATURES.items():
     args = []
     for t in argt:
-        if t is ctypes.c_void_p or (hasattr(t, "_type_") and not isinstance(t._type_, str)):
+        if t in (ctypes.c_void_p, ctypes.c_char_p) or (hasattr(t, "_type_") and not isinstance(t._type_, str)):
             args.append(None)
         elif t in (ctypes.c_float, ctypes.c_double):
             args.append(0.0)

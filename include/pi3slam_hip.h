@@ -277,6 +277,18 @@ int pi3_bundle_adjust(double* points, double* poses, const double* intr, const f
                       double sqrt_info_rot, double sqrt_info_pos, double* summary_dev, double* workspace,
                       long workspace_doubles, void* stream);
 
+/* The same adjustment with Theia's DEFAULT point parametrization, which is what the reference's two calls run with
+ * (use_homogeneous_point_parametrization = true is never changed: utils/reconstruction_alignment.py:150-152,
+ * utils/chunk_reconstruction.py:199-204): every track is the 4-vector [X, 1] / |[X, 1]| stepped in the tangent space of
+ * its unit sphere (ceres::HomogeneousVectorParameterization: Householder basis, Plus).  Same objective and optimum as
+ * pi3_bundle_adjust (Euclidean steps); the LM damping acts in different coordinates, so the iterates differ
+ * (tests/test_ba_oracle.py).  Same arguments, same workspace size. */
+int pi3_bundle_adjust_homogeneous(double* points, double* poses, const double* intr, const float* uv,
+                                  const unsigned char* valid, const float* uvT, const unsigned char* validT, int N, int K,
+                                  double huber_width, int max_iters, const double* prior_R, const double* prior_C,
+                                  const unsigned char* prior_flag, double sqrt_info_rot, double sqrt_info_pos,
+                                  double* summary_dev, double* workspace, long workspace_doubles, void* stream);
+
 /* pt.sfm.SetOutlierTracksToUnestimated(tracks, max_reprojection_error_px, min_triangulation_angle_deg)
  * (utils/chunk_reconstruction.py:218, utils/reconstruction_alignment.py:170): estimated[s*K + k] = 1 iff every
  * observation of the track is in front of its camera and within max px, and two viewing rays subtend more than the

@@ -139,8 +139,29 @@ def homogeneous_plus_jacobian(h: np.ndarray) -> np.ndarray:
     return 0.5 * np.linalg.norm(h) * Hh[:, :3]
 
 
+def point_frames(X: np.ndarray) -> np.ndarray:
+    """T (P, 3, 3) = d X / d delta at delta = 0 for every track, h = [X, 1] / |[X, 1]| RE-DERIVED from X (the device does
+    the same each iteration; identical to carrying h while its last component stays positive, which the tests check):
+    T = (d X / d h) (d Plus / d delta) = (1 / w) [I | -X] . 0.5 (I - beta v v^T)[:, :3]."""
+    P = len(X)
+    h = np.concatenate([X, np.ones((P, 1))], 1)
+    h /= np.linalg.norm(h, axis=1, keepdims=True)
+    T = np.zeros((P, 3, 3))
+    for i in range(P):
+        T[i] = (np.concatenate([np.eye(3), -X[i][:, None]], 1) / h[i, 3]) @ homogeneous_plus_jacobian(h[i])
+    return T
+
+
+def points_plus(X: np.ndarray, delta: np.ndarray) -> np.ndarray:
+    """X after the tangent steps delta (P, 3) on the spheres of h = [X, 1] / |[X, 1]|."""
+    h = np.concatenate([X, np.ones((len(X), 1))], 1)
+    h /= np.linalg.norm(h, axis=1, keepdims=True)
+    hn = np.stack([homogeneous_plus(h[i], delta[i]) for i in range(len(X))])
+    return hn[:, :3] / hn[:, 3:4]
+
+
 def bundle_adjust(R, C, intr, X, uv, valid, huber_width: float, max_iters: int, prior: Optional[Dict] = None,
-                  homogeneous: bool = False):
+                  homogeneous: bool = False, carry_h: bool = False):
     """R (N,3,3) world->camera, C (N,3), intr (N,4), X (N*K,3); uv (N,N,K,2), valid (N,N,K).
     Returns refined (R, C, X) and a summary dict.  prior: {'R','C','flag','sqrt_info_rot','sqrt_info_pos'}.
     homogeneous=True: every track is the unit 4-vector h = [X, 1] / |[X, 1]| stepped in the 3-dimensional tangent space
@@ -150,8 +171,8 @@ def bundle_adjust(R, C, intr, X, uv, valid, huber_width: float, max_iters: int, 
     what that changes after the reference's 10 / 50 iterations."""
     R, C, X = R.copy(), C.copy(), X.copy()
     N, P = len(R), len(X)
-    hvec = None
-    if homogeneous:
+    hvec = None              # carry_h: keep the 4-vectors from iteration to iteration as Ceres does (default: re-derive)
+    if homogeneous and carry_h:
         hvec = np.concatenate([X, np.ones((P, 1))], 1)
         hvec /= np.linalg.norm(hvec, axis=1, keepdims=True)
     trk, cam, px = observations(uv, valid)
@@ -162,11 +183,13 @@ def bundle_adjust(R, C, intr, X, uv, valid, huber_width: float, max_iters: int, 
     for _ in range(max_iters):
         r, Jc, Jp, front = residuals(R, C, intr, X, trk, cam, px)
         if homogeneous:      # d r / d delta = (d r / d X) (d X / d h) (d h / d delta),  X = h[:3] / h[3]
-            T = np.zeros((P, 3, 3))
-            for i in range(P):
-                hw = hvec[i, 3]
-                dX_dh = np.concatenate([np.eye(3), -X[i][:, None]], 1) / hw
-                T[i] = dX_dh @ homogeneous_plus_jacobian(hvec[i])
+            if carry_h:
+                T = np.zeros((P, 3, 3))
+                for i in range(P):
+                    dX_dh = np.concatenate([np.eye(3), -X[i][:, None]], 1) / hvec[i, 3]
+                    T[i] = dX_dh @ homogeneous_plus_jacobian(hvec[i])
+            else:
+                T = point_frames(X)
             Jp = np.einsum("mij,mjk->mik", Jp, T[trk])
         _, w = huber((r ** 2).sum(1), huber_width)
         w = w * front
@@ -193,9 +216,11 @@ def bundle_adjust(R, C, intr, X, uv, valid, huber_width: float, max_iters: int, 
         model = -0.5 * g @ d + 0.5 * d @ (D * d)
         Rn = np.stack([exp_so3(d[6 * t:6 * t + 3]) @ R[t] for t in range(N)])
         Cn = C + d[:nc].reshape(N, 6)[:, 3:]
-        if homogeneous:
+        if homogeneous and carry_h:
             hn = np.stack([homogeneous_plus(hvec[i], d[nc + 3 * i: nc + 3 * i + 3]) for i in range(P)])
             Xn = hn[:, :3] / hn[:, 3:4]
+        elif homogeneous:
+            Xn = points_plus(X, d[nc:].reshape(P, 3))
         else:
             Xn = X + d[nc:].reshape(P, 3)
         cnew = total_cost(Rn, Cn, intr, Xn, trk, cam, px, huber_width, prior)
@@ -206,7 +231,7 @@ def bundle_adjust(R, C, intr, X, uv, valid, huber_width: float, max_iters: int, 
             decrease = 2.0
             rel = abs(cost - cnew) / max(cost, 1e-300)
             R, C, X, cost = Rn, Cn, Xn, cnew
-            if homogeneous:
+            if homogeneous and carry_h:
                 hvec = hn
             summary["accepted_steps"] += 1
             if rel < 1e-6:
@@ -229,11 +254,13 @@ def _segsum(idx: np.ndarray, vals: np.ndarray, n: int) -> np.ndarray:
     return out.reshape((n,) + vals.shape[1:])
 
 
-def schur_step(R, C, intr, X, trk, cam, px, K, huber_width, radius, prior):
+def schur_step(R, C, intr, X, trk, cam, px, K, huber_width, radius, prior, homogeneous: bool = False):
     """One damped Gauss-Newton step through the Schur complement on the points.
     -> (ok, dc (N,6), dp (P,3), model_decrease).  ok = False: the reduced system was not positive definite."""
     N, P = len(R), len(X)
     r, Jc, Jp, front = residuals(R, C, intr, X, trk, cam, px)
+    if homogeneous:          # the point columns in the tangent coordinates of the tracks' spheres; dp is then a tangent step
+        Jp = np.einsum("mij,mjk->mik", Jp, point_frames(X)[trk])
     _, w = huber((r ** 2).sum(1), huber_width)
     w = w * front
     B = _segsum(cam, np.einsum("m,mia,mib->mab", w, Jc, Jc), N)            # camera blocks
@@ -280,7 +307,7 @@ def schur_step(R, C, intr, X, trk, cam, px, K, huber_width, radius, prior):
 
 
 def bundle_adjust_schur(R, C, intr, X, uv, valid, huber_width: float, max_iters: int, prior: Optional[Dict] = None,
-                        trace: Optional[list] = None):
+                        trace: Optional[list] = None, homogeneous: bool = False):
     """bundle_adjust() with the linear solve of every iteration done by schur_step; same trust-region rules, same
     summary.  trace (a list) receives one dict per iteration: cost before, candidate cost, accepted, radius, ok."""
     R, C, X = R.copy(), C.copy(), X.copy()
@@ -290,9 +317,9 @@ def bundle_adjust_schur(R, C, intr, X, uv, valid, huber_width: float, max_iters:
     summary = {"initial_cost": cost, "iterations": 0, "accepted_steps": 0, "chol_failures": 0}
     radius, decrease = 1e4, 2.0
     for _ in range(max_iters):
-        ok, dc, dp, model = schur_step(R, C, intr, X, trk, cam, px, K, huber_width, radius, prior)
+        ok, dc, dp, model = schur_step(R, C, intr, X, trk, cam, px, K, huber_width, radius, prior, homogeneous)
         Rn = np.stack([exp_so3(dc[t, :3]) @ R[t] for t in range(N)])
-        Cn, Xn = C + dc[:, 3:], X + dp
+        Cn, Xn = C + dc[:, 3:], (points_plus(X, dp) if homogeneous else X + dp)
         cnew = total_cost(Rn, Cn, intr, Xn, trk, cam, px, huber_width, prior)
         summary["iterations"] += 1
         summary["chol_failures"] += 0 if ok else 1

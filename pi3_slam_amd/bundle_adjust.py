@@ -23,10 +23,12 @@ from . import ops
 # Ceres returns): sanity_gate=False switches it off for reference-parity runs (OfflineReconstructor(ba_sanity_gate=False),
 # `cli reconstruct --no-ba-sanity-gate`); max_camera_move_extents = how many scene extents a camera centre may move;
 # min_surviving_tracks = how many of the tracks that took part must still be estimated.
+# homogeneous_points: Theia's use_homogeneous_point_parametrization, which the reference never changes from its default
+# (true): tracks step in the tangent space of their 4-vector (pi3_bundle_adjust_homogeneous).  False = Euclidean steps.
 PER_CHUNK = dict(max_iters=10, huber_width=2.0, max_reprojection_px=2.0, min_triangulation_angle_deg=0.25,
-                 sanity_gate=True, max_camera_move_extents=1.0, min_surviving_tracks=3)
+                 sanity_gate=True, max_camera_move_extents=1.0, min_surviving_tracks=3, homogeneous_points=True)
 AFTER_ALIGNMENT = dict(max_iters=50, huber_width=3.0, max_reprojection_px=3.0, min_triangulation_angle_deg=0.25,
-                       sanity_gate=True, max_camera_move_extents=1.0, min_surviving_tracks=3)
+                       sanity_gate=True, max_camera_move_extents=1.0, min_surviving_tracks=3, homogeneous_points=True)
 PRIOR_SQRT_INFO_ROT = (1.0 / 2.0) ** 0.5        # orientation prior covariance 2 I (reconstruction_alignment.py:123)
 PRIOR_SQRT_INFO_POS = (1.0 / 25.0) ** 0.5       # position prior covariance 25 I (:127)
 
@@ -142,7 +144,8 @@ def bundle_adjust_chunk(chunk: Dict, W: int, H: int, max_observations_per_track:
                 r = poses_to_rc(P.to(device).reshape(1, 4, 4))[0]
                 pr[v], pc[v], pf[v] = r[:9], r[9:], 1
     summary = ops.bundle_adjust(pts, rc, intr, uv, valid, settings["huber_width"], settings["max_iters"], pr, pc, pf,
-                                PRIOR_SQRT_INFO_ROT, PRIOR_SQRT_INFO_POS)
+                                PRIOR_SQRT_INFO_ROT, PRIOR_SQRT_INFO_POS,
+                                homogeneous=bool(settings.get("homogeneous_points", True)))
     est = ops.ba_outlier_tracks(pts, rc, intr, uv, valid, settings["max_reprojection_px"],
                                 settings["min_triangulation_angle_deg"])
     s = summary.cpu()

@@ -37,6 +37,7 @@ struct BaProblem {
   const uint8_t* prior_flag;  // [N]
   double sqrt_info_rot, sqrt_info_pos, huber;
   int N, K;
+  int homogeneous;            // 1: tracks step in the tangent space of their homogeneous 4-vector (see ba_point_frame)
 };
 
 __device__ __forceinline__ double huber_rho(double s, double a, double& w) {
@@ -46,9 +47,58 @@ __device__ __forceinline__ double huber_rho(double s, double a, double& w) {
   return 2.0 * a * r - a * a;
 }
 
-// residual + Jacobians of one observation; returns false when the point is not in front of the camera
+// Theia's default point parametrization (use_homogeneous_point_parametrization = true, which the reference leaves
+// untouched: utils/reconstruction_alignment.py:150-152, utils/chunk_reconstruction.py:199-204): a track is the 4-vector
+// h = [X, 1] / |[X, 1]| under ceres::HomogeneousVectorParameterization - the solver steps delta (3) in the tangent space of
+// h's unit sphere, h' = Plus(h, delta) = H(h) [sin(|delta|/2) delta / |delta|, cos(|delta|/2)] with the Householder
+// reflection H(h) = I - beta v v^T that maps h onto e_4.  The objective is the same function of X = h[:3] / h[3]; what
+// changes is the coordinate system the LM damping (diag of J^T J) acts in, i.e. the path, not the optimum (oracle:
+// ba_ref.point_frames / points_plus; tests/test_ba_oracle.py measures the difference).  h is re-derived from X each
+// iteration (identical to carrying it while h[3] > 0).
+//   ba_point_frame: T = d X / d delta at 0 = (1 / w) [I | -X] . 0.5 H[:, :3]   (row-major 3 x 3), w = h[3] = 1 / |[X, 1]|
+struct BaFrame { double T[9]; double v[4]; double beta, w; };
+__device__ __forceinline__ void ba_point_frame(const double X[3], BaFrame& f) {
+  const double n = sqrt(X[0] * X[0] + X[1] * X[1] + X[2] * X[2] + 1.0);
+  const double w = 1.0 / n;
+  const double h[3] = {X[0] * w, X[1] * w, X[2] * w};
+  const double sigma = h[0] * h[0] + h[1] * h[1] + h[2] * h[2];
+  f.w = w;
+  f.v[3] = 1.0;
+  if (sigma <= 1e-300) {           // X = 0: h = e_4 already, H = I (pivot w > 0)
+    f.beta = 0.0;
+    f.v[0] = h[0]; f.v[1] = h[1]; f.v[2] = h[2];
+  } else {
+    const double mu = sqrt(w * w + sigma);
+    const double vp = -sigma / (w + mu);              // pivot > 0 branch of ceres::internal::ComputeHouseholderVector
+    f.beta = 2.0 * vp * vp / (sigma + vp * vp);
+    f.v[0] = h[0] / vp; f.v[1] = h[1] / vp; f.v[2] = h[2] / vp;
+  }
+  const double s = 0.5 * n;                            // 0.5 |h| / w with |h| = 1
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+      const double Hab = (a == b ? 1.0 : 0.0) - f.beta * f.v[a] * f.v[b];
+      const double H3b = -f.beta * f.v[3] * f.v[b];
+      f.T[3 * a + b] = s * (Hab - X[a] * H3b);
+    }
+}
+// X after the tangent step d on the sphere of its homogeneous vector
+__device__ __forceinline__ void ba_point_plus(const double X[3], const BaFrame& f, const double d[3], double Xn[3]) {
+  const double nd = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+  if (nd == 0.0) { Xn[0] = X[0]; Xn[1] = X[1]; Xn[2] = X[2]; return; }
+  const double sc = sin(0.5 * nd) / nd;
+  double y[4] = {d[0] * sc, d[1] * sc, d[2] * sc, cos(0.5 * nd)};
+  const double vy = f.beta * (f.v[0] * y[0] + f.v[1] * y[1] + f.v[2] * y[2] + f.v[3] * y[3]);
+#pragma unroll
+  for (int c = 0; c < 4; ++c) y[c] -= f.v[c] * vy;     // |h| = 1
+  Xn[0] = y[0] / y[3]; Xn[1] = y[1] / y[3]; Xn[2] = y[2] / y[3];
+}
+
+// residual + Jacobians of one observation; returns false when the point is not in front of the camera.
+// T (or null): the track's frame; the point columns Jp then refer to the tangent step (Jc never does).
 __device__ __forceinline__ bool ba_project(const double* pose, const double* in4, const double* X, double u, double v,
-                                           double r[2], double Jc[2][6], double Jp[2][3]) {
+                                           double r[2], double Jc[2][6], double Jp[2][3], const double* T = nullptr) {
   const double* R = pose;
   const double d0 = X[0] - pose[9], d1 = X[1] - pose[10], d2 = X[2] - pose[11];
   const double x = R[0] * d0 + R[1] * d1 + R[2] * d2;
@@ -71,6 +121,14 @@ __device__ __forceinline__ bool ba_project(const double* pose, const double* in4
   // centre: -Jpi R
 #pragma unroll
   for (int c = 0; c < 3; ++c) { Jc[0][3 + c] = -Jp[0][c]; Jc[1][3 + c] = -Jp[1][c]; }
+  if (T) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const double j0 = Jp[q][0], j1 = Jp[q][1], j2 = Jp[q][2];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) Jp[q][c] = j0 * T[c] + j1 * T[3 + c] + j2 * T[6 + c];
+    }
+  }
   return true;
 }
 
@@ -100,11 +158,14 @@ __global__ __launch_bounds__(256) void ba_linearize_points(BaProblem pb, const d
     const int s = (int)(i / K), k = (int)(i - (long)s * K);
     const double X[3] = {pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]};
     double C[6] = {0, 0, 0, 0, 0, 0}, g[3] = {0, 0, 0};
+    BaFrame fr;
+    if (pb.homogeneous) ba_point_frame(X, fr);
     for (int t = 0; t < N; ++t) {
       const long o = ((long)s * N + t) * K + k;
       if (!pb.valid[o]) continue;
       double r[2], Jc[2][6], Jp[2][3];
-      if (!ba_project(poses + 12 * t, pb.intr + 4 * t, X, (double)pb.uv[2 * o], (double)pb.uv[2 * o + 1], r, Jc, Jp))
+      if (!ba_project(poses + 12 * t, pb.intr + 4 * t, X, (double)pb.uv[2 * o], (double)pb.uv[2 * o + 1], r, Jc, Jp,
+                      pb.homogeneous ? fr.T : nullptr))
         continue;
       double w;
       cost += huber_rho(r[0] * r[0] + r[1] * r[1], pb.huber, w);
@@ -280,7 +341,10 @@ __global__ __launch_bounds__(256) void ba_obs_blocks(BaProblem pb, const double*
   if (pb.validT[o]) {
     const double X[3] = {pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]};
     double r[2], Jc[2][6], Jp[2][3], w;
-    if (ba_project(poses + 12 * t, pb.intr + 4 * t, X, (double)pb.uvT[2 * o], (double)pb.uvT[2 * o + 1], r, Jc, Jp)) {
+    BaFrame fr;
+    if (pb.homogeneous) ba_point_frame(X, fr);
+    if (ba_project(poses + 12 * t, pb.intr + 4 * t, X, (double)pb.uvT[2 * o], (double)pb.uvT[2 * o + 1], r, Jc, Jp,
+                   pb.homogeneous ? fr.T : nullptr)) {
       huber_rho(r[0] * r[0] + r[1] * r[1], pb.huber, w);
       double* E = Eblk + 18 * o;
 #pragma unroll
@@ -570,13 +634,16 @@ __global__ __launch_bounds__(256) void ba_backsub_points(BaProblem pb, const dou
     const double X[3] = {pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]};
     double Ci[6], D[3];
     double dx[3] = {0, 0, 0};
+    BaFrame fr;
+    if (pb.homogeneous) ba_point_frame(X, fr);
     if (st->chol_fail == 0.0 && ba_point_inverse(Cblk + 6 * i, st->radius, Ci, D)) {
       double v[3] = {gp[3 * i], gp[3 * i + 1], gp[3 * i + 2]};   // g_i + sum_t E_it^T dc_t
       for (int t = 0; t < N; ++t) {
         const long o = ((long)s * N + t) * K + k;
         if (!pb.valid[o]) continue;
         double r[2], Jc[2][6], Jp[2][3], w;
-        if (!ba_project(poses + 12 * t, pb.intr + 4 * t, X, (double)pb.uv[2 * o], (double)pb.uv[2 * o + 1], r, Jc, Jp))
+        if (!ba_project(poses + 12 * t, pb.intr + 4 * t, X, (double)pb.uv[2 * o], (double)pb.uv[2 * o + 1], r, Jc, Jp,
+                        pb.homogeneous ? fr.T : nullptr))
           continue;
         huber_rho(r[0] * r[0] + r[1] * r[1], pb.huber, w);
         double jd0 = 0.0, jd1 = 0.0;      // Jc dc
@@ -592,8 +659,15 @@ __global__ __launch_bounds__(256) void ba_backsub_points(BaProblem pb, const dou
 #pragma unroll
       for (int c = 0; c < 3; ++c) model += -0.5 * gp[3 * i + c] * dx[c] + 0.5 * D[c] * dx[c] * dx[c];
     }
+    if (pb.homogeneous) {
+      double Xn[3];
+      ba_point_plus(X, fr, dx, Xn);
 #pragma unroll
-    for (int c = 0; c < 3; ++c) pts_new[3 * i + c] = X[c] + dx[c];
+      for (int c = 0; c < 3; ++c) pts_new[3 * i + c] = Xn[c];
+    } else {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) pts_new[3 * i + c] = X[c] + dx[c];
+    }
   }
   const double tot = ba_block_sum<256>(model, red, tid);
   if (tid == 0) model_part[blockIdx.x] = tot;
@@ -726,11 +800,11 @@ extern "C" long pi3_ba_workspace_doubles(int N, int K) {
          3L * N + 64;
 }
 
-extern "C" int pi3_bundle_adjust(double* points, double* poses, const double* intr, const float* uv,
-                                 const unsigned char* valid, const float* uvT, const unsigned char* validT, int N, int K,
-                                 double huber_width, int max_iters, const double* prior_R, const double* prior_C,
-                                 const unsigned char* prior_flag, double sqrt_info_rot, double sqrt_info_pos,
-                                 double* summary_dev, double* workspace, long workspace_doubles, void* stream) {
+static int ba_run(double* points, double* poses, const double* intr, const float* uv, const unsigned char* valid,
+                  const float* uvT, const unsigned char* validT, int N, int K, double huber_width, int max_iters,
+                  const double* prior_R, const double* prior_C, const unsigned char* prior_flag, double sqrt_info_rot,
+                  double sqrt_info_pos, int homogeneous, double* summary_dev, double* workspace, long workspace_doubles,
+                  void* stream) {
   if (!points || !poses || !intr || !uv || !valid || !uvT || !validT || !summary_dev || !workspace || N <= 0 ||
       N > BA_MAXN || K <= 0 || max_iters < 0 || !(huber_width > 0.0) ||
       ((prior_flag != nullptr) && (!prior_R || !prior_C))) {
@@ -774,6 +848,7 @@ extern "C" int pi3_bundle_adjust(double* points, double* poses, const double* in
   pb.uv = uv; pb.valid = valid; pb.uvT = uvT; pb.validT = validT; pb.intr = intr;
   pb.prior_R = prior_R; pb.prior_C = prior_C; pb.prior_flag = prior_flag;
   pb.sqrt_info_rot = sqrt_info_rot; pb.sqrt_info_pos = sqrt_info_pos; pb.huber = huber_width; pb.N = N; pb.K = K;
+  pb.homogeneous = homogeneous ? 1 : 0;
   // cost at the start
   hipLaunchKernelGGL(ba_cost_points, dim3(nblk), dim3(256), 0, st, pb, points, poses, cost_part, state);
   hipLaunchKernelGGL(ba_prior_cost, dim3((N + 63) / 64), dim3(64), 0, st, pb, poses, prior_cost, state);
@@ -817,6 +892,26 @@ extern "C" int pi3_bundle_adjust(double* points, double* poses, const double* in
   return pi3_check_launch("bundle_adjust");
 }
 
+extern "C" int pi3_bundle_adjust(double* points, double* poses, const double* intr, const float* uv,
+                                 const unsigned char* valid, const float* uvT, const unsigned char* validT, int N, int K,
+                                 double huber_width, int max_iters, const double* prior_R, const double* prior_C,
+                                 const unsigned char* prior_flag, double sqrt_info_rot, double sqrt_info_pos,
+                                 double* summary_dev, double* workspace, long workspace_doubles, void* stream) {
+  return ba_run(points, poses, intr, uv, valid, uvT, validT, N, K, huber_width, max_iters, prior_R, prior_C, prior_flag,
+                sqrt_info_rot, sqrt_info_pos, 0, summary_dev, workspace, workspace_doubles, stream);
+}
+
+// The same adjustment with Theia's default point parametrization (see ba_point_frame): what the reference's calls use.
+extern "C" int pi3_bundle_adjust_homogeneous(double* points, double* poses, const double* intr, const float* uv,
+                                             const unsigned char* valid, const float* uvT, const unsigned char* validT,
+                                             int N, int K, double huber_width, int max_iters, const double* prior_R,
+                                             const double* prior_C, const unsigned char* prior_flag, double sqrt_info_rot,
+                                             double sqrt_info_pos, double* summary_dev, double* workspace,
+                                             long workspace_doubles, void* stream) {
+  return ba_run(points, poses, intr, uv, valid, uvT, validT, N, K, huber_width, max_iters, prior_R, prior_C, prior_flag,
+                sqrt_info_rot, sqrt_info_pos, 1, summary_dev, workspace, workspace_doubles, stream);
+}
+
 extern "C" int pi3_ba_outlier_tracks(const double* points, const double* poses, const double* intr, const float* uv,
                                      const unsigned char* valid, int N, int K, double max_reprojection_px,
                                      double min_triangulation_angle_deg, unsigned char* estimated, void* stream) {
@@ -827,7 +922,7 @@ extern "C" int pi3_ba_outlier_tracks(const double* points, const double* poses, 
   BaProblem pb;
   pb.uv = uv; pb.valid = valid; pb.uvT = nullptr; pb.validT = nullptr; pb.intr = intr;
   pb.prior_R = nullptr; pb.prior_C = nullptr; pb.prior_flag = nullptr;
-  pb.sqrt_info_rot = 0; pb.sqrt_info_pos = 0; pb.huber = 1.0; pb.N = N; pb.K = K;
+  pb.sqrt_info_rot = 0; pb.sqrt_info_pos = 0; pb.huber = 1.0; pb.N = N; pb.K = K; pb.homogeneous = 0;
   hipLaunchKernelGGL(ba_outlier_tracks, dim3(ba_nblk(N, K)), dim3(256), 0, (hipStream_t)stream, pb, points, poses,
                      max_reprojection_px, cos(min_triangulation_angle_deg * 3.14159265358979323846 / 180.0), estimated);
   return pi3_check_launch("ba_outlier_tracks");

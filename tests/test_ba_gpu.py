@@ -73,13 +73,16 @@ def test_bundle_adjust_matches_oracle(dev, case):
     assert abs(out[0] - s_long["final_cost"]) <= 1e-4 * s_long["final_cost"] + 1e-9, (out[0], s_long["final_cost"])
 
 
-def _compare_with_schur_oracle(dev, pb, huber, iters, prior=None, cost_rtol=1e-9, atol_pose=1e-7, atol_pts=1e-6):
-    """pi3_bundle_adjust against oracle/ba_ref.bundle_adjust_schur on the same problem: same number of iterations and
-    accepted steps, costs to cost_rtol, parameters to atol.  Returns (device summary, oracle summary)."""
+def _compare_with_schur_oracle(dev, pb, huber, iters, prior=None, cost_rtol=1e-9, atol_pose=1e-7, atol_pts=1e-6,
+                               homogeneous=False):
+    """pi3_bundle_adjust (homogeneous: pi3_bundle_adjust_homogeneous) against oracle/ba_ref.bundle_adjust_schur on the same
+    problem: same number of iterations and accepted steps, costs to cost_rtol, parameters to atol.  Returns (device
+    summary, oracle summary)."""
     from oracle import ba_ref
     from pi3_slam_amd import ops
     N = len(pb["R"])
-    R, C, X, s = ba_ref.bundle_adjust_schur(pb["R"], pb["C"], pb["intr"], pb["X"], pb["uv"], pb["valid"], huber, iters, prior)
+    R, C, X, s = ba_ref.bundle_adjust_schur(pb["R"], pb["C"], pb["intr"], pb["X"], pb["uv"], pb["valid"], huber, iters, prior,
+                                            homogeneous=homogeneous)
     pts, rc, intr, uv, valid = _to_dev(pb, dev)
     pr = pc = pf = None
     if prior is not None:
@@ -87,7 +90,8 @@ def _compare_with_schur_oracle(dev, pb, huber, iters, prior=None, cost_rtol=1e-9
         pc = torch.from_numpy(prior["C"]).to(dev)
         pf = torch.from_numpy(prior["flag"]).to(dev)
     out = ops.bundle_adjust(pts, rc, intr, uv, valid, huber, iters, pr, pc, pf,
-                            prior["sqrt_info_rot"] if prior else 0.0, prior["sqrt_info_pos"] if prior else 0.0).cpu().numpy()
+                            prior["sqrt_info_rot"] if prior else 0.0, prior["sqrt_info_pos"] if prior else 0.0,
+                            homogeneous=homogeneous).cpu().numpy()
     torch.cuda.synchronize()
     assert abs(out[8] - s["initial_cost"]) <= cost_rtol * s["initial_cost"], (out[8], s["initial_cost"])
     assert (int(out[5]), int(out[6])) == (s["iterations"], s["accepted_steps"]), (out, s)
@@ -241,3 +245,42 @@ def test_chunk_bundle_adjust_and_reconstructor_flag(dev, tmp_path):
     assert traj[True].shape == traj[False].shape == (6, 8)
     assert np.abs(traj[True][:, 1:4] - traj[False][:, 1:4]).max() < 2e-2     # consistent data: BA only polishes
     assert np.abs(traj[True][:, 1:4] - pb["C_gt"]).max() < 2e-2
+
+
+@pytest.mark.parametrize("N,K,iters,with_prior", [(6, 10, 6, False), (9, 14, 4, True), (22, 12, 3, True), (27, 10, 2, False)])
+def test_homogeneous_point_parametrization_matches_the_oracle(dev, N, K, iters, with_prior):
+    """pi3_bundle_adjust_homogeneous (Theia's default point parametrization, which the reference's calls run with:
+    tracks step in the tangent space of their 4-vector, ceres::HomogeneousVectorParameterization) against the oracle's
+    Schur form with the same parametrization: step for step in the well-conditioned phase, small and multi-panel
+    camera systems, with and without pose priors.  The product's bundle_adjust_chunk uses this form by default."""
+    pb = make_problem(N=N, K=K, seed=31 + N, noise_px=0.5, outlier_frac=0.04, perturb=0.7)
+    prior = None
+    if with_prior:
+        flag = np.zeros(N, np.uint8)
+        flag[: max(2, N // 4)] = 1
+        prior = dict(R=pb["R_gt"], C=pb["C_gt"] + 0.03, flag=flag, sqrt_info_rot=0.5 ** 0.5, sqrt_info_pos=0.2)
+    out_h, s_h = _compare_with_schur_oracle(dev, pb, 3.0 if with_prior else 2.0, iters, prior, cost_rtol=1e-9, atol_pose=1e-7,
+                                            atol_pts=1e-6, homogeneous=True)
+    out_e, s_e = _compare_with_schur_oracle(dev, pb, 3.0 if with_prior else 2.0, iters, prior, homogeneous=False)
+    assert out_h[0] < out_h[8] and out_e[0] < out_e[8]
+    assert out_h[0] != out_e[0]                       # a different path ...
+    assert abs(out_h[0] - out_e[0]) < 0.05 * out_e[0]  # ... towards the same optimum
+
+
+def test_homogeneous_and_euclidean_settings_of_the_chunk_adjuster(dev):
+    """bundle_adjust_chunk: homogeneous_points=True (default, = the reference's configuration) and False reach the same
+    cost to 1e-4 on a consistent chunk after the after-alignment setting's 50 iterations; zero iterations is the identity
+    in both."""
+    from pi3_slam_amd import ops
+    pb = make_problem(N=8, K=12, seed=5, noise_px=0.4, perturb=0.6)
+    N = 8
+    costs = {}
+    for hom in (True, False):
+        pts, rc, intr, uv, valid = _to_dev(pb, dev)
+        out = ops.bundle_adjust(pts, rc, intr, uv, valid, 3.0, 50, homogeneous=hom).cpu().numpy()
+        costs[hom] = out[0]
+        p0, r0, _, _, _ = _to_dev(pb, dev)
+        p1, r1 = p0.clone(), r0.clone()
+        ops.bundle_adjust(p1, r1, intr, uv, valid, 3.0, 0, homogeneous=hom)
+        assert torch.equal(p0, p1) and torch.equal(r0, r1)
+    assert abs(costs[True] - costs[False]) <= 1e-4 * costs[False], costs

@@ -263,8 +263,7 @@ def test_homogeneous_point_parametrization_matches_the_oracle(dev, N, K, iters, 
                                             atol_pts=1e-6, homogeneous=True)
     out_e, s_e = _compare_with_schur_oracle(dev, pb, 3.0 if with_prior else 2.0, iters, prior, homogeneous=False)
     assert out_h[0] < out_h[8] and out_e[0] < out_e[8]
-    assert out_h[0] != out_e[0]                       # a different path ...
-    assert abs(out_h[0] - out_e[0]) < 0.05 * out_e[0]  # ... towards the same optimum
+    assert out_h[0] != out_e[0]                       # a different path (the same optimum: the 50-iteration test below)
 
 
 def test_homogeneous_and_euclidean_settings_of_the_chunk_adjuster(dev):

@@ -277,8 +277,8 @@ int pi3_bundle_adjust(double* points, double* poses, const double* intr, const f
                       double sqrt_info_rot, double sqrt_info_pos, double* summary_dev, double* workspace,
                       long workspace_doubles, void* stream);
 
-/* The same adjustment with Theia's DEFAULT point parametrization, which is what the reference's two calls run with
- * (use_homogeneous_point_parametrization = true is never changed: utils/reconstruction_alignment.py:150-152,
+/* The same adjustment with the point parametrization the reference's two calls configure
+ * (ba_options.use_homogeneous_point_parametrization = True: utils/reconstruction_alignment.py:147-152,
  * utils/chunk_reconstruction.py:199-204): every track is the 4-vector [X, 1] / |[X, 1]| stepped in the tangent space of
  * its unit sphere (ceres::HomogeneousVectorParameterization: Householder basis, Plus).  Same objective and optimum as
  * pi3_bundle_adjust (Euclidean steps); the LM damping acts in different coordinates, so the iterates differ

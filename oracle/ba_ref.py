@@ -108,7 +108,7 @@ def total_cost(R, C, intr, X, trk, cam, px, a, prior) -> float:
 def householder(x: np.ndarray):
     """(v, beta) with (I - beta v v^T) x = +-|x| e_last: ceres::internal::ComputeHouseholderVector, the basis of
     ceres::HomogeneousVectorParameterization (what Theia's use_homogeneous_point_parametrization puts on a track's
-    4-vector: utils/reconstruction_alignment.py:150-152 leaves that option at its default, true)."""
+    4-vector; the reference sets that option to True: utils/reconstruction_alignment.py:147-152)."""
     sigma = float(x[:-1] @ x[:-1])
     v = x.astype(np.float64).copy()
     v[-1] = 1.0

@@ -15,7 +15,7 @@ from . import ops
 INVERSE_DEPTH_MESSAGE = (
     "use_inverse_depth=True is not implemented: the reference switches pytheia's bundle adjuster to one inverse-depth "
     "parameter per track anchored in the track's first view (utils/chunk_reconstruction.py:186-187,199-204; "
-    "utils/reconstruction_alignment.py:147-152); csrc/ba.hip optimises Euclidean 3-D points only.  Run with "
+    "utils/reconstruction_alignment.py:147-152); csrc/ba.hip optimises 3-D points (Euclidean or homogeneous steps) only.  Run with "
     "use_inverse_depth=False (the reference's default).")
 
 

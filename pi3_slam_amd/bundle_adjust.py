@@ -23,8 +23,8 @@ from . import ops
 # Ceres returns): sanity_gate=False switches it off for reference-parity runs (OfflineReconstructor(ba_sanity_gate=False),
 # `cli reconstruct --no-ba-sanity-gate`); max_camera_move_extents = how many scene extents a camera centre may move;
 # min_surviving_tracks = how many of the tracks that took part must still be estimated.
-# homogeneous_points: Theia's use_homogeneous_point_parametrization, which the reference never changes from its default
-# (true): tracks step in the tangent space of their 4-vector (pi3_bundle_adjust_homogeneous).  False = Euclidean steps.
+# homogeneous_points: Theia's use_homogeneous_point_parametrization, which the reference sets to True unless
+# --use-inverse-depth is given (utils/chunk_reconstruction.py:199-204, utils/reconstruction_alignment.py:147-152): tracks step in the tangent space of their 4-vector (pi3_bundle_adjust_homogeneous).  False = Euclidean steps.
 PER_CHUNK = dict(max_iters=10, huber_width=2.0, max_reprojection_px=2.0, min_triangulation_angle_deg=0.25,
                  sanity_gate=True, max_camera_move_extents=1.0, min_surviving_tracks=3, homogeneous_points=True)
 AFTER_ALIGNMENT = dict(max_iters=50, huber_width=3.0, max_reprojection_px=3.0, min_triangulation_angle_deg=0.25,

@@ -47,8 +47,8 @@ __device__ __forceinline__ double huber_rho(double s, double a, double& w) {
   return 2.0 * a * r - a * a;
 }
 
-// Theia's default point parametrization (use_homogeneous_point_parametrization = true, which the reference leaves
-// untouched: utils/reconstruction_alignment.py:150-152, utils/chunk_reconstruction.py:199-204): a track is the 4-vector
+// The reference's point parametrization (ba_options.use_homogeneous_point_parametrization = True unless
+// --use-inverse-depth: utils/reconstruction_alignment.py:147-152, utils/chunk_reconstruction.py:199-204): a track is the 4-vector
 // h = [X, 1] / |[X, 1]| under ceres::HomogeneousVectorParameterization - the solver steps delta (3) in the tangent space of
 // h's unit sphere, h' = Plus(h, delta) = H(h) [sin(|delta|/2) delta / |delta|, cos(|delta|/2)] with the Householder
 // reflection H(h) = I - beta v v^T that maps h onto e_4.  The objective is the same function of X = h[:3] / h[3]; what

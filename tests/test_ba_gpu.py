@@ -126,8 +126,8 @@ def test_multi_panel_with_pose_priors_matches_the_oracle(dev):
     _compare_with_schur_oracle(dev, pb, 3.0, 8, prior)
 
 
-@pytest.mark.parametrize("iters", [1, 10])
-def test_whole_chunk_matches_the_oracle(dev, iters):
+@pytest.mark.parametrize("iters,homogeneous", [(1, False), (10, False), (2, True)])
+def test_whole_chunk_matches_the_oracle(dev, iters, homogeneous):
     """The shipped size: 100 cameras x 200 keypoints (600 unknowns = 12.5 panels, 20 000 tracks, ~1 M observations in
     the reference's pattern: every earlier frame + the next two) on bench.synthetic_ba_problem, one LM iteration and
     the per-chunk stage's ten, against the Schur-complement oracle.  Cost 1e-9; parameters 1e-7 after one step and
@@ -136,7 +136,7 @@ def test_whole_chunk_matches_the_oracle(dev, iters):
     from bench import synthetic_ba_problem
     pb = synthetic_ba_problem(100, 200, seed=3, noise_px=0.5, perturb=1.0)
     tol = dict(atol_pose=1e-7, atol_pts=1e-6) if iters == 1 else dict(atol_pose=1e-6, atol_pts=1e-5)
-    out, s = _compare_with_schur_oracle(dev, pb, 2.0, iters, **tol)
+    out, s = _compare_with_schur_oracle(dev, pb, 2.0, iters, homogeneous=homogeneous, **tol)   # (2, True): the product's default form
     assert out[9] == 0 and s["chol_failures"] == 0 and out[0] < 0.2 * out[8], (out, s)
 
 
@@ -249,7 +249,7 @@ def test_chunk_bundle_adjust_and_reconstructor_flag(dev, tmp_path):
 
 @pytest.mark.parametrize("N,K,iters,with_prior", [(6, 10, 6, False), (9, 14, 4, True), (22, 12, 3, True), (27, 10, 2, False)])
 def test_homogeneous_point_parametrization_matches_the_oracle(dev, N, K, iters, with_prior):
-    """pi3_bundle_adjust_homogeneous (Theia's default point parametrization, which the reference's calls run with:
+    """pi3_bundle_adjust_homogeneous (the point parametrization the reference's calls configure:
     tracks step in the tangent space of their 4-vector, ceres::HomogeneousVectorParameterization) against the oracle's
     Schur form with the same parametrization: step for step in the well-conditioned phase, small and multi-panel
     camera systems, with and without pose priors.  The product's bundle_adjust_chunk uses this form by default."""

@@ -102,10 +102,10 @@ def test_schur_form_rejects_every_step_on_a_non_finite_observation():
 
 
 def test_homogeneous_point_parametrization_reaches_the_same_optimum():
-    """The reference leaves Theia's use_homogeneous_point_parametrization at its default (true:
-    utils/reconstruction_alignment.py:150-152, utils/chunk_reconstruction.py:199-204): a track is a unit 4-vector
-    stepped on its sphere (ceres::HomogeneousVectorParameterization).  The device adjuster and oracle.bundle_adjust step
-    Euclidean points.  Same objective, same geometry, different LM path - this test states what that changes, with the
+    """The reference sets Theia's use_homogeneous_point_parametrization = True
+    (utils/reconstruction_alignment.py:147-152, utils/chunk_reconstruction.py:199-204): a track is a unit 4-vector
+    stepped on its sphere (ceres::HomogeneousVectorParameterization).  Both the device and the oracle have both forms; this
+    test states what Euclidean steps would change.  Same objective, same geometry, different LM path - this test states what that changes, with the
     oracle's own homogeneous form (Householder basis, Plus and its Jacobian checked by finite differences):
       * the final cost agrees to 5e-5 relative after the per-chunk setting (10 iterations, Huber 2) and to 1e-6 after the
         after-alignment setting (50 iterations, Huber 3);

@@ -289,6 +289,18 @@ int pi3_bundle_adjust_homogeneous(double* points, double* poses, const double* i
                                   const unsigned char* prior_flag, double sqrt_info_rot, double sqrt_info_pos,
                                   double* summary_dev, double* workspace, long workspace_doubles, void* stream);
 
+/* The reference's --use-inverse-depth (reconstruction.InitializeInverseDepth() + ba_options.use_inverse_depth_parametrization
+ * = True: utils/chunk_reconstruction.py:187-204, utils/reconstruction_alignment.py:147-152): every track (s, k) is ONE
+ * parameter, the inverse depth along the bearing of its keypoint in its reference view s (its own frame),
+ * X = C_s + R_s^T (b / rho); observations by other cameras depend on (pose_t, pose_s, rho), the reference view's own
+ * observation carries no residual.  `points` are snapped onto those rays at the start and returned Euclidean.  Same
+ * arguments and workspace as pi3_bundle_adjust.  Restated from the published parametrization: parity unpinned. */
+int pi3_bundle_adjust_inverse_depth(double* points, double* poses, const double* intr, const float* uv,
+                                    const unsigned char* valid, const float* uvT, const unsigned char* validT, int N, int K,
+                                    double huber_width, int max_iters, const double* prior_R, const double* prior_C,
+                                    const unsigned char* prior_flag, double sqrt_info_rot, double sqrt_info_pos,
+                                    double* summary_dev, double* workspace, long workspace_doubles, void* stream);
+
 /* pt.sfm.SetOutlierTracksToUnestimated(tracks, max_reprojection_error_px, min_triangulation_angle_deg)
  * (utils/chunk_reconstruction.py:218, utils/reconstruction_alignment.py:170): estimated[s*K + k] = 1 iff every
  * observation of the track is in front of its camera and within max px, and two viewing rays subtend more than the

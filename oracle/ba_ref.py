@@ -246,6 +246,125 @@ def bundle_adjust(R, C, intr, X, uv, valid, huber_width: float, max_iters: int, 
     return R, C, X, summary
 
 
+# ------------------------------------------------------------------------------------------------ inverse depth
+# The reference's --use-inverse-depth (utils/chunk_reconstruction.py:187-188,199-204; utils/reconstruction_alignment.py:
+# 147-152): reconstruction.InitializeInverseDepth() + ba_options.use_inverse_depth_parametrization = True.  TheiaSfM then
+# holds, per track, ONE parameter - the inverse depth rho along the bearing of the track's feature in its REFERENCE view
+# (the first view that observed it; a track of this pipeline is created with its own frame's keypoint first,
+# chunk_reconstruction.py:142-160, so the reference view of track (s, k) is frame s):
+#     X = C_s + R_s^T (b / rho),   b = ((u - cx) / fx, (v - cy) / fy, 1) of the keypoint in frame s,
+# and every OTHER observation's reprojection error is a function of (pose_s, pose_t, rho); the reference view's own
+# observation is met exactly by construction and carries no residual.  PARITY UNPINNED like the rest of this file.
+def inverse_depth_state(R, C, intr, X, uv, valid):
+    """(b (P, 3), rho (P,), anchor (P,)) from Euclidean points: InitializeInverseDepth - the depth of every track in its
+    reference view; the point is thereby snapped onto the reference keypoint's ray."""
+    N, _, K = valid.shape
+    P = N * K
+    anchor = np.arange(P) // K
+    kk = np.arange(P) % K
+    px = uv[anchor, anchor, kk].astype(np.float64)
+    ia = intr[anchor]
+    b = np.stack([(px[:, 0] - ia[:, 2]) / ia[:, 0], (px[:, 1] - ia[:, 3]) / ia[:, 1], np.ones(P)], 1)
+    z = np.einsum("pj,pj->p", R[anchor][:, 2, :], X - C[anchor])
+    return b, 1.0 / z, anchor
+
+
+def inverse_depth_points(R, C, b, rho, anchor):
+    return C[anchor] + np.einsum("pji,pj->pi", R[anchor], b / rho[:, None])
+
+
+def invdepth_observations(uv, valid):
+    """observations() without every track's reference-view observation."""
+    trk, cam, px = observations(uv, valid)
+    K = valid.shape[2]
+    keep = cam != trk // K
+    return trk[keep], cam[keep], px[keep]
+
+
+def invdepth_jacobians(R, C, intr, b, rho, anchor, trk, cam, px):
+    """-> r (M,2), Jt (M,2,6) w.r.t. the observing camera, Ja (M,2,6) w.r.t. the reference camera, Jr (M,2) w.r.t. rho,
+    front.  Chain rule through X(pose_a, rho): dX/dC_a = I, dX/dw_a = R_a^T [p_a]x (R_a <- exp([w]x) R_a), dX/drho =
+    -R_a^T p_a / rho with p_a = b / rho."""
+    X = inverse_depth_points(R, C, b, rho, anchor)
+    r, Jt, Jp, front = residuals(R, C, intr, X, trk, cam, px)
+    a = anchor[trk]
+    pa = b[trk] / rho[trk][:, None]
+    RaT = np.transpose(R[a], (0, 2, 1))
+    dX_dw = np.einsum("mij,mjk->mik", RaT, skew(pa))
+    Ja = np.concatenate([np.einsum("mij,mjk->mik", Jp, dX_dw), Jp], axis=2)
+    Jr = -np.einsum("mij,mj->mi", Jp, np.einsum("mij,mj->mi", RaT, pa)) / rho[trk][:, None]
+    return r, Jt, Ja, Jr, front
+
+
+def invdepth_cost(R, C, intr, b, rho, anchor, trk, cam, px, a, prior) -> float:
+    X = inverse_depth_points(R, C, b, rho, anchor)
+    r, _, _, front = residuals(R, C, intr, X, trk, cam, px)
+    rh, _ = huber((r ** 2).sum(1), a)
+    return 0.5 * rh[front].sum() + prior_terms(R, C, prior)[0]
+
+
+def bundle_adjust_inverse_depth(R, C, intr, X, uv, valid, huber_width: float, max_iters: int,
+                                prior: Optional[Dict] = None):
+    """bundle_adjust() with one inverse-depth parameter per track (dense normal equations over 6 N + P unknowns, the
+    same LM rules).  Returns refined (R, C, X, summary); X are the Euclidean points of the refined state."""
+    R, C = R.copy(), C.copy()
+    N = len(R)
+    b, rho, anchor = inverse_depth_state(R, C, intr, X, uv, valid)
+    P = len(rho)
+    trk, cam, px = invdepth_observations(uv, valid)
+    cost = invdepth_cost(R, C, intr, b, rho, anchor, trk, cam, px, huber_width, prior)
+    summary = {"initial_cost": cost, "iterations": 0, "accepted_steps": 0}
+    radius, decrease = 1e4, 2.0
+    nc = 6 * N
+    for _ in range(max_iters):
+        r, Jt, Ja, Jr, front = invdepth_jacobians(R, C, intr, b, rho, anchor, trk, cam, px)
+        _, w = huber((r ** 2).sum(1), huber_width)
+        w = w * front
+        a = anchor[trk]
+        n = nc + P
+        H, g = np.zeros((n, n)), np.zeros(n)
+        it = (6 * cam[:, None] + np.arange(6)[None]).astype(int)
+        ia = (6 * a[:, None] + np.arange(6)[None]).astype(int)
+        ir = (nc + trk)[:, None].astype(int)
+        J = np.concatenate([Jt, Ja, Jr[:, :, None]], 2)                  # (M, 2, 13)
+        idx = np.concatenate([it, ia, ir], 1)
+        np.add.at(H, (idx[:, :, None], idx[:, None, :]), np.einsum("m,mia,mib->mab", w, J, J))
+        np.add.at(g, idx, np.einsum("m,mia,mi->ma", w, J, r))
+        _, Hd, gprior = prior_terms(R, C, prior)
+        H[np.arange(nc), np.arange(nc)] += Hd.reshape(-1)
+        g[:nc] += gprior.reshape(-1)
+        D = np.clip(np.diag(H), 1e-6, 1e32) / radius
+        ok = True
+        try:
+            L = np.linalg.cholesky(H + np.diag(D))
+            d = -np.linalg.solve(L.T, np.linalg.solve(L, g))
+        except np.linalg.LinAlgError:
+            ok, d = False, np.zeros_like(g)
+        model = -0.5 * g @ d + 0.5 * d @ (D * d)
+        Rn = np.stack([exp_so3(d[6 * t:6 * t + 3]) @ R[t] for t in range(N)])
+        Cn = C + d[:nc].reshape(N, 6)[:, 3:]
+        rn = rho + d[nc:]
+        cnew = invdepth_cost(Rn, Cn, intr, b, rn, anchor, trk, cam, px, huber_width, prior)
+        summary["iterations"] += 1
+        q = (cost - cnew) / model if (ok and model > 0) else -1.0
+        if q > 1e-3 and np.isfinite(cnew):
+            radius = min(radius / max(1.0 / 3.0, 1.0 - (2 * q - 1) ** 3), 1e16)
+            decrease = 2.0
+            rel = abs(cost - cnew) / max(cost, 1e-300)
+            R, C, rho, cost = Rn, Cn, rn, cnew
+            summary["accepted_steps"] += 1
+            if rel < 1e-6:
+                break
+        else:
+            radius /= decrease
+            decrease *= 2.0
+            if radius < 1e-32:
+                break
+    summary["final_cost"] = cost
+    summary["radius"] = radius
+    return R, C, inverse_depth_points(R, C, b, rho, anchor), summary
+
+
 def _segsum(idx: np.ndarray, vals: np.ndarray, n: int) -> np.ndarray:
     """out[j] = sum of vals[m] over idx[m] == j, in observation order (np.bincount adds sequentially), any trailing
     shape; the fixed order makes the oracle itself reproducible."""

@@ -12,13 +12,6 @@ import torch
 from . import ops
 
 
-INVERSE_DEPTH_MESSAGE = (
-    "use_inverse_depth=True is not implemented: the reference switches pytheia's bundle adjuster to one inverse-depth "
-    "parameter per track anchored in the track's first view (utils/chunk_reconstruction.py:186-187,199-204; "
-    "utils/reconstruction_alignment.py:147-152); csrc/ba.hip optimises 3-D points (Euclidean or homogeneous steps) only.  Run with "
-    "use_inverse_depth=False (the reference's default).")
-
-
 def create_view_graph_matches(chunk_size: int, overlap_size: int) -> List[Tuple[int, int]]:
     """(ref_view_idx, qry_view_idx) pairs of the overlapping region — utils/reconstruction_alignment.py:16-37."""
     return [(chunk_size - overlap_size + i, i) for i in range(overlap_size)]
@@ -152,8 +145,6 @@ def align_and_refine_reconstructions(chunk_ref: Dict, chunk_qry: Dict, view_grap
     match, the strict near-half filter and the Umeyama optimum are similarity-equivariant; tested), it is what the
     chunk-parallel path does, and it never feeds re-rounded global-frame points into the next solve."""
     print("🔄 Starting reconstruction alignment (closed-form Sim(3) over the overlap views)...")
-    if use_inverse_depth:
-        raise NotImplementedError(INVERSE_DEPTH_MESSAGE)
     try:
         out = estimate_sim3(chunk_ref, chunk_qry, view_graph_matches, device, use_masks, weights=weights)
         o = out.cpu()
@@ -174,6 +165,8 @@ def align_and_refine_reconstructions(chunk_ref: Dict, chunk_qry: Dict, view_grap
             from .bundle_adjust import AFTER_ALIGNMENT, bundle_adjust_chunk, overlap_priors
             priors = overlap_priors(chunk_ref, view_graph_matches)
             settings = dict(AFTER_ALIGNMENT, **bundle_adjust.get("settings", {}))
+            if use_inverse_depth:      # reconstruction_alignment.py:147-149
+                settings["inverse_depth"] = True
             ba = bundle_adjust_chunk(chunk_qry, bundle_adjust["width"], bundle_adjust["height"],
                                      bundle_adjust.get("max_observations_per_track", 5), device, settings, priors,
                                      release_observations=True)     # a chunk's last adjustment: free ~18 MB of HBM

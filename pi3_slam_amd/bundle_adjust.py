@@ -23,6 +23,8 @@ from . import ops
 # Ceres returns): sanity_gate=False switches it off for reference-parity runs (OfflineReconstructor(ba_sanity_gate=False),
 # `cli reconstruct --no-ba-sanity-gate`); max_camera_move_extents = how many scene extents a camera centre may move;
 # min_surviving_tracks = how many of the tracks that took part must still be estimated.
+# inverse_depth (default False): the reference's --use-inverse-depth - use_inverse_depth_parametrization = True and
+# use_homogeneous_point_parametrization = False (pi3_bundle_adjust_inverse_depth).
 # homogeneous_points: Theia's use_homogeneous_point_parametrization, which the reference sets to True unless
 # --use-inverse-depth is given (utils/chunk_reconstruction.py:199-204, utils/reconstruction_alignment.py:147-152): tracks step in the tangent space of their 4-vector (pi3_bundle_adjust_homogeneous).  False = Euclidean steps.
 PER_CHUNK = dict(max_iters=10, huber_width=2.0, max_reprojection_px=2.0, min_triangulation_angle_deg=0.25,
@@ -145,7 +147,8 @@ def bundle_adjust_chunk(chunk: Dict, W: int, H: int, max_observations_per_track:
                 pr[v], pc[v], pf[v] = r[:9], r[9:], 1
     summary = ops.bundle_adjust(pts, rc, intr, uv, valid, settings["huber_width"], settings["max_iters"], pr, pc, pf,
                                 PRIOR_SQRT_INFO_ROT, PRIOR_SQRT_INFO_POS,
-                                homogeneous=bool(settings.get("homogeneous_points", True)))
+                                homogeneous=bool(settings.get("homogeneous_points", True)) and not settings.get("inverse_depth"),
+                                inverse_depth=bool(settings.get("inverse_depth", False)))
     est = ops.ba_outlier_tracks(pts, rc, intr, uv, valid, settings["max_reprojection_px"],
                                 settings["min_triangulation_angle_deg"])
     s = summary.cpu()

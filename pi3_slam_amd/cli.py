@@ -45,8 +45,8 @@ RECON_FLAGS: Sequence[Tuple[str, Dict]] = (
     ("--device", dict(default="cuda")),
 )
 RECON_SWITCHES = (("--save-per-chunk", "per-chunk ply files as well"),
-                  ("--use-inverse-depth", "the reference's flag; NOT implemented here (raises): the device bundle adjustment "
-                                         "parametrises points in xyz"),
+                  ("--use-inverse-depth", "one inverse depth per track along its reference keypoint's ray in both bundle "
+                                         "adjustments (utils/chunk_reconstruction.py:187-204; pi3_bundle_adjust_inverse_depth)"),
                   ("--save-observations", "also write the projected track observations"),
                   ("--no-bundle-adjust", "closed-form Sim(3) chain only: skip the per-chunk and the prior-constrained "
                                          "bundle adjustment (utils/chunk_reconstruction.py:188-219, "

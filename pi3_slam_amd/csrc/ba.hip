@@ -38,6 +38,7 @@ struct BaProblem {
   double sqrt_info_rot, sqrt_info_pos, huber;
   int N, K;
   int homogeneous;            // 1: tracks step in the tangent space of their homogeneous 4-vector (see ba_point_frame)
+  int invdepth;               // 1: one inverse-depth parameter per track (see "inverse depth" below)
 };
 
 __device__ __forceinline__ double huber_rho(double s, double a, double& w) {
@@ -225,6 +226,45 @@ __device__ __forceinline__ void ba_log_so3(const double* R, double w[3]) {
   w[0] = f * vx; w[1] = f * vy; w[2] = f * vz;
 }
 
+// ---- inverse depth (the reference's --use-inverse-depth: reconstruction.InitializeInverseDepth() +
+// ba_options.use_inverse_depth_parametrization = True, utils/chunk_reconstruction.py:187-204,
+// utils/reconstruction_alignment.py:147-152).  A track (s, k) is ONE parameter, the inverse depth rho along the bearing b
+// of its keypoint in its reference view s (the first view that observed it: its own frame):
+//     X = C_s + R_s^T (b / rho),   b = ((u - cx) / fx, (v - cy) / fy, 1)
+// so every observation by another camera t depends on (pose_t, pose_s, rho) and the reference view's own observation is
+// met by construction (no residual).  The stored points stay Euclidean and ON their rays (snapped at the start, every
+// candidate built from the candidate pose and rho), so a kernel derives p_s = R_s (X - C_s) and rho = 1 / p_s.z from
+// them.  Chain rule through X: dX/dC_s = I, dX/dw_s = R_s^T [p_s]x (R_s <- exp([w]x) R_s), dX/drho = -(X - C_s) / rho.
+// The linear algebra reuses the Euclidean kernels with the scalar embedded in their 3 x 3 point blocks
+// (C_i = diag(c, 1, 1), g_i = (g, 0, 0), E_it = [e | 0 | 0]); what is new are the reference camera's entries in a track's
+// E row, its diagonal terms, and the direct camera-camera blocks w Ja^T Jt of the normal equations (ba_id_cross_blocks).
+__device__ __forceinline__ void ba_id_chain(const double* pose_s, const double X[3], const double Jp[2][3], double Ja[2][6],
+                                            double jr[2]) {
+  const double* R = pose_s;
+  const double d[3] = {X[0] - pose_s[9], X[1] - pose_s[10], X[2] - pose_s[11]};
+  const double p[3] = {R[0] * d[0] + R[1] * d[1] + R[2] * d[2], R[3] * d[0] + R[4] * d[1] + R[5] * d[2],
+                       R[6] * d[0] + R[7] * d[1] + R[8] * d[2]};
+  const double inv_rho = p[2];      // rho = 1 / p.z
+  // M = R^T [p]x, column j = R^T (p x e_j):  [p]x = [[0, -pz, py], [pz, 0, -px], [-py, px, 0]]
+  const double c0[3] = {0.0, p[2], -p[1]}, c1[3] = {-p[2], 0.0, p[0]}, c2[3] = {p[1], -p[0], 0.0};
+  double M[3][3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    M[a][0] = R[a] * c0[0] + R[3 + a] * c0[1] + R[6 + a] * c0[2];
+    M[a][1] = R[a] * c1[0] + R[3 + a] * c1[1] + R[6 + a] * c1[2];
+    M[a][2] = R[a] * c2[0] + R[3 + a] * c2[1] + R[6 + a] * c2[2];
+  }
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      Ja[q][c] = Jp[q][0] * M[0][c] + Jp[q][1] * M[1][c] + Jp[q][2] * M[2][c];
+      Ja[q][3 + c] = Jp[q][c];
+    }
+    jr[q] = -(Jp[q][0] * d[0] + Jp[q][1] * d[1] + Jp[q][2] * d[2]) * inv_rho;      // Jp . dX/drho, dX/drho = -(X - C_s) / rho
+  }
+}
+
 // ---- pass 2: per camera t: B_t = sum w Jc^T Jc (21 values), g_t = sum w Jc^T r, + pose priors.  One WG per camera.
 __global__ __launch_bounds__(256) void ba_camera_blocks(BaProblem pb, const double* __restrict__ pts,
                                                         const double* __restrict__ poses, double* __restrict__ Bblk,
@@ -241,6 +281,7 @@ __global__ __launch_bounds__(256) void ba_camera_blocks(BaProblem pb, const doub
     const int s = (int)(i / K), k = (int)(i - (long)s * K);
     const long o = ((long)s * N + t) * K + k;
     if (!pb.valid[o]) continue;
+    if (pb.invdepth && s == t) continue;      // a track's reference-view observation carries no residual
     const double X[3] = {pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]};
     double r[2], Jc[2][6], Jp[2][3];
     if (!ba_project(poses + 12 * t, pb.intr + 4 * t, X, (double)pb.uv[2 * o], (double)pb.uv[2 * o + 1], r, Jc, Jp)) continue;
@@ -253,6 +294,28 @@ __global__ __launch_bounds__(256) void ba_camera_blocks(BaProblem pb, const doub
       for (int c = p; c < 6; ++c) a[q++] += w * (Jc[0][p] * Jc[0][c] + Jc[1][p] * Jc[1][c]);
 #pragma unroll
     for (int p = 0; p < 6; ++p) a[21 + p] += w * (Jc[0][p] * r[0] + Jc[1][p] * r[1]);
+  }
+  if (pb.invdepth) {      // camera t as the REFERENCE view of its own tracks: every other observation of them moves with it
+    for (long e = tid; e < (long)K * N; e += 256) {
+      const int k = (int)(e / N), t2 = (int)(e - (long)k * N);
+      if (t2 == t) continue;
+      const long i = (long)t * K + k;
+      const long o = ((long)t * N + t2) * K + k;
+      if (!pb.valid[o] || !pb.valid[((long)t * N + t) * K + k]) continue;
+      const double X[3] = {pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]};
+      double r[2], Jc[2][6], Jp[2][3], Ja[2][6], jr[2];
+      if (!ba_project(poses + 12 * t2, pb.intr + 4 * t2, X, (double)pb.uv[2 * o], (double)pb.uv[2 * o + 1], r, Jc, Jp)) continue;
+      ba_id_chain(poses + 12 * t, X, Jp, Ja, jr);
+      double w;
+      huber_rho(r[0] * r[0] + r[1] * r[1], pb.huber, w);
+      int q = 0;
+#pragma unroll
+      for (int p = 0; p < 6; ++p)
+#pragma unroll
+        for (int c = p; c < 6; ++c) a[q++] += w * (Ja[0][p] * Ja[0][c] + Ja[1][p] * Ja[1][c]);
+#pragma unroll
+      for (int p = 0; p < 6; ++p) a[21 + p] += w * (Ja[0][p] * r[0] + Ja[1][p] * r[1]);
+    }
   }
   for (int c = 0; c < 27; ++c) {
     const double v = ba_block_sum<256>(a[c], red, tid);
@@ -791,20 +854,210 @@ __global__ __launch_bounds__(256) void ba_outlier_tracks(BaProblem pb, const dou
 }
 
 // ------------------------------------------------------------------------------------------------------------- C ABI
+// ---- inverse depth: kernels (thread per track unless stated)
+__device__ __forceinline__ void ba_id_bearing(const BaProblem& pb, int s, int k, double b[3]) {
+  const long o = ((long)s * pb.N + s) * pb.K + k;
+  const double* in4 = pb.intr + 4 * s;
+  b[0] = ((double)pb.uv[2 * o] - in4[2]) / in4[0];
+  b[1] = ((double)pb.uv[2 * o + 1] - in4[3]) / in4[1];
+  b[2] = 1.0;
+}
+// X = C_s + R_s^T (b / rho): rho == nullptr -> the depth of pts in the reference view (InitializeInverseDepth: snap)
+__global__ __launch_bounds__(256) void ba_id_points(BaProblem pb, const double* __restrict__ poses,
+                                                    const double* __restrict__ rho, const double* __restrict__ pts_in,
+                                                    double* __restrict__ pts_out, const BaState* st) {
+  const int N = pb.N, K = pb.K;
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if ((st && st->done != 0.0) || i >= (long)N * K) return;
+  const int s = (int)(i / K), k = (int)(i - (long)s * K);
+  const double* P = poses + 12 * s;
+  if (!pb.valid[((long)s * N + s) * K + k]) {       // no reference observation: the track is left alone
+    if (pts_in != pts_out)
+      for (int c = 0; c < 3; ++c) pts_out[3 * i + c] = pts_in[3 * i + c];
+    return;
+  }
+  double b[3];
+  ba_id_bearing(pb, s, k, b);
+  double z;
+  if (rho) z = 1.0 / rho[i];
+  else z = P[6] * (pts_in[3 * i] - P[9]) + P[7] * (pts_in[3 * i + 1] - P[10]) + P[8] * (pts_in[3 * i + 2] - P[11]);
+  const double p[3] = {b[0] * z, b[1] * z, z};
+#pragma unroll
+  for (int c = 0; c < 3; ++c) pts_out[3 * i + c] = P[9 + c] + P[c] * p[0] + P[3 + c] * p[1] + P[6 + c] * p[2];
+}
+
+// per track: c = sum w jr.jr, g = sum w jr.r, cost, the E row (observing cameras + the reference camera), ok flags
+__global__ __launch_bounds__(256) void ba_id_linearize(BaProblem pb, const double* __restrict__ pts,
+                                                       const double* __restrict__ poses, double* __restrict__ Cblk,
+                                                       double* __restrict__ gp, double* __restrict__ Eblk,
+                                                       uint8_t* __restrict__ ok, double* __restrict__ cost_part,
+                                                       const BaState* st) {
+  __shared__ double red[4];
+  const int N = pb.N, K = pb.K, tid = threadIdx.x;
+  const long i = (long)blockIdx.x * 256 + tid;
+  double cost = 0.0;
+  if (st->done == 0.0 && i < (long)N * K) {
+    const int s = (int)(i / K), k = (int)(i - (long)s * K);
+    const double X[3] = {pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]};
+    const bool has_ref = pb.valid[((long)s * N + s) * K + k] != 0;
+    double c = 0.0, g = 0.0, Ea[6] = {0, 0, 0, 0, 0, 0};
+    bool any = false;
+    for (int t = 0; t < N; ++t) {
+      const long o = ((long)s * N + t) * K + k, oT = i * N + t;
+      uint8_t good = 0;
+      if (t != s && has_ref && pb.valid[o]) {
+        double r[2], Jc[2][6], Jp[2][3], Ja[2][6], jr[2];
+        if (ba_project(poses + 12 * t, pb.intr + 4 * t, X, (double)pb.uv[2 * o], (double)pb.uv[2 * o + 1], r, Jc, Jp)) {
+          ba_id_chain(poses + 12 * s, X, Jp, Ja, jr);
+          double w;
+          cost += huber_rho(r[0] * r[0] + r[1] * r[1], pb.huber, w);
+          c += w * (jr[0] * jr[0] + jr[1] * jr[1]);
+          g += w * (jr[0] * r[0] + jr[1] * r[1]);
+          double* E = Eblk + 18 * oT;
+#pragma unroll
+          for (int a = 0; a < 6; ++a) {
+            E[3 * a] = w * (Jc[0][a] * jr[0] + Jc[1][a] * jr[1]);
+            E[3 * a + 1] = 0.0;
+            E[3 * a + 2] = 0.0;
+            Ea[a] += w * (Ja[0][a] * jr[0] + Ja[1][a] * jr[1]);
+          }
+          good = 1;
+          any = true;
+        }
+      }
+      if (t != s) ok[oT] = good;
+    }
+    {
+      double* E = Eblk + 18 * (i * N + s);
+#pragma unroll
+      for (int a = 0; a < 6; ++a) { E[3 * a] = Ea[a]; E[3 * a + 1] = 0.0; E[3 * a + 2] = 0.0; }
+      ok[i * N + s] = any ? 1 : 0;
+    }
+    Cblk[6 * i] = c; Cblk[6 * i + 1] = 0.0; Cblk[6 * i + 2] = 0.0; Cblk[6 * i + 3] = 1.0; Cblk[6 * i + 4] = 0.0; Cblk[6 * i + 5] = 1.0;
+    gp[3 * i] = g; gp[3 * i + 1] = 0.0; gp[3 * i + 2] = 0.0;
+  }
+  const double tot = ba_block_sum<256>(cost, red, tid);
+  if (tid == 0) cost_part[blockIdx.x] = 0.5 * tot;
+}
+
+// cost of candidate / start parameters without the reference-view observations (they are met by construction, but only
+// up to rounding: leaving them out keeps the cost exactly the oracle's sum)
+__global__ __launch_bounds__(256) void ba_id_cost(BaProblem pb, const double* __restrict__ pts,
+                                                  const double* __restrict__ poses, double* __restrict__ cost_part,
+                                                  const BaState* st) {
+  __shared__ double red[4];
+  const int N = pb.N, K = pb.K, tid = threadIdx.x;
+  const long i = (long)blockIdx.x * 256 + tid;
+  double cost = 0.0;
+  if (st->done == 0.0 && i < (long)N * K) {
+    const int s = (int)(i / K), k = (int)(i - (long)s * K);
+    const double X[3] = {pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]};
+    if (pb.valid[((long)s * N + s) * K + k])
+      for (int t = 0; t < N; ++t) {
+        const long o = ((long)s * N + t) * K + k;
+        if (t == s || !pb.valid[o]) continue;
+        double r[2], Jc[2][6], Jp[2][3];
+        if (!ba_project(poses + 12 * t, pb.intr + 4 * t, X, (double)pb.uv[2 * o], (double)pb.uv[2 * o + 1], r, Jc, Jp))
+          continue;
+        double w;
+        cost += huber_rho(r[0] * r[0] + r[1] * r[1], pb.huber, w);
+      }
+  }
+  const double tot = ba_block_sum<256>(cost, red, tid);
+  if (tid == 0) cost_part[blockIdx.x] = 0.5 * tot;
+}
+
+// direct camera-camera blocks: X[s][t] = sum_k w Ja(s, k, t)^T Jc(s, k, t)  (6 x 6; rows: reference camera s).  One wave per (s, t).
+__global__ __launch_bounds__(64) void ba_id_cross_blocks(BaProblem pb, const double* __restrict__ pts,
+                                                         const double* __restrict__ poses, double* __restrict__ Xblk,
+                                                         const BaState* st) {
+  const int N = pb.N, K = pb.K, s = blockIdx.y, t = blockIdx.x, lane = threadIdx.x;
+  if (st->done != 0.0) return;
+  double a[36];
+#pragma unroll
+  for (int c = 0; c < 36; ++c) a[c] = 0.0;
+  if (s != t)
+    for (int k = lane; k < K; k += 64) {
+      const long i = (long)s * K + k, o = ((long)s * N + t) * K + k;
+      if (!pb.valid[o] || !pb.valid[((long)s * N + s) * K + k]) continue;
+      const double X[3] = {pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]};
+      double r[2], Jc[2][6], Jp[2][3], Ja[2][6], jr[2];
+      if (!ba_project(poses + 12 * t, pb.intr + 4 * t, X, (double)pb.uv[2 * o], (double)pb.uv[2 * o + 1], r, Jc, Jp)) continue;
+      ba_id_chain(poses + 12 * s, X, Jp, Ja, jr);
+      double w;
+      huber_rho(r[0] * r[0] + r[1] * r[1], pb.huber, w);
+#pragma unroll
+      for (int p = 0; p < 6; ++p)
+#pragma unroll
+        for (int c = 0; c < 6; ++c) a[6 * p + c] += w * (Ja[0][p] * Jc[0][c] + Ja[1][p] * Jc[1][c]);
+    }
+#pragma unroll
+  for (int c = 0; c < 36; ++c) {
+    const double v = wave_sum_f64(a[c]);
+    if (lane == 0) Xblk[((long)s * N + t) * 36 + c] = v;
+  }
+}
+// S (lower triangle) += the cross blocks: H[tr][tc] = X[tr][tc] + X[tc][tr]^T
+__global__ __launch_bounds__(256) void ba_id_add_cross(int N, const double* __restrict__ Xblk, double* __restrict__ S,
+                                                       const BaState* st) {
+  if (st->done != 0.0) return;
+  const int n = 6 * N;
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= (long)n * n) return;
+  const int r = (int)(e / n), c = (int)(e - (long)r * n);
+  const int tr = r / 6, tc = c / 6;
+  if (tr <= tc) return;
+  const int a = r - 6 * tr, b = c - 6 * tc;
+  S[e] += Xblk[((long)tr * N + tc) * 36 + 6 * a + b] + Xblk[((long)tc * N + tr) * 36 + 6 * b + a];
+}
+
+// d rho = -(g + sum_t E_it . dc_t) / (c + D): candidate inverse depths and the model decrease
+__global__ __launch_bounds__(256) void ba_id_backsub(BaProblem pb, const double* __restrict__ pts,
+                                                     const double* __restrict__ poses, const double* __restrict__ Cblk,
+                                                     const double* __restrict__ gp, const double* __restrict__ Eblk,
+                                                     const uint8_t* __restrict__ ok, const double* __restrict__ dcam,
+                                                     double* __restrict__ rho_new, double* __restrict__ model_part,
+                                                     const BaState* st) {
+  __shared__ double red[4];
+  const int N = pb.N, K = pb.K, tid = threadIdx.x;
+  const long i = (long)blockIdx.x * 256 + tid;
+  double model = 0.0;
+  if (st->done == 0.0 && i < (long)N * K) {
+    const int s = (int)(i / K);
+    const double* P = poses + 12 * s;
+    const double z = P[6] * (pts[3 * i] - P[9]) + P[7] * (pts[3 * i + 1] - P[10]) + P[8] * (pts[3 * i + 2] - P[11]);
+    double rho = 1.0 / z, Ci[6], D[3], dr = 0.0;
+    if (st->chol_fail == 0.0 && ba_point_inverse(Cblk + 6 * i, st->radius, Ci, D)) {
+      double v = gp[3 * i];
+      for (int t = 0; t < N; ++t) {
+        if (!ok[i * N + t]) continue;
+        const double* E = Eblk + 18 * (i * N + t);
+#pragma unroll
+        for (int a = 0; a < 6; ++a) v += E[3 * a] * dcam[6 * t + a];
+      }
+      dr = -Ci[0] * v;
+      model = -0.5 * gp[3 * i] * dr + 0.5 * D[0] * dr * dr;
+    }
+    rho_new[i] = rho + dr;
+  }
+  const double tot = ba_block_sum<256>(model, red, tid);
+  if (tid == 0) model_part[blockIdx.x] = tot;
+}
+
 static inline int ba_nblk(int N, int K) { return (int)(((long)N * K + 255) / 256); }
 
 extern "C" long pi3_ba_workspace_doubles(int N, int K) {
   const long n6 = 6L * N, nk = (long)N * K;
   return 16 /*state*/ + 6 * nk + 3 * nk + 3 * nk /*pts_new*/ + 12L * N /*poses_new*/ + 21L * N + 6L * N /*gc*/ +
          6L * N /*dcam*/ + 6L * N /*Dcam*/ + BA_SLICES * n6 * n6 + BA_SLICES * n6 + 2 * n6 * n6 + 18 * nk * N + (nk * N + 7) / 8 + 3L * ba_nblk(N, K) +
-         3L * N + 64;
+         3L * N + 64 + nk /*inverse depth: rho_new*/ + 36L * N * N /*cross blocks*/;
 }
 
 static int ba_run(double* points, double* poses, const double* intr, const float* uv, const unsigned char* valid,
                   const float* uvT, const unsigned char* validT, int N, int K, double huber_width, int max_iters,
                   const double* prior_R, const double* prior_C, const unsigned char* prior_flag, double sqrt_info_rot,
-                  double sqrt_info_pos, int homogeneous, double* summary_dev, double* workspace, long workspace_doubles,
-                  void* stream) {
+                  double sqrt_info_pos, int mode /* 0 Euclidean, 1 homogeneous, 2 inverse depth */, double* summary_dev,
+                  double* workspace, long workspace_doubles, void* stream) {
   if (!points || !poses || !intr || !uv || !valid || !uvT || !validT || !summary_dev || !workspace || N <= 0 ||
       N > BA_MAXN || K <= 0 || max_iters < 0 || !(huber_width > 0.0) ||
       ((prior_flag != nullptr) && (!prior_R || !prior_C))) {
@@ -840,6 +1093,10 @@ static int ba_run(double* points, double* poses, const double* intr, const float
   double* prior_cost = w; w += N;
   double* model_cam = w; w += N;
   double* prior_cost2 = w; w += N;
+  w += 64;      // (the spare doubles of the size formula)
+  double* rho_new = w; w += nk;
+  double* Xblk = w; w += 36L * N * N;
+  const bool invd = mode == 2;
   if (hipMemsetAsync(state, 0, 16 * sizeof(double), st) != hipSuccess) {
     pi3_set_error("pi3_bundle_adjust: hipMemsetAsync failed");
     return PI3_ERR_LAUNCH;
@@ -848,22 +1105,35 @@ static int ba_run(double* points, double* poses, const double* intr, const float
   pb.uv = uv; pb.valid = valid; pb.uvT = uvT; pb.validT = validT; pb.intr = intr;
   pb.prior_R = prior_R; pb.prior_C = prior_C; pb.prior_flag = prior_flag;
   pb.sqrt_info_rot = sqrt_info_rot; pb.sqrt_info_pos = sqrt_info_pos; pb.huber = huber_width; pb.N = N; pb.K = K;
-  pb.homogeneous = homogeneous ? 1 : 0;
+  pb.homogeneous = mode == 1 ? 1 : 0;
+  pb.invdepth = invd ? 1 : 0;
+  if (invd)   // InitializeInverseDepth: every track onto the ray of its reference keypoint, at its current depth there
+    hipLaunchKernelGGL(ba_id_points, dim3(nblk), dim3(256), 0, st, pb, poses, (const double*)nullptr, points, points,
+                       (const BaState*)nullptr);
   // cost at the start
-  hipLaunchKernelGGL(ba_cost_points, dim3(nblk), dim3(256), 0, st, pb, points, poses, cost_part, state);
+  if (invd) hipLaunchKernelGGL(ba_id_cost, dim3(nblk), dim3(256), 0, st, pb, points, poses, cost_part, state);
+  else hipLaunchKernelGGL(ba_cost_points, dim3(nblk), dim3(256), 0, st, pb, points, poses, cost_part, state);
   hipLaunchKernelGGL(ba_prior_cost, dim3((N + 63) / 64), dim3(64), 0, st, pb, poses, prior_cost, state);
   hipLaunchKernelGGL(ba_decide, dim3(1), dim3(256), 0, st, nblk, N, 3 * nk, cost_part, prior_cost, model_part, model_cam, 1,
                      points, pts_new, poses, poses_new, max_iters, state);
   for (int it = 0; it < max_iters; ++it) {
-    hipLaunchKernelGGL(ba_linearize_points, dim3(nblk), dim3(256), 0, st, pb, points, poses, Cblk, gp, cost_part, state);
+    if (invd) {
+      hipLaunchKernelGGL(ba_id_linearize, dim3(nblk), dim3(256), 0, st, pb, points, poses, Cblk, gp, Eblk, obs_ok, cost_part,
+                         state);
+      hipLaunchKernelGGL(ba_id_cross_blocks, dim3(N, N), dim3(64), 0, st, pb, points, poses, Xblk, state);
+    } else {
+      hipLaunchKernelGGL(ba_linearize_points, dim3(nblk), dim3(256), 0, st, pb, points, poses, Cblk, gp, cost_part, state);
+      hipLaunchKernelGGL(ba_obs_blocks, dim3((unsigned)((nk * N + 255) / 256)), dim3(256), 0, st, pb, points, poses, Eblk,
+                         obs_ok, state);
+    }
     hipLaunchKernelGGL(ba_camera_blocks, dim3(N), dim3(256), 0, st, pb, points, poses, Bblk, gc, prior_cost, state);
-    hipLaunchKernelGGL(ba_obs_blocks, dim3((unsigned)((nk * N + 255) / 256)), dim3(256), 0, st, pb, points, poses, Eblk,
-                       obs_ok, state);
     hipLaunchKernelGGL(ba_schur_rows, dim3(N, BA_SLICES), dim3(BA_MAXN), 0, st, pb, Eblk, obs_ok, Cblk, gp, S_part,
                        rhs_part, state);
     const int n = (int)n6;
     hipLaunchKernelGGL(ba_assemble_cameras, dim3((unsigned)((n6 * n6 + 255) / 256)), dim3(256), 0, st, N, S_part, rhs_part,
                        Bblk, gc, S, dcam, Dcam, state);
+    if (invd)
+      hipLaunchKernelGGL(ba_id_add_cross, dim3((unsigned)((n6 * n6 + 255) / 256)), dim3(256), 0, st, N, Xblk, S, state);
     for (int c0 = 0; c0 < n; c0 += BA_NB) {
       const int nb = n - c0 < BA_NB ? n - c0 : BA_NB;
       hipLaunchKernelGGL(ba_chol_diag, dim3(1), dim3(256), 0, st, n, c0, nb, S, Lfac, state);
@@ -875,11 +1145,20 @@ static int ba_run(double* points, double* poses, const double* intr, const float
       }
     }
     hipLaunchKernelGGL(ba_chol_solve, dim3(1), dim3(1024), 0, st, n, Lfac, dcam, state);
-    hipLaunchKernelGGL(ba_backsub_points, dim3(nblk), dim3(256), 0, st, pb, points, poses, Cblk, gp, dcam, pts_new,
-                       model_part, state);
+    if (invd)
+      hipLaunchKernelGGL(ba_id_backsub, dim3(nblk), dim3(256), 0, st, pb, points, poses, Cblk, gp, Eblk, obs_ok, dcam, rho_new,
+                         model_part, state);
+    else
+      hipLaunchKernelGGL(ba_backsub_points, dim3(nblk), dim3(256), 0, st, pb, points, poses, Cblk, gp, dcam, pts_new,
+                         model_part, state);
     hipLaunchKernelGGL(ba_update_cameras, dim3((N + 63) / 64), dim3(64), 0, st, N, poses, dcam, gc, Dcam, poses_new,
                        model_cam, state);
-    hipLaunchKernelGGL(ba_cost_points, dim3(nblk), dim3(256), 0, st, pb, pts_new, poses_new, cost_part2, state);
+    if (invd) {      // candidate points from the candidate reference poses and inverse depths
+      hipLaunchKernelGGL(ba_id_points, dim3(nblk), dim3(256), 0, st, pb, poses_new, rho_new, points, pts_new, state);
+      hipLaunchKernelGGL(ba_id_cost, dim3(nblk), dim3(256), 0, st, pb, pts_new, poses_new, cost_part2, state);
+    } else {
+      hipLaunchKernelGGL(ba_cost_points, dim3(nblk), dim3(256), 0, st, pb, pts_new, poses_new, cost_part2, state);
+    }
     hipLaunchKernelGGL(ba_prior_cost, dim3((N + 63) / 64), dim3(64), 0, st, pb, poses_new, prior_cost2, state);
     hipLaunchKernelGGL(ba_decide, dim3(1), dim3(256), 0, st, nblk, N, 3 * nk, cost_part2, prior_cost2, model_part, model_cam,
                        0, points, pts_new, poses, poses_new, max_iters, state);
@@ -912,6 +1191,18 @@ extern "C" int pi3_bundle_adjust_homogeneous(double* points, double* poses, cons
                 sqrt_info_rot, sqrt_info_pos, 1, summary_dev, workspace, workspace_doubles, stream);
 }
 
+// The reference's --use-inverse-depth (see "inverse depth" above): one inverse depth per track along the bearing of its
+// keypoint in its own frame.  `points` are snapped onto those rays first and stay Euclidean for the caller.
+extern "C" int pi3_bundle_adjust_inverse_depth(double* points, double* poses, const double* intr, const float* uv,
+                                               const unsigned char* valid, const float* uvT, const unsigned char* validT,
+                                               int N, int K, double huber_width, int max_iters, const double* prior_R,
+                                               const double* prior_C, const unsigned char* prior_flag,
+                                               double sqrt_info_rot, double sqrt_info_pos, double* summary_dev,
+                                               double* workspace, long workspace_doubles, void* stream) {
+  return ba_run(points, poses, intr, uv, valid, uvT, validT, N, K, huber_width, max_iters, prior_R, prior_C, prior_flag,
+                sqrt_info_rot, sqrt_info_pos, 2, summary_dev, workspace, workspace_doubles, stream);
+}
+
 extern "C" int pi3_ba_outlier_tracks(const double* points, const double* poses, const double* intr, const float* uv,
                                      const unsigned char* valid, int N, int K, double max_reprojection_px,
                                      double min_triangulation_angle_deg, unsigned char* estimated, void* stream) {
@@ -922,7 +1213,7 @@ extern "C" int pi3_ba_outlier_tracks(const double* points, const double* poses, 
   BaProblem pb;
   pb.uv = uv; pb.valid = valid; pb.uvT = nullptr; pb.validT = nullptr; pb.intr = intr;
   pb.prior_R = nullptr; pb.prior_C = nullptr; pb.prior_flag = nullptr;
-  pb.sqrt_info_rot = 0; pb.sqrt_info_pos = 0; pb.huber = 1.0; pb.N = N; pb.K = K; pb.homogeneous = 0;
+  pb.sqrt_info_rot = 0; pb.sqrt_info_pos = 0; pb.huber = 1.0; pb.N = N; pb.K = K; pb.homogeneous = 0; pb.invdepth = 0;
   hipLaunchKernelGGL(ba_outlier_tracks, dim3(ba_nblk(N, K)), dim3(256), 0, (hipStream_t)stream, pb, points, poses,
                      max_reprojection_px, cos(min_triangulation_angle_deg * 3.14159265358979323846 / 180.0), estimated);
   return pi3_check_launch("ba_outlier_tracks");

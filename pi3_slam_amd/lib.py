@@ -59,6 +59,7 @@ SIGNATURES = {
     "pi3_remap_bilinear_u8": [_vp, _i, _i, _i, _vp, _vp, _i, _i, _vp, _vp],
     "pi3_bundle_adjust": [_vp] * 7 + [_i, _i, _d, _i, _vp, _vp, _vp, _d, _d, _vp, _vp, _l, _vp],
     "pi3_bundle_adjust_homogeneous": [_vp] * 7 + [_i, _i, _d, _i, _vp, _vp, _vp, _d, _d, _vp, _vp, _l, _vp],
+    "pi3_bundle_adjust_inverse_depth": [_vp] * 7 + [_i, _i, _d, _i, _vp, _vp, _vp, _d, _d, _vp, _vp, _l, _vp],
     "pi3_ba_outlier_tracks": [_vp] * 5 + [_i, _i, _d, _d, _vp, _vp],
     "pi3_set_knob": [C.c_char_p, _l],
 }

@@ -63,9 +63,7 @@ class Pi3SLAMOnline:
                  use_inverse_depth: bool = False, moge_model=None, moge_model_path: Optional[str] = None,
                  hip_graph: bool = True, output_dir: Optional[str] = None, num_loader_workers: int = 0,
                  bundle_adjust: bool = True):
-        if use_inverse_depth:
-            from .alignment import INVERSE_DEPTH_MESSAGE
-            raise NotImplementedError(INVERSE_DEPTH_MESSAGE)
+        self.use_inverse_depth = bool(use_inverse_depth)   # online_reconstructor.py:246,1018,1235
         self.chunk_length, self.overlap = int(chunk_length), int(overlap)
         self.pixel_limit = 255000 // 2
         self.output_dir = output_dir or os.path.join("/tmp", f"pi3_online_{os.getpid()}")
@@ -116,7 +114,8 @@ class Pi3SLAMOnline:
         if not self.bundle_adjust or chunk.get("keypoints") is None:
             return None
         return {"width": int(chunk.get("original_width", 1920)), "height": int(chunk.get("original_height", 1080)),
-                "max_observations_per_track": self.max_observations_per_track}
+                "max_observations_per_track": self.max_observations_per_track,
+                "settings": {"inverse_depth": self.use_inverse_depth}}
 
     def _refine_new_chunk(self, chunk: Dict) -> None:
         args = self._ba_args(chunk)
@@ -126,7 +125,7 @@ class Pi3SLAMOnline:
         t0 = time.time()
         with torch.cuda.stream(self._align_stream):
             bundle_adjust_chunk(chunk, args["width"], args["height"], args["max_observations_per_track"],
-                                str(self.device), PER_CHUNK)
+                                str(self.device), dict(PER_CHUNK, **args["settings"]))
         self._record_timing("bundle_adjust_chunk", time.time() - t0)
 
     def _consume(self, chunk: Dict) -> Dict:
@@ -149,7 +148,8 @@ class Pi3SLAMOnline:
             return np.eye(4)
         with torch.cuda.stream(self._align_stream):     # beside, not behind, the next chunk's forward
             ok, info = align_and_refine_reconstructions(self.chunk_reconstructions[-2], chunk, self._matches,
-                                                        device=str(self.device), bundle_adjust=self._ba_args(chunk))
+                                                        use_inverse_depth=self.use_inverse_depth, device=str(self.device),
+                                                        bundle_adjust=self._ba_args(chunk))
         self.alignment_infos.append(info if ok else None)
         if not ok:
             print(f"   ❌ Alignment failed for chunk {len(self.chunk_reconstructions) - 1}")
@@ -224,7 +224,7 @@ class Pi3SLAMOnline:
                             with torch.cuda.stream(self._align_stream):
                                 my_ok, info = align_and_refine_reconstructions(
                                     prev_payload, chunk, self._matches, device=str(self.device),
-                                    bundle_adjust=self._ba_args(chunk))
+                                    use_inverse_depth=self.use_inverse_depth, bundle_adjust=self._ba_args(chunk))
                             if my_ok:
                                 my_G = info["sim3_summary"]["global_matrix"]
                         pay = chain_payload(chunk)

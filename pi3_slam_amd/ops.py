@@ -493,10 +493,13 @@ def remap_bilinear_u8(frames_u8: torch.Tensor, map_x: torch.Tensor, map_y: torch
 def bundle_adjust(points: torch.Tensor, poses: torch.Tensor, intr: torch.Tensor, uv: torch.Tensor, valid: torch.Tensor,
                   huber_width: float, max_iters: int, prior_R: Optional[torch.Tensor] = None,
                   prior_C: Optional[torch.Tensor] = None, prior_flag: Optional[torch.Tensor] = None,
-                  sqrt_info_rot: float = 0.0, sqrt_info_pos: float = 0.0, homogeneous: bool = False) -> torch.Tensor:
+                  sqrt_info_rot: float = 0.0, sqrt_info_pos: float = 0.0, homogeneous: bool = False,
+                  inverse_depth: bool = False) -> torch.Tensor:
     """points f64 [N*K,3] and poses f64 [N,12] (R world->camera | centre) refined in place; intr f64 [N,4];
     uv f32 [N,N,K,2], valid u8 [N,N,K].  -> summary f64 [11] (device).  homogeneous: Theia's default point
-    parametrization (pi3_bundle_adjust_homogeneous) instead of Euclidean steps."""
+    parametrization (pi3_bundle_adjust_homogeneous) instead of Euclidean steps; inverse_depth: one inverse depth per track
+    along its reference keypoint's ray (pi3_bundle_adjust_inverse_depth; points are snapped onto those rays)."""
+    assert not (homogeneous and inverse_depth)
     lib = _L.load()
     N, _, K = valid.shape
     for t in (points, poses, intr):
@@ -511,7 +514,8 @@ def bundle_adjust(points: torch.Tensor, poses: torch.Tensor, intr: torch.Tensor,
     if prior_flag is not None:
         assert prior_flag.dtype == torch.uint8 and prior_R.dtype == torch.float64 and prior_C.dtype == torch.float64
         prior_R, prior_C, prior_flag = prior_R.contiguous(), prior_C.contiguous(), prior_flag.contiguous()
-    fn = lib.pi3_bundle_adjust_homogeneous if homogeneous else lib.pi3_bundle_adjust
+    fn = (lib.pi3_bundle_adjust_inverse_depth if inverse_depth else
+          lib.pi3_bundle_adjust_homogeneous if homogeneous else lib.pi3_bundle_adjust)
     rc = fn(points.data_ptr(), poses.data_ptr(), intr.data_ptr(), uv.data_ptr(), valid.data_ptr(),
             uvT.data_ptr(), validT.data_ptr(), N, K, float(huber_width), int(max_iters),
             _L.ptr(prior_R), _L.ptr(prior_C), _L.ptr(prior_flag), float(sqrt_info_rot),

@@ -66,10 +66,9 @@ class OfflineReconstructor:
         self.overlap = int(overlap) if overlap is not None else (loaded_ov or 10)
         self.max_observations_per_track = max_observations_per_track
         self.save_per_chunk = save_per_chunk
-        if use_inverse_depth:      # accepted-and-ignored would silently change what the user asked for
-            from .alignment import INVERSE_DEPTH_MESSAGE
-            raise NotImplementedError(INVERSE_DEPTH_MESSAGE)
-        self.use_inverse_depth = False
+        # the reference's --use-inverse-depth: both adjustments run with one inverse depth per track
+        # (utils/chunk_reconstruction.py:187-204, utils/reconstruction_alignment.py:147-152; pi3_bundle_adjust_inverse_depth)
+        self.use_inverse_depth = bool(use_inverse_depth)
         from .dist import resolve_device
         self.device = resolve_device(device)     # 'cuda' -> this rank's card (the one the process group is bound to)
         if torch.cuda.is_available():
@@ -104,7 +103,8 @@ class OfflineReconstructor:
             return None
         matches = create_view_graph_matches(self.chunk_length, self.overlap)
         ok, info = align_and_refine_reconstructions(self.reconstructions[-2], self.reconstructions[-1], matches,
-                                                    device=self.device, bundle_adjust=self._ba_args(self.reconstructions[-1]))
+                                                    use_inverse_depth=self.use_inverse_depth, device=self.device,
+                                                    bundle_adjust=self._ba_args(self.reconstructions[-1]))
         if not ok:
             print(f"   ❌ Alignment failed for chunk {len(self.reconstructions) - 1}")
             return None
@@ -116,7 +116,7 @@ class OfflineReconstructor:
         # offline_reconstructor.py:66-67: 1920x1080 when a chunk file does not carry its size
         return {"width": int(data.get("original_width", 1920)), "height": int(data.get("original_height", 1080)),
                 "max_observations_per_track": self.max_observations_per_track,
-                "settings": {"sanity_gate": self.ba_sanity_gate}}
+                "settings": {"sanity_gate": self.ba_sanity_gate, "inverse_depth": self.use_inverse_depth}}
 
     def _summarise_refinement(self) -> None:
         """Which adjustments ran, were applied, or were kept out by the sanity gate - `refinement_stages` alone lists a
@@ -293,6 +293,7 @@ class OfflineReconstructor:
                 ok = True
                 if c > 0:
                     ok, info = align_and_refine_reconstructions(prev, data, matches, device=self.device,
+                                                                use_inverse_depth=self.use_inverse_depth,
                                                                 bundle_adjust=self._ba_args(data))
                     self.alignment_infos.append(info if ok else None)
                     if not ok:

@@ -283,3 +283,53 @@ def test_homogeneous_and_euclidean_settings_of_the_chunk_adjuster(dev):
         ops.bundle_adjust(p1, r1, intr, uv, valid, 3.0, 0, homogeneous=hom)
         assert torch.equal(p0, p1) and torch.equal(r0, r1)
     assert abs(costs[True] - costs[False]) <= 1e-4 * costs[False], costs
+
+
+@pytest.mark.parametrize("N,K,iters,with_prior,noise", [(5, 8, 4, False, 0.5), (7, 10, 6, True, 0.3), (12, 9, 3, False, 1.0),
+                                                        (26, 8, 2, True, 0.5)])
+def test_inverse_depth_parametrization_matches_the_oracle(dev, N, K, iters, with_prior, noise):
+    """pi3_bundle_adjust_inverse_depth (the reference's --use-inverse-depth: InitializeInverseDepth +
+    use_inverse_depth_parametrization, utils/chunk_reconstruction.py:187-204) against oracle/ba_ref.
+    bundle_adjust_inverse_depth (dense normal equations over 6 N + N K unknowns; Jacobians checked by finite differences
+    in tests/test_ba_oracle.py): the same iterations and accepted steps, cost to 1e-9, cameras to 1e-7, the returned
+    Euclidean points (on the rays of their reference keypoints) to 1e-6 - small and multi-panel camera systems, with and
+    without pose priors, Huber active."""
+    from oracle import ba_ref
+    from pi3_slam_amd import ops
+    pb = make_problem(N=N, K=K, seed=77 + N, noise_px=noise, outlier_frac=0.04, perturb=0.6)
+    huber = 3.0 if with_prior else 2.0
+    prior = None
+    pr = pc = pf = None
+    if with_prior:
+        flag = np.zeros(N, np.uint8)
+        flag[: max(2, N // 4)] = 1
+        prior = dict(R=pb["R_gt"], C=pb["C_gt"] + 0.03, flag=flag, sqrt_info_rot=0.5 ** 0.5, sqrt_info_pos=0.2)
+        pr, pc, pf = (torch.from_numpy(pb["R_gt"].reshape(N, 9)).to(dev), torch.from_numpy(prior["C"]).to(dev),
+                      torch.from_numpy(flag).to(dev))
+    R, C, X, s = ba_ref.bundle_adjust_inverse_depth(pb["R"], pb["C"], pb["intr"], pb["X"], pb["uv"], pb["valid"], huber, iters,
+                                                    prior)
+    pts, rc, intr, uv, valid = _to_dev(pb, dev)
+    out = ops.bundle_adjust(pts, rc, intr, uv, valid, huber, iters, pr, pc, pf, 0.5 ** 0.5 if prior else 0.0,
+                            0.2 if prior else 0.0, inverse_depth=True).cpu().numpy()
+    torch.cuda.synchronize()
+    assert abs(out[8] - s["initial_cost"]) <= 1e-9 * s["initial_cost"], (out[8], s["initial_cost"])
+    assert (int(out[5]), int(out[6])) == (s["iterations"], s["accepted_steps"]) and out[9] == 0, (out, s)
+    assert abs(out[0] - s["final_cost"]) <= 1e-8 * s["final_cost"] + 1e-12, (out[0], s["final_cost"])
+    assert out[0] < out[8]
+    rcn = rc.cpu().numpy()
+    np.testing.assert_allclose(rcn[:, :9].reshape(N, 3, 3), R, atol=1e-7)
+    np.testing.assert_allclose(rcn[:, 9:], C, atol=1e-7)
+    np.testing.assert_allclose(pts.cpu().numpy(), X, atol=1e-6)
+    # the returned points sit on the rays of their reference keypoints: reprojection into the reference view = the keypoint
+    Xn = pts.cpu().numpy().reshape(N, K, 3)
+    for s_ in range(N):
+        p = (Xn[s_] - rcn[s_, 9:]) @ rcn[s_, :9].reshape(3, 3).T
+        u = pb["intr"][s_, 0] * p[:, 0] / p[:, 2] + pb["intr"][s_, 2]
+        v = pb["intr"][s_, 1] * p[:, 1] / p[:, 2] + pb["intr"][s_, 3]
+        assert np.abs(u - pb["uv"][s_, s_, :, 0]).max() < 1e-6 and np.abs(v - pb["uv"][s_, s_, :, 1]).max() < 1e-6
+    # zero iterations: only the snap (InitializeInverseDepth), poses untouched
+    pts0, rc0, _, _, _ = _to_dev(pb, dev)
+    ops.bundle_adjust(pts0, rc0, intr, uv, valid, huber, 0, inverse_depth=True)
+    b, rho, anchor = ba_ref.inverse_depth_state(pb["R"], pb["C"], pb["intr"], pb["X"], pb["uv"], pb["valid"])
+    np.testing.assert_allclose(pts0.cpu().numpy(), ba_ref.inverse_depth_points(pb["R"], pb["C"], b, rho, anchor), atol=1e-12)
+    assert torch.equal(rc0, _to_dev(pb, dev)[1])

@@ -138,3 +138,53 @@ def test_homogeneous_point_parametrization_reaches_the_same_optimum():
             res = np.abs(s * A @ Rg.T + t - B)
             assert res[: len(Ce)].max() < cam_tol, (iters, seed, res[: len(Ce)].max())
             assert abs(s - 1.0) < 0.03                          # the free gauge: per-cent level, not zero
+
+
+def test_inverse_depth_jacobians_and_convergence():
+    """oracle.bundle_adjust_inverse_depth (the reference's --use-inverse-depth, restated: one inverse depth per track along
+    the bearing of its keypoint in its own frame): analytic Jacobians w.r.t. the reference camera and rho against central
+    differences; on exact observations a perturbed start converges back to zero cost; the returned points reproject
+    exactly onto their reference keypoints; scipy cannot lower the converged cost."""
+    from scipy.optimize import minimize
+    pb = make_problem(N=5, K=8, seed=2, noise_px=0.5, perturb=0.8)
+    R, C, intr, X, uv, valid = (pb[k] for k in ("R", "C", "intr", "X", "uv", "valid"))
+    b, rho, anchor = ba_ref.inverse_depth_state(R, C, intr, X, uv, valid)
+    trk, cam, px = ba_ref.invdepth_observations(uv, valid)
+    assert not np.any(cam == anchor[trk])
+    r, Jt, Ja, Jr, front = ba_ref.invdepth_jacobians(R, C, intr, b, rho, anchor, trk, cam, px)
+
+    def res(R_, C_, rho_):
+        return ba_ref.residuals(R_, C_, intr, ba_ref.inverse_depth_points(R_, C_, b, rho_, anchor), trk, cam, px)[0]
+    eps, worst = 1e-6, 0.0
+    for m in (0, 7, 19, 33):
+        a = anchor[trk[m]]
+        for j in range(6):
+            d = np.zeros(6)
+            d[j] = eps
+            Rp, Cp, Rm, Cm = R.copy(), C.copy(), R.copy(), C.copy()
+            Rp[a], Cp[a] = ba_ref.exp_so3(d[:3]) @ R[a], C[a] + d[3:]
+            Rm[a], Cm[a] = ba_ref.exp_so3(-d[:3]) @ R[a], C[a] - d[3:]
+            worst = max(worst, np.abs((res(Rp, Cp, rho)[m] - res(Rm, Cm, rho)[m]) / (2 * eps) - Ja[m, :, j]).max())
+        rp, rm = rho.copy(), rho.copy()
+        rp[trk[m]] += eps
+        rm[trk[m]] -= eps
+        worst = max(worst, np.abs((res(R, C, rp)[m] - res(R, C, rm)[m]) / (2 * eps) - Jr[m]).max())
+    assert worst < 1e-6 * max(np.abs(Ja).max(), np.abs(Jr).max())
+    # exact data, perturbed start -> zero cost
+    pe = make_problem(N=5, K=8, seed=3, noise_px=0.0, perturb=0.6)
+    Re, Ce, Xe, se = ba_ref.bundle_adjust_inverse_depth(pe["R"], pe["C"], pe["intr"], pe["X"], pe["uv"], pe["valid"], 2.0, 40)
+    assert se["final_cost"] < 1e-9 * se["initial_cost"]
+    # noisy data: converged cost is a local minimum of the same objective (L-BFGS from the solution cannot improve it)
+    Rn, Cn, Xn, sn = ba_ref.bundle_adjust_inverse_depth(R, C, intr, X, uv, valid, 2.0, 50)
+    bn, rhon, _ = ba_ref.inverse_depth_state(Rn, Cn, intr, Xn, uv, valid)
+    N, P = len(R), len(rho)
+
+    def fun(z):
+        R2 = np.stack([ba_ref.exp_so3(z[6 * t:6 * t + 3]) @ Rn[t] for t in range(N)])
+        C2 = Cn + z[:6 * N].reshape(N, 6)[:, 3:]
+        return ba_ref.invdepth_cost(R2, C2, intr, bn, rhon + z[6 * N:], anchor, trk, cam, px, 2.0, None)
+    opt = minimize(fun, np.zeros(6 * N + P), method="L-BFGS-B", options={"maxiter": 500, "ftol": 1e-15, "gtol": 1e-10})
+    assert opt.fun >= sn["final_cost"] * (1 - 1e-5)
+    for s_ in range(N):      # the points reproject onto their reference keypoints
+        p = (Xn.reshape(N, -1, 3)[s_] - Cn[s_]) @ Rn[s_].T
+        assert np.abs(intr[s_, 0] * p[:, 0] / p[:, 2] + intr[s_, 2] - uv[s_, s_, :, 0]).max() < 1e-9

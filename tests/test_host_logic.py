@@ -204,17 +204,20 @@ def test_in_order_drain_releases_chunks_in_chunk_order():
         d.put(3, "again")
 
 
-def test_use_inverse_depth_is_refused_not_ignored(tmp_path):
-    """utils/chunk_reconstruction.py:186-187,199-204 / utils/reconstruction_alignment.py:147-152: the reference's
-    inverse-depth parametrisation is not implemented by the device adjuster; the flag must raise, not change meaning."""
-    from pi3_slam_amd.alignment import align_and_refine_reconstructions
+def test_use_inverse_depth_reaches_both_adjustments(tmp_path):
+    """utils/chunk_reconstruction.py:186-187,199-204 / utils/reconstruction_alignment.py:147-152: --use-inverse-depth
+    switches BOTH adjustments to one inverse-depth parameter per track.  The flag travels from the constructor into the
+    settings of the per-chunk stage and, through align_and_refine_reconstructions, of the prior-constrained stage."""
     from pi3_slam_amd.reconstructor import OfflineReconstructor
-    with pytest.raises(NotImplementedError):
-        OfflineReconstructor(str(tmp_path), str(tmp_path / "o"), use_inverse_depth=True)
-    with pytest.raises(NotImplementedError):
-        align_and_refine_reconstructions({}, {}, [(0, 0)], use_inverse_depth=True)
     r = OfflineReconstructor(str(tmp_path), str(tmp_path / "o"), device="cpu")
     assert r.use_inverse_depth is False and r.bundle_adjust is True
+    r = OfflineReconstructor(str(tmp_path), str(tmp_path / "o2"), device="cpu", use_inverse_depth=True)
+    assert r.use_inverse_depth is True
+    args = r._ba_args({"keypoints": torch.zeros(2, 3, 2), "original_width": 10, "original_height": 8})
+    assert args["settings"]["inverse_depth"] is True and args["settings"]["sanity_gate"] is True
+    from pi3_slam_amd.bundle_adjust import AFTER_ALIGNMENT, PER_CHUNK
+    assert PER_CHUNK["homogeneous_points"] and AFTER_ALIGNMENT["homogeneous_points"]        # the reference's default
+    assert "inverse_depth" not in PER_CHUNK or PER_CHUNK["inverse_depth"] is False
 
 
 def test_bundle_adjust_sanity_gate():

@@ -245,6 +245,14 @@ def test_chunk_bundle_adjust_and_reconstructor_flag(dev, tmp_path):
     assert traj[True].shape == traj[False].shape == (6, 8)
     assert np.abs(traj[True][:, 1:4] - traj[False][:, 1:4]).max() < 2e-2     # consistent data: BA only polishes
     assert np.abs(traj[True][:, 1:4] - pb["C_gt"]).max() < 2e-2
+    # the reference's --use-inverse-depth: both stages run with one inverse depth per track
+    rec = OfflineReconstructor(str(tmp_path), str(tmp_path / "out_id"), bundle_adjust=True, use_inverse_depth=True)
+    rec.run()
+    tid = np.loadtxt(tmp_path / "out_id" / "trajectory_tum.txt")
+    assert rec.ba_infos and all(i["success"] for i in rec.ba_infos)
+    assert all(i is None or i.get("bundle_adjustment", {}).get("success") for i in rec.alignment_infos)
+    assert rec.refinement_summary["per_chunk_bundle_adjust"]["applied"] == 2
+    assert tid.shape == (6, 8) and np.abs(tid[:, 1:4] - pb["C_gt"]).max() < 2e-2
 
 
 @pytest.mark.parametrize("N,K,iters,with_prior", [(6, 10, 6, False), (9, 14, 4, True), (22, 12, 3, True), (27, 10, 2, False)])

@@ -158,17 +158,22 @@ def test_fuzz_bundle_adjust_against_schur_oracle(dev):
             prior = dict(R=pb["R_gt"], C=pb["C_gt"] + 0.02, flag=flag, sqrt_info_rot=0.5 ** 0.5, sqrt_info_pos=0.2)
             pr, pc, pf = (torch.from_numpy(pb["R_gt"].reshape(N, 9)).to(dev), torch.from_numpy(prior["C"]).to(dev),
                           torch.from_numpy(flag).to(dev))
-        hom = bool(rng.integers(0, 2))            # Euclidean steps / Theia's homogeneous point parametrization
-        R, C, X, s = ba_ref.bundle_adjust_schur(pb["R"], pb["C"], pb["intr"], pb["X"], pb["uv"], pb["valid"], huber, iters, prior,
-                                                homogeneous=hom)
+        form = int(rng.integers(0, 3))            # Euclidean steps / homogeneous point parametrization / inverse depth
+        hom, invd = form == 1, form == 2
+        if invd:
+            R, C, X, s = ba_ref.bundle_adjust_inverse_depth(pb["R"], pb["C"], pb["intr"], pb["X"], pb["uv"], pb["valid"], huber,
+                                                            iters, prior)
+        else:
+            R, C, X, s = ba_ref.bundle_adjust_schur(pb["R"], pb["C"], pb["intr"], pb["X"], pb["uv"], pb["valid"], huber, iters,
+                                                    prior, homogeneous=hom)
         to = lambda a, dt=None: torch.from_numpy(np.ascontiguousarray(a)).to(dev) if dt is None else \
             torch.from_numpy(np.ascontiguousarray(a)).to(dev, dt)             # noqa: E731
         pts = to(pb["X"])
         rc = to(np.concatenate([pb["R"].reshape(N, 9), pb["C"]], 1))
         intr, uv, valid = to(pb["intr"]), to(pb["uv"]), to(pb["valid"])
         out = ops.bundle_adjust(pts, rc, intr, uv, valid, huber, iters, pr, pc, pf, 0.5 ** 0.5 if prior else 0.0,
-                                0.2 if prior else 0.0, homogeneous=hom).cpu().numpy()
-        tag = (n, N, K, huber, iters, prior is not None, hom)
+                                0.2 if prior else 0.0, homogeneous=hom, inverse_depth=invd).cpu().numpy()
+        tag = (n, N, K, huber, iters, prior is not None, form)
         assert abs(out[8] - s["initial_cost"]) <= 1e-9 * max(s["initial_cost"], 1e-12), tag
         assert (int(out[5]), int(out[6])) == (s["iterations"], s["accepted_steps"]), (tag, out[:10], s)
         assert abs(out[0] - s["final_cost"]) <= 1e-7 * max(s["final_cost"], 1e-9) + 1e-12, (tag, out[0], s["final_cost"])

@@ -815,7 +815,15 @@ __device__ __forceinline__ void g4_glds16(const char* sbase, unsigned voff, unsi
                : "memory", "m0");
 }
 
-template <bool OUT_BF16, int ACT, bool QK = false>
+// fragment read from inline asm (immediate offset), so that its place between the asm MFMAs is the place it is issued
+// at: a C++ load may be hoisted by the scheduler to the top of the block, which is what leaves a lone wave's MFMAs waiting
+// behind a burst of 16 reads + 16 LDS-DMA issues.  The consumer waits with an explicit s_waitcnt lgkmcnt(0).
+template <int OFF>
+__device__ __forceinline__ void g4_lds_read(bf16x8& d, unsigned addr) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF));
+}
+
+template <bool OUT_BF16, int ACT, bool QK = false, bool ILV = false>
 __global__ __launch_bounds__(256) void gemm4w_kernel(GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -935,6 +943,53 @@ __global__ __launch_bounds__(256) void gemm4w_kernel(GemmParams p) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     G4_BARRIER()
+    if constexpr (ILV) {
+      // Interleaved form: every half is eight groups of {2 fragment reads of the NEXT half, (half B) 2 LDS-DMA issues of
+      // tile u + 2, 8 MFMAs of the current half}, all inline asm and therefore issued in exactly this order: the matrix
+      // pipe never waits behind a burst of issue-only instructions (a 16x16x32 MFMA holds the vector issue for 8 of its 16
+      // cycles; the reads and DMA issues ride in the other 8).
+      const unsigned abase0 = lds0 + a_base, wbase0 = lds0 + w_base;
+#define G4_RD1(FA, FW, AB, WB, I) g4_lds_read<(I) * 2048>(FW[I], WB); g4_lds_read<(I) * 2048>(FA[I], AB);
+#define G4_MF8(FA, FW, I)                                                                  \
+  _Pragma("unroll") for (int j = 0; j < 8; ++j)                                            \
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[I][j]) : "v"(FW[I]), "v"(FA[j]));
+#define G4_ST2(U, I)                                                                       \
+  {                                                                                        \
+    const unsigned sb = lds0 + ((U) & 1) * G2_BUF + wave * 4096;                           \
+    const char* sa = Ab + (long)(U) * 128;                                                 \
+    const char* sw = Wb + (long)(U) * 128;                                                 \
+    g4_glds16(sa, aoff[I], sb + ((I) >> 2) * G2_HALF + ((I) & 3) * 1024);                  \
+    g4_glds16(sw, woff[I], sb + (2 + ((I) >> 2)) * G2_HALF + ((I) & 3) * 1024);            \
+  }
+#define G4_GROUP_A(I) G4_RD1(fa1, fw1, ab + off1, wb + off1, I) G4_MF8(fa0, fw0, I)
+#define G4_GROUP_B(I) if (more1) { G4_RD1(fa0, fw0, abn + off0, wbn + off0, I) } if (more2) G4_ST2(u + 2, I) G4_MF8(fa1, fw1, I)
+      {
+        const unsigned ab = abase0, wb = wbase0;
+        G4_RD1(fa0, fw0, ab + off0, wb + off0, 0) G4_RD1(fa0, fw0, ab + off0, wb + off0, 1)
+        G4_RD1(fa0, fw0, ab + off0, wb + off0, 2) G4_RD1(fa0, fw0, ab + off0, wb + off0, 3)
+        G4_RD1(fa0, fw0, ab + off0, wb + off0, 4) G4_RD1(fa0, fw0, ab + off0, wb + off0, 5)
+        G4_RD1(fa0, fw0, ab + off0, wb + off0, 6) G4_RD1(fa0, fw0, ab + off0, wb + off0, 7)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
+      for (int u = 0; u < nk; ++u) {
+        const unsigned ab = abase0 + (u & 1) * G2_BUF, wb = wbase0 + (u & 1) * G2_BUF;
+        const unsigned abn = abase0 + ((u + 1) & 1) * G2_BUF, wbn = wbase0 + ((u + 1) & 1) * G2_BUF;
+        const bool more1 = u + 1 < nk, more2 = u + 2 < nk;
+        // ---- half A: reads of (u, kk = 1) under the MFMAs of (u, kk = 0)
+        G4_GROUP_A(0) G4_GROUP_A(1) G4_GROUP_A(2) G4_GROUP_A(3) G4_GROUP_A(4) G4_GROUP_A(5) G4_GROUP_A(6) G4_GROUP_A(7)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // DMA(u + 1) landed
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the reads of buffer (u & 1) returned
+        G4_BARRIER()
+        // ---- half B: reads of (u + 1, kk = 0) and the DMA of tile u + 2 under the MFMAs of (u, kk = 1)
+        G4_GROUP_B(0) G4_GROUP_B(1) G4_GROUP_B(2) G4_GROUP_B(3) G4_GROUP_B(4) G4_GROUP_B(5) G4_GROUP_B(6) G4_GROUP_B(7)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // fa0 / fw0 for the next half A
+      }
+#undef G4_RD1
+#undef G4_MF8
+#undef G4_ST2
+#undef G4_GROUP_A
+#undef G4_GROUP_B
+    } else {
     G4_READ(fa0, fw0, smem, off0)
     for (int u = 0; u < nk; ++u) {
       const char* bp = smem + (u & 1) * G2_BUF;
@@ -950,6 +1005,7 @@ __global__ __launch_bounds__(256) void gemm4w_kernel(GemmParams p) {
       if (u + 2 < nk) { G4_STAGE(u + 2) }
       G4_MFMA(fa1, fw1)
     }
+    }   // !ILV
     // the hazard recogniser does not see into the asm MFMAs: let the last ones retire before the epilogue reads AGPRs
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
     // nobody reads the pipeline buffers after the last barrier: the epilogue may reuse them at once
@@ -969,10 +1025,10 @@ __global__ __launch_bounds__(256) void gemm4w_kernel(GemmParams p) {
   }
 }
 
-template <bool OUT_BF16, int ACT, bool QK = false>
+template <bool OUT_BF16, int ACT, bool QK = false, bool ILV = false>
 static int launch4w(const GemmParams& p, hipStream_t stream) {
   const int nbm = (p.M + G2_BM - 1) / G2_BM, nbn = p.N / G2_BN;
-  auto kern = gemm4w_kernel<OUT_BF16, ACT, QK>;
+  auto kern = gemm4w_kernel<OUT_BF16, ACT, QK, ILV>;
   static unsigned long long optin = 0;
   constexpr int LDS_BYTES = QK ? G2_LDS_QK : G2_LDS_TOTAL;
   if (int rc = pi3_lds_optin((const void*)kern, LDS_BYTES, &optin, "gemm4w")) return rc;
@@ -1020,14 +1076,20 @@ int pi3_gemm256_try(const GemmParams& p, int out_dtype, int act, hipStream_t str
     impl3 = (e && atoi(e) == 3) ? 1 : 0;
   }
   // the four-wave 128 x 128-per-wave form (round 4 experiment); its LDS-DMA uses 32-bit offsets from the matrix bases
-  const int impl4 = (int)pi3_knob("gemm_4w", 0) && (long)p.M * p.lda * 2 < (1l << 32) && (long)p.N * p.ldw * 2 < (1l << 32);
+  const int impl4 = ((long)p.M * p.lda * 2 < (1l << 32) && (long)p.N * p.ldw * 2 < (1l << 32)) ? (int)pi3_knob("gemm_4w", 0) : 0;
   if (p.qk_mode) {   // fused q/k head epilogue: bf16 output, no activation, one head per wave column block
     if (out_dtype != 0 || act != 0 || p.gamma || p.rpg || p.N != 3 * p.qk_H * 64 ||
         (p.qk_k2max && p.qk_attnS < 128))
       return 1;
+    if (impl4 == 2) return launch4w<true, 0, true, true>(p, stream);
     if (impl4) return launch4w<true, 0, true>(p, stream);
     if (impl3 && (p.K % 32) == 0) return launch3<true, 0, true>(p, stream);
     return launch256<true, 0, false, true, true>(p, stream);
+  }
+  if (impl4 == 2) {      // interleaved K loop (reads and DMA issues between the MFMAs)
+    if (out_dtype == 0 && act == 0) return launch4w<true, 0, false, true>(p, stream);
+    if (out_dtype == 0 && (act == 1 || act == 3)) return launch4w<true, 1, false, true>(p, stream);
+    if (out_dtype == 1 && act == 0) return launch4w<false, 0, false, true>(p, stream);
   }
   if (impl4) {
     if (out_dtype == 0 && act == 0) return launch4w<true, 0>(p, stream);

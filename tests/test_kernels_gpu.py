@@ -503,10 +503,11 @@ def test_gemm_four_wave_variant_is_bit_identical(dev, M, N, K):
     try:
         lib.set_knob("gemm_4w", 0)
         base = run_all()
-        lib.set_knob("gemm_4w", 1)
-        for rep in range(3):
-            got = run_all()
-            for i, (g, b) in enumerate(zip(got, base)):
-                assert torch.equal(g, b), (rep, i, (g.float() - b.float()).abs().max().item())
+        for form in (1, 2):          # 2: fragment reads and LDS-DMA issues interleaved between the MFMAs (all inline asm)
+            lib.set_knob("gemm_4w", form)
+            for rep in range(3):
+                got = run_all()
+                for i, (g, b) in enumerate(zip(got, base)):
+                    assert torch.equal(g, b), (form, rep, i, (g.float() - b.float()).abs().max().item())
     finally:
         lib.set_knob("gemm_4w", 0)

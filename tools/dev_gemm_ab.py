@@ -7,6 +7,7 @@ Variants (every one computes the same result; the check at the start compares ea
   base               shipped defaults
   gelu_as            gelu_form = 1: the round 1-3 Abramowitz-Stegun GELU (fc1 only)
   4w                 gemm_4w = 1: four waves per workgroup, 128 x 128 block per wave, accumulators in AGPRs
+  4w-ilv             gemm_4w = 2: the same with fragment reads and LDS-DMA issues interleaved between the MFMAs (all asm)
   stag<N>            gemm_stagger_ns = N: workgroup b starts b * N ns late                      (AB_ALL=1)
   rpref              gemm_rpref = 1: residual lines touched during the last K tiles (proj, fc2) (AB_ALL=1)
 """
@@ -25,7 +26,7 @@ R = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 NL = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 M = int(os.environ.get("AB_M", "64300"))
 KNOBS = ("gelu_form", "gemm_stagger_ns", "gemm_rpref", "gemm_4w")
-VARIANTS = [("base", {}), ("gelu_as", {"gelu_form": 1}), ("4w", {"gemm_4w": 1})]
+VARIANTS = [("base", {}), ("gelu_as", {"gelu_form": 1}), ("4w", {"gemm_4w": 1}), ("4w-ilv", {"gemm_4w": 2})]
 if os.environ.get("AB_ALL"):      # the round-4 experiments that found nothing (profiles/EXPERIMENTS.md)
     VARIANTS += [("stag30", {"gemm_stagger_ns": 30}), ("stag120", {"gemm_stagger_ns": 120}), ("rpref", {"gemm_rpref": 1})]
 

@@ -962,7 +962,11 @@ __global__ __launch_bounds__(256) void gemm4w_kernel(GemmParams p) {
     g4_glds16(sw, woff[I], sb + (2 + ((I) >> 2)) * G2_HALF + ((I) & 3) * 1024);            \
   }
 #define G4_GROUP_A(I) G4_RD1(fa1, fw1, ab + off1, wb + off1, I) G4_MF8(fa0, fw0, I)
-#define G4_GROUP_B(I) if (more1) { G4_RD1(fa0, fw0, abn + off0, wbn + off0, I) } if (more2) G4_ST2(u + 2, I) G4_MF8(fa1, fw1, I)
+// (the 16 DMA issues of tile u + 2 sit in the FIRST four groups: the last one then has 1.75 halves to land instead of 1)
+#define G4_GROUP_B(I)                                                                      \
+  if (more1) { G4_RD1(fa0, fw0, abn + off0, wbn + off0, I) }                               \
+  if (more2 && (I) < 4) { G4_ST2(u + 2, 2 * (I)) G4_ST2(u + 2, 2 * (I) + 1) }              \
+  G4_MF8(fa1, fw1, I)
       {
         const unsigned ab = abase0, wb = wbase0;
         G4_RD1(fa0, fw0, ab + off0, wb + off0, 0) G4_RD1(fa0, fw0, ab + off0, wb + off0, 1)

@@ -693,7 +693,21 @@ def extras(engine, moge, make_creator, run, dev):
         t0 = time.perf_counter()
         summary = ops.bundle_adjust(pts, rc, intr_d, uv_d, valid_d, 2.0, 10).cpu().numpy()
         times.append(time.perf_counter() - t0)
+    forms = {}
+    for form, kw in (("homogeneous_points_reference_default", dict(homogeneous=True)), ("inverse_depth", dict(inverse_depth=True))):
+        tf, sf = [], None
+        for rep in range(2):
+            pts = to(pb["X"])
+            rc = to(np.concatenate([pb["R"].reshape(CL, 9), pb["C"]], 1))
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            sf = ops.bundle_adjust(pts, rc, intr_d, uv_d, valid_d, 2.0, 10, **kw).cpu().numpy()
+            tf.append(time.perf_counter() - t0)
+        forms[form] = {"ms_total": 1e3 * min(tf), "lm_iterations": int(sf[5]), "accepted_steps": int(sf[6]),
+                       "ms_per_lm_iteration": 1e3 * min(tf) / max(1, int(sf[5])), "final_cost": float(sf[0])}
     out["bundle_adjust_chunk"] = {
+        "point_parametrization": "euclidean (pi3_bundle_adjust); other_forms: the reference's default and --use-inverse-depth",
+        "other_forms": forms,
         "ms_total": 1e3 * min(times), "lm_iterations": int(summary[5]), "accepted_steps": int(summary[6]),
         "ms_per_lm_iteration": 1e3 * min(times) / max(1, int(summary[5])),
         "initial_cost": float(summary[8]), "final_cost": float(summary[0]), "cameras": CL, "tracks": CL * KP,

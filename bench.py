@@ -262,8 +262,21 @@ def main(args) -> None:
     backend = os.environ.get("PI3_DIST_BACKEND", "nccl")   # "gloo" only to rehearse the N > 1 logic on a 1-GPU box
     dev = torch.device(f"cuda:{local_rank % max(1, ndev) if backend == 'gloo' else local_rank}")
     torch.cuda.set_device(dev)
-    if world > 1:
+    # PI3_DIST_FORCE=1: build the process group and take the wave-alignment path even with ONE rank - a 1-rank RCCL group
+    # is the only way to run the nccl branch of this file (device-resident boundary blocks, all-gathers, comm record) on
+    # a one-GPU box; the line then carries `comm` like an N > 1 line (tests/test_pipeline_gpu.py)
+    grouped = world > 1 or os.environ.get("PI3_DIST_FORCE") == "1"
+    if grouped:
         import torch.distributed as dist
+        if world == 1:
+            import socket
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if "MASTER_PORT" not in os.environ:
+                with socket.socket() as sk:
+                    sk.bind(("127.0.0.1", 0))
+                    os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)   # RCCL over xGMI
         else:
@@ -327,7 +340,7 @@ def main(args) -> None:
         for meta, chunk in cr.process_chunks(items):
             t0 = time.perf_counter()
             with torch.cuda.stream(align_stream):
-                if world == 1:
+                if not grouped:
                     if state["prev"] is not None:
                         ok, _ = align_and_refine_reconstructions(state["prev"], chunk, matches, device=str(dev))
                         assert ok
@@ -352,7 +365,7 @@ def main(args) -> None:
 
     def sync_all():
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if grouped:
             import torch.distributed as dist
             dist.barrier()
             torch.cuda.synchronize(dev)
@@ -366,7 +379,7 @@ def main(args) -> None:
         sync_all()
         dt = time.perf_counter() - t0
     comm = None
-    if world > 1:
+    if grouped:
         import torch.distributed as dist
         from pi3_slam_amd.dist import boundary_numel
         own_dt = dt
@@ -441,7 +454,7 @@ def main(args) -> None:
             line["cpu_baseline"] = cpu_baseline(cfg, args.cpu_frames)
         _REAL_STDOUT.write(json.dumps(line) + "\n")
         _REAL_STDOUT.flush()
-    if world > 1:
+    if grouped:
         import torch.distributed as dist
         dist.destroy_process_group()
 

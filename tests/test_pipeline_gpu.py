@@ -410,6 +410,31 @@ def test_bench_two_ranks_rehearsal(tmp_path, built_lib, launcher):
     assert rec["n1_reference_ms_per_step"]["ms_per_step"] > 0
 
 
+def test_bench_nccl_branch_with_a_forced_one_rank_group(built_lib):
+    """bench.py's nccl (= RCCL) code path on the hardware that is available: PI3_DIST_FORCE=1 builds a ONE-rank RCCL group
+    and takes the wave-alignment path (device-resident boundary blocks through dist.all_gather on nccl, the 136-byte
+    record all-gather, max-over-ranks all_reduce, barrier) - the calls that otherwise run for the first time on the
+    driver's 8-GPU node.  The line must carry the comm record with what RCCL reports."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PI3_DIST_FORCE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "PI3_DIST_BACKEND", "PI3_BENCH_LAUNCHER"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
+                        "--no-extras", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    rec = json.loads(lines[0])
+    comm = rec["comm"]
+    assert rec["n_gpus"] == 1 and comm["backend"] == "nccl" and comm["world_size"] == 1
+    assert comm["ranks"][0]["device"] == "cuda:0" and comm["ranks"][0]["device_name"]
+    assert "rccl_version" in comm and "unavailable" not in str(comm["rccl_version"])
+    assert comm["allgather_bytes_per_wave"]["boundary_blocks"] == (1 + 2 * 20 * 200 * 6 + 16) * 4
+    assert rec["value"] > 30 and 0 < rec["roofline"]["frac"] < 1 and len(comm["per_rank"]) == 1
+
+
 def test_rccl_branch_with_a_one_rank_group(tmp_path, built_lib):
     """The nccl (= RCCL) branch of the chunk-parallel code on the hardware that is available: ONE rank on this box's GPU
     (two ranks cannot share a card under RCCL).  Device-resident boundary blocks, all-gathers of device tensors,

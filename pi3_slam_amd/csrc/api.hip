@@ -45,7 +45,7 @@ int pi3_lds_optin(const void* kern, int bytes, unsigned long long* done_mask, co
 // tools/ use pi3_set_knob to interleave variants inside one process (perf deltas of a few per cent are only resolvable
 // that way: the cards of the pool differ by +-4 %).
 namespace {
-struct Knob { char name[32]; long value; int state; };   // state 0: free, 1: resolved "unset" (use the default), 2: has a value
+typedef Pi3Knob Knob;
 Knob g_knobs[64];
 int g_knob_lock = 0;
 struct KnobGuard {
@@ -62,14 +62,19 @@ Knob* knob_slot(const char* name) {
       for (const char* c = name; *c && i + 1 < sizeof(env); ++c, ++i) env[i] = (*c >= 'a' && *c <= 'z') ? *c - 32 : *c;
       env[i] = 0;
       const char* e = getenv(env);
+      k.value = e ? atol(e) : 0;         // value before state: a lock-free reader (PI3_KNOB) tests the state first
       k.state = e ? 2 : 1;
-      k.value = e ? atol(e) : 0;
       return &k;
     }
   }
   return nullptr;
 }
 }  // namespace
+
+const Pi3Knob* pi3_knob_slot(const char* name) {
+  KnobGuard g;
+  return knob_slot(name);
+}
 
 long pi3_knob(const char* name, long dflt) {
   KnobGuard g;
@@ -78,7 +83,7 @@ long pi3_knob(const char* name, long dflt) {
 }
 
 extern "C" int pi3_set_knob(const char* name, long value) {
-  if (!name || !*name || strlen(name) >= sizeof(Knob::name)) {
+  if (!name || !*name || strlen(name) >= sizeof(((Knob*)nullptr)->name)) {
     pi3_set_error("pi3_set_knob: bad knob name");
     return PI3_ERR_ARG;
   }

@@ -547,7 +547,7 @@ int pi3_attention64_launch(const void* q, const void* k, const void* v, long tok
   // frame-wise sequences (nw_req = 4): knob attn_frame_nw picks four-wave (256 rows, default) or two-wave (128 rows)
   // workgroups.  643 tokens are 10 full 64-row wave blocks + 3 rows: three four-wave workgroups give 12 wave slots of
   // which the third workgroup's (2, 2, 1, 0 blocks) last half idles; six two-wave workgroups end in a short one
-  const int nw = nw_req == 4 ? ((int)pi3_knob("attn_frame_nw", 4) == 2 ? 2 : 4) : nw_knob;
+  const int nw = nw_req == 4 ? ((int)PI3_KNOB("attn_frame_nw", 4) == 2 ? 2 : 4) : nw_knob;
   const int qrows = nw * 64;
   p.S = S; p.H = H; p.B = B; p.nqb = (S + qrows - 1) / qrows;
   const long nwg = (long)p.nqb * H * B;

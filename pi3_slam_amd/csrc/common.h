@@ -30,7 +30,16 @@ int pi3_check_launch(const char* what);
 // Opt `kern` into `bytes` of dynamic LDS (above the 64 KB default) on the CURRENT device, once per device: the attribute
 // is per device, so `done_mask` (one function-local static per kernel instance) carries one bit per device ordinal.
 // Returns PI3_OK or PI3_ERR_LAUNCH with the runtime's message in pi3_last_error().
-long pi3_knob(const char* name, long dflt);   // run-time A/B knob (api.hip): pi3_set_knob value, else env PI3_<NAME>, else dflt
+// run-time A/B knob (api.hip): pi3_set_knob value, else env PI3_<NAME>, else dflt.  Slots live in a static table, so a
+// launch path resolves the name once (PI3_KNOB: a function-local static pointer) and then reads two words per launch.
+struct Pi3Knob { char name[32]; volatile long value; volatile int state; };   // state 0 free, 1 unset, 2 has a value
+const Pi3Knob* pi3_knob_slot(const char* name);
+long pi3_knob(const char* name, long dflt);
+#define PI3_KNOB(NAME, DFLT)                                                     \
+  ([]() -> long {                                                                \
+    static const Pi3Knob* k_ = pi3_knob_slot(NAME);                              \
+    return (k_ && k_->state == 2) ? k_->value : (long)(DFLT);                    \
+  }())
 int pi3_lds_optin(const void* kern, int bytes, unsigned long long* done_mask, const char* what);
 
 __device__ __forceinline__ float bf16_bits_to_f32(uint16_t b) {

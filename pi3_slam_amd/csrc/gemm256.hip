@@ -1071,16 +1071,16 @@ int pi3_gemm256_try(const GemmParams& p, int out_dtype, int act, hipStream_t str
   }
   const_cast<GemmParams&>(p).tile_order = order_knob >= 0 ? order_knob : (p.N / G2_BN <= 4 ? 1 : 0);
   // run-time knobs (pi3_set_knob / PI3_GEMM_STAGGER_NS, PI3_GEMM_RPREF, PI3_GELU_FORM): see the kernel
-  const_cast<GemmParams&>(p).stagger_ns = (int)pi3_knob("gemm_stagger_ns", 0);
-  const_cast<GemmParams&>(p).rpref = (int)pi3_knob("gemm_rpref", 0);
-  if (act == 1 && pi3_knob("gelu_form", 0) == 1) act = 3;
+  const_cast<GemmParams&>(p).stagger_ns = (int)PI3_KNOB("gemm_stagger_ns", 0);
+  const_cast<GemmParams&>(p).rpref = (int)PI3_KNOB("gemm_rpref", 0);
+  if (act == 1 && PI3_KNOB("gelu_form", 0) == 1) act = 3;
   static int impl3 = -1;     // PI3_GEMM_IMPL=3: the two-workgroups-per-CU 128x256 kernel for every large GEMM (A/B knob)
   if (impl3 < 0) {
     const char* e = getenv("PI3_GEMM_IMPL");
     impl3 = (e && atoi(e) == 3) ? 1 : 0;
   }
   // the four-wave 128 x 128-per-wave form (round 4 experiment); its LDS-DMA uses 32-bit offsets from the matrix bases
-  const int impl4 = ((long)p.M * p.lda * 2 < (1l << 32) && (long)p.N * p.ldw * 2 < (1l << 32)) ? (int)pi3_knob("gemm_4w", 0) : 0;
+  const int impl4 = ((long)p.M * p.lda * 2 < (1l << 32) && (long)p.N * p.ldw * 2 < (1l << 32)) ? (int)PI3_KNOB("gemm_4w", 0) : 0;
   if (p.qk_mode) {   // fused q/k head epilogue: bf16 output, no activation, one head per wave column block
     if (out_dtype != 0 || act != 0 || p.gamma || p.rpg || p.N != 3 * p.qk_H * 64 ||
         (p.qk_k2max && p.qk_attnS < 128))

@@ -270,3 +270,22 @@ def test_checkpoint_directory_config_json(tmp_path):
     (tmp_path / "config.json").write_text(json.dumps({"pos_type": None}))
     with pytest.raises(NotImplementedError):
         config_from_checkpoint_dir(str(tmp_path))
+
+
+def test_ba_summary_and_keypoint_weights():
+    """bundle_adjust.ba_summary counts what ran / was applied / was rejected by the sanity gate / failed (what
+    OfflineReconstructor.refinement_summary reports); alignment.keypoint_weights is w = mask * sigmoid(conf) (SURVEY §7
+    step 7) on the overlap views of a chunk dictionary."""
+    from pi3_slam_amd.alignment import keypoint_weights
+    from pi3_slam_amd.bundle_adjust import ba_summary
+    infos = [{"success": True}, {"success": False, "rejected": "a camera moved 3 units"}, None, {"success": False},
+             {"success": True}, {"success": False, "reason": "no keypoints"}]
+    assert ba_summary(infos) == {"ran": 5, "applied": 2, "rejected_by_sanity_gate": 1, "failed": 2}
+    assert ba_summary([]) == {"ran": 0, "applied": 0, "rejected_by_sanity_gate": 0, "failed": 0}
+    g = torch.Generator().manual_seed(0)
+    conf = torch.randn(5, 7, 1, generator=g).half()
+    masks = torch.rand(5, 7, 1, generator=g) > 0.3
+    w = keypoint_weights({"conf": conf, "masks": masks}, [4, 1])
+    assert w.shape == (2, 7) and w.dtype == torch.float32
+    want = torch.sigmoid(conf[[4, 1]].float().reshape(2, 7)) * masks[[4, 1]].reshape(2, 7).float()
+    assert torch.equal(w, want) and (w[~masks[[4, 1]].reshape(2, 7)] == 0).all() and (w <= 1).all()

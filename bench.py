@@ -628,12 +628,12 @@ def extras(engine, moge, make_creator, run, dev):
             stream_files.append(q)
         workers = min(8, max(2, len(os.sched_getaffinity(0)) // 2))
         online = {}
-        for mode, graph in (("hip_graph", True), ("eager", False)):
+        for mode, graph in (("hip_graph", True), ("eager", False), ("hip_graph_reuse_overlap", True)):
             slam = Pi3SLAMOnline(model=engine, chunk_length=CL, overlap=OV, device=str(dev), keypoint_type="grid",
                                  max_num_keypoints=KP, do_metric_depth=moge is not None, moge_model=moge, hip_graph=graph,
                                  output_dir=os.path.join(tmp, "online_" + mode), bundle_adjust=False,
-                                 num_loader_workers=workers)
-            slam.process_chunks(stream_files[:180])           # graph capture of the chunk shape: untimed
+                                 num_loader_workers=workers, reuse_overlap_encoder=mode.endswith("reuse_overlap"))
+            slam.process_chunks(stream_files[:260])           # graph capture of the chunk shape: untimed
             torch.cuda.synchronize(dev)
             before = slam.get_statistics()["num_frames"]
             t0 = time.perf_counter()
@@ -645,13 +645,16 @@ def extras(engine, moge, make_creator, run, dev):
                 "frames_per_s": n_stream / dt, "chunk_frames_per_s": sum(r["chunk"]["_metrics"]["num_frames"] for r in res) / dt,
                 "chunks": len(res), "wall_s": dt, "new_frames_accounted": slam.get_statistics()["num_frames"] - before,
                 "pi3_forward_ms_mean": 1e3 * st.get("pi3_forward", {}).get("mean_s", float("nan")),
-                "consume_ms_max": 1e3 * st.get("consume_chunk", {}).get("max_s", float("nan"))}
+                "consume_ms_max": 1e3 * st.get("consume_chunk", {}).get("max_s", float("nan")),
+                "encoder_frames_reused": slam._creator.reused_frames}
             del slam
         out["online_stream_4k"] = dict(
             online["hip_graph"], hip_graph=True, bundle_adjust=False, input_frames=n_stream,
-            eager_launches=online["eager"],
+            eager_launches=online["eager"], reuse_overlap_encoder=online["hip_graph_reuse_overlap"],
             note="Pi3SLAMOnline.process_chunks on 4000 PNG files (100 distinct), cl=100 ov=20 -> 50 chunks; decode threads, "
-                 "device resize, hipGraph replay of the forward (eager_launches: the same run with plain launches), "
+                 "device resize, hipGraph replay of the forward (eager_launches: the same run with plain launches; "
+                 "reuse_overlap_encoder: the opt-in switch that takes the 20 overlap frames' encoder output from the previous "
+                 "chunk - same bits, less work, so it is reported here and never in the headline), "
                  "Sim(3) alignment of every chunk to its predecessor, results drained in order.  frames_per_s counts input "
                  "frames (every chunk re-processes its 20 overlap frames: chunk_frames_per_s).  Bundle adjustment is off: "
                  "recipe weights give no consistent geometry")

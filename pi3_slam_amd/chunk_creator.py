@@ -60,6 +60,8 @@ class OfflineCreatorConfig:
     device_resize: bool = False             # loader workers only decode; Resize + ToTensor run on the GPU (bit-identical)
     hip_graph: bool = False                 # replay the per-chunk pi3 forward as one captured hipGraph per chunk shape
     overlap_stages: bool = True             # False: stage-in, launch and finish of a chunk run back to back (A/B knob)
+    reuse_overlap_encoder: bool = False     # a chunk whose first `overlap` paths are the previous chunk's last ones takes
+                                            # their (frame-local) encoder output from that chunk: bit-identical results
 
 
 _UV_CACHE: Dict = {}
@@ -131,6 +133,9 @@ class OfflineChunkCreator:
             self.model = Pi3Engine(Pi3Config(), dev)
         else:
             self.model = Pi3Engine.from_pretrained(config.model_path, dev)
+
+        self._tail_paths: Optional[List[str]] = None    # reuse_overlap_encoder: the files whose encoder output the engine holds
+        self.reused_frames = 0
 
         # MoGe is optional equipment: without it chunks keep pi3's own scale (offline_chunk_creator.py:70-79)
         self.moge_model = moge_model
@@ -320,13 +325,26 @@ class OfflineChunkCreator:
                 kp_err = e
         mark("keypoints queued")
 
+        # overlap reuse (opt-in): the SAME files at the head of this chunk as at the tail of the one launched before it
+        rh = kt = 0
+        ov = int(cfg.overlap)
+        if cfg.reuse_overlap_encoder and getattr(self.model, "supports_overlap_reuse", False) and 0 < ov < N \
+                and st.paths is not None and len(st.paths) == N:
+            names = [str(p) for p in st.paths]
+            rh = ov if self._tail_paths == names[:ov] else 0
+            kt, self._tail_paths = ov, names[-ov:]
+        else:
+            self._tail_paths = None
+        reuse = dict(reuse_head=rh, keep_tail=kt) if (rh or kt) else {}
+        self.reused_frames += rh
+
         ev["f0"].record(cur)
         # the graph of a shape costs one eager run + one capture the first time: worth it for the nominal chunk shape, which
         # repeats, not for the ragged last chunk of a sequence (in a 4 000-frame stream its capture was 2.6 % of the run)
         if cfg.hip_graph and hasattr(self.model, "forward_graphed") and N == int(cfg.chunk_length):
-            pi3 = self.model.forward_graphed(imgs)     # static outputs: packed below, before the next replay
+            pi3 = self.model.forward_graphed(imgs, **reuse)     # static outputs: packed below, before the next replay
         else:
-            pi3 = self.model(imgs)
+            pi3 = self.model(imgs, **reuse)
         ev["f1"].record(cur)
         mark("forward queued")
 

@@ -35,7 +35,9 @@ CREATE_FLAGS: Sequence[Tuple[str, Dict]] = (
     ("--keypoint-seed", dict(type=int, default=0, help="seed of the grid subsampling, -1 = unseeded")),
 )
 CREATE_SWITCHES = (("--device-resize", "Resize + ToTensor on the GPU (loader workers decode only)"),
-                   ("--hip-graph", "replay the per-chunk forward as one captured hipGraph"))
+                   ("--hip-graph", "replay the per-chunk forward as one captured hipGraph"),
+                   ("--reuse-overlap-encoder", "overlap frames take their encoder output from the previous chunk "
+                                               "(bit-identical; single-GPU streams)"))
 RECON_FLAGS: Sequence[Tuple[str, Dict]] = (
     ("--chunks", dict(REQ, help="directory holding chunks/chunk_*.pt and chunk_metadata.json")),
     ("--output", dict(REQ, help="directory for trajectory_tum.txt and the ply files")),
@@ -97,7 +99,7 @@ def run_create(a: argparse.Namespace) -> None:
         keypoint_detection_threshold=a.kp_threshold, estimate_camera_params=a.estimate_intrinsics,
         num_loader_workers=a.num_workers, cam_dist_path=a.cam_dist_path, moge_model_path=a.moge_model_path,
         keypoint_seed=None if a.keypoint_seed < 0 else a.keypoint_seed, device_resize=a.device_resize,
-        hip_graph=a.hip_graph)
+        hip_graph=a.hip_graph, reuse_overlap_encoder=a.reuse_overlap_encoder)
     OfflineChunkCreator(cfg).process_and_save(paths[lo:hi])
 
 

@@ -172,9 +172,17 @@ class Pi3Engine:
                   eps=self.cfg.eps, pos=consts["pos"], cs=consts["cs"], attn_events=attn_events)
 
     # ------------------------------------------------------------------ forward
+    supports_overlap_reuse = True
+
     @torch.no_grad()
     def forward(self, imgs: torch.Tensor, return_intermediates: bool = False,
-                global_attn_events: Optional[list] = None) -> Dict[str, torch.Tensor]:
+                global_attn_events: Optional[list] = None, reuse_head: int = 0, keep_tail: int = 0) -> Dict[str, torch.Tensor]:
+        """reuse_head / keep_tail (sliding-window streams, opt-in: OfflineCreatorConfig.reuse_overlap_encoder): the encoder
+        is frame-local (frame-wise attention only, dinov2/layers/block.py:88-113), so the overlap frames a chunk shares
+        with its predecessor have the SAME encoder output in both - the predecessor's last `keep_tail` frames are kept
+        on the device and a chunk that starts with the same `reuse_head` frames skips the encoder for them.  The outputs
+        are bit-identical to a full run (every kernel of the encoder is row- / frame-local with a fixed accumulation
+        order; tests/test_engine_gpu.py); the caller vouches that the frames are the same images."""
         cfg, w, dev = self.cfg, self.w, self.device
         assert imgs.ndim == 5 and imgs.shape[2] == 3, "expected (B, N, 3, H, W)"
         B, N, _, Himg, Wimg = imgs.shape
@@ -186,6 +194,11 @@ class Pi3Engine:
         S = F * T
         D = cfg.dim
         inter = {}
+        tail_key = self.__dict__.get("_enc_tail_key")
+        r = int(reuse_head)
+        if not (B == 1 and 0 < r < F and tail_key == (Himg, Wimg, r)):
+            r = 0                      # nothing (valid) to reuse: the whole encoder runs
+        Fe, Se = F - r, (F - r) * T    # frames / rows the encoder works on: [r, F)
 
         x = self._buffer("x", (S, D), torch.float32)
         xn = self._buffer("xn", (S, D), torch.bfloat16)
@@ -197,20 +210,29 @@ class Pi3Engine:
 
         # ---- patch embed (+ cls / registers / interpolated pos-embed): vision_transformer.py:215-234
         patches = self._buffer("patches", (F * P, 640), torch.bfloat16)
-        ops.patch_gather(imgs.view(F, 3, Himg, Wimg), patches, IMAGE_MEAN, IMAGE_STD)
-        ops.gemm(patches, w["encoder.patch_embed.proj.weight"], x, M=F * P, bias=w["encoder.patch_embed.proj.bias"],
+        xe = x[r * T:]                 # the encoder's rows (all of x unless overlap frames are reused)
+        ops.patch_gather(imgs.view(F, 3, Himg, Wimg)[r:], patches, IMAGE_MEAN, IMAGE_STD)
+        ops.gemm(patches, w["encoder.patch_embed.proj.weight"], xe, M=Fe * P, bias=w["encoder.patch_embed.proj.bias"],
                  rpg=P, gstride=T, goff=cfg.n_dec_reg, addtab=c["pos_patch"])
-        ops.fill_tokens(x, F, T, 0, c["special_enc"])
+        ops.fill_tokens(xe, Fe, T, 0, c["special_enc"])
         if return_intermediates:
             inter["tokens"] = x.clone()
 
         # ---- encoder: 24 pre-LN blocks, frame-wise attention, LayerScale, no RoPE (dinov2/layers/block.py:88-113)
         for i in range(cfg.enc_depth):
-            self._block(f"encoder.blocks.{i}", x, S, F, T, T, c, rope=False, qk_norm=False, ls=True, bufs=bufs)
+            self._block(f"encoder.blocks.{i}", xe, Se, Fe, T, T, c, rope=False, qk_norm=False, ls=True, bufs=bufs)
         # final norm; patch tokens kept, the 5 special slots become the decoder's register tokens (pi3.py:140-144)
         hidden = self._buffer("hidden", (S, D), torch.float32)
-        ops.layernorm(x, w["encoder.norm.weight"], w["encoder.norm.bias"], hidden, cfg.eps, rows=S, T=T,
+        ops.layernorm(xe, w["encoder.norm.weight"], w["encoder.norm.bias"], hidden[r * T:], cfg.eps, rows=Se, T=T,
                       nspecial=cfg.n_dec_reg, special=c["special_dec"])
+        if r:
+            hidden[: r * T].copy_(self._buffer("enc_tail", (r * T, D), torch.float32))
+        kt = int(keep_tail)
+        if B == 1 and 0 < kt < F:      # the decoder updates `hidden` in place: keep the tail's encoder output now
+            self._buffer("enc_tail", (kt * T, D), torch.float32).copy_(hidden[(F - kt) * T:])
+            self._enc_tail_key = (Himg, Wimg, kt)
+        elif kt == 0 and not return_intermediates:
+            self._enc_tail_key = None
         if return_intermediates:
             inter["enc_out"] = hidden.clone()
 
@@ -277,28 +299,41 @@ class Pi3Engine:
 
     # algorithmic FLOPs of one forward (SURVEY.md §8d formula) — used by bench.py for the roofline line
     # ------------------------------------------------------------------ hipGraph replay (BASELINE config 5)
-    def forward_graphed(self, imgs: torch.Tensor) -> Dict[str, torch.Tensor]:
+    def forward_graphed(self, imgs: torch.Tensor, reuse_head: int = 0, keep_tail: int = 0) -> Dict[str, torch.Tensor]:
         """forward() through a captured hipGraph: the ~1300 kernel launches of a chunk become one graph launch.  The
         first call for an input shape runs eagerly once (allocates the persistent buffers, the attention scratch, the
         per-size tables), captures the second run, and replays from then on.  Inputs are copied into the graph's static
         frame buffer; the returned tensors are the graph's static outputs (overwritten by the next replay)."""
-        key = tuple(imgs.shape)
+        # overlap reuse (see forward): whether the head is reused is decided HERE, outside the capture, so that a graph
+        # always replays the path it recorded; the kept tail lives in a persistent (pinned) buffer the graphs share
+        tail_key = self.__dict__.get("_enc_tail_key")
+        Bq, Nq, _, Hq, Wq = imgs.shape
+        rh = int(reuse_head) if (Bq == 1 and 0 < int(reuse_head) < Nq and tail_key == (Hq, Wq, int(reuse_head))) else 0
+        kt = int(keep_tail) if (Bq == 1 and 0 < int(keep_tail) < Nq) else 0
+        key = tuple(imgs.shape) + (rh, kt)
         graphs = self.__dict__.setdefault("_graphs", {})
         if key not in graphs:
             static_in = imgs.to(self.device, dtype=torch.float32).contiguous().clone()
             self._pinning = True          # every buffer this shape touches stays alive as long as the engine
             try:
-                self.forward(static_in)
+                saved = None
+                if rh:                    # the eager warm-up run below must not consume / replace the live tail
+                    saved = self._buffer("enc_tail", (rh * (self._shape_consts(Hq, Wq)["T"]), self.cfg.dim), torch.float32).clone()
+                self.forward(static_in, reuse_head=rh, keep_tail=kt)
+                if saved is not None:
+                    self._buffer("enc_tail", tuple(saved.shape), torch.float32).copy_(saved)
+                    self._enc_tail_key = (Hq, Wq, rh)
                 torch.cuda.synchronize(self.device)
                 graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(graph, capture_error_mode="thread_local"):   # other threads may allocate meanwhile
-                    static_out = self.forward(static_in)
+                    static_out = self.forward(static_in, reuse_head=rh, keep_tail=kt)
             finally:
                 self._pinning = False
             graphs[key] = (graph, static_in, static_out)
         graph, static_in, static_out = graphs[key]
         static_in.copy_(imgs, non_blocking=True)
         graph.replay()
+        self._enc_tail_key = (Hq, Wq, kt) if kt else None      # what the replay just left in the tail buffer
         return static_out
 
     def flops(self, B: int, N: int, H: int, W: int) -> Dict[str, float]:

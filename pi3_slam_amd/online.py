@@ -62,7 +62,7 @@ class Pi3SLAMOnline:
                  do_metric_depth: bool = False, save_debug_projections: bool = False, model_path: Optional[str] = None,
                  use_inverse_depth: bool = False, moge_model=None, moge_model_path: Optional[str] = None,
                  hip_graph: bool = True, output_dir: Optional[str] = None, num_loader_workers: int = 0,
-                 bundle_adjust: bool = True):
+                 bundle_adjust: bool = True, reuse_overlap_encoder: bool = False):
         self.use_inverse_depth = bool(use_inverse_depth)   # online_reconstructor.py:246,1018,1235
         self.chunk_length, self.overlap = int(chunk_length), int(overlap)
         self.pixel_limit = 255000 // 2
@@ -72,7 +72,8 @@ class Pi3SLAMOnline:
             overlap=self.overlap, device=device, do_metric_depth=do_metric_depth, keypoint_type=keypoint_type,
             max_num_keypoints=max_num_keypoints, keypoint_detection_threshold=keypoint_detection_threshold,
             estimate_camera_params=estimate_camera_params, num_loader_workers=num_loader_workers,
-            pin_memory=num_loader_workers > 0, moge_model_path=moge_model_path, device_resize=True, hip_graph=hip_graph)
+            pin_memory=num_loader_workers > 0, moge_model_path=moge_model_path, device_resize=True, hip_graph=hip_graph,
+            reuse_overlap_encoder=reuse_overlap_encoder)
         self._creator = OfflineChunkCreator(cfg, model=model, moge_model=moge_model)
         self._creator.undistortion_maps = undistortion_maps
         self.rank, self.world = self._creator.rank, self._creator.world

@@ -340,3 +340,72 @@ def test_checkpoint_files_load_like_the_reference_layouts(dev, tmp_path):
     d1, d2 = ref.infer(frame)["depth"], m2.infer(frame)["depth"]
     assert torch.equal(torch.nan_to_num(d1, posinf=1e9), torch.nan_to_num(d2, posinf=1e9))
 
+
+
+def _sliding_chunks(n_frames, length, overlap, H, W, dev, seed):
+    g = torch.Generator(device=dev).manual_seed(seed)
+    frames = torch.rand(n_frames, 3, H, W, device=dev, generator=g)
+    step = length - overlap
+    return [frames[s:s + length].unsqueeze(0).contiguous() for s in range(0, n_frames - overlap, step)]
+
+
+@pytest.mark.parametrize("which", ["small", "full"])
+def test_overlap_frames_reuse_the_previous_chunks_encoder_output(dev, full_engine, which):
+    """Sliding-window streams (chunk c+1 starts with the last `overlap` frames of chunk c): the encoder is frame-local
+    (dinov2/layers/block.py:88-113 - frame-wise attention only), so reuse_head / keep_tail must give the SAME bits as a
+    full run, eager and through the captured graphs; a tail of another size or frame shape is not used.  'full' runs
+    the 958.7 M-parameter model at 308 x 406 (gemm256 + attn_fwd64_kernel<4> on row-offset views of the buffers)."""
+    from pi3_slam_amd.engine import Pi3Engine
+    from pi3_slam_amd.weights import Pi3Config
+    if which == "small":
+        eng = Pi3Engine(Pi3Config(dim=128, enc_depth=2, dec_depth=4, head_depth=1, cam_dim=128, pos_grid=5), str(dev))
+        L, ov, H, W = 5, 2, 56, 70
+    else:
+        eng, L, ov, H, W = full_engine, 8, 2, 308, 406
+    chunks = _sliding_chunks(3 * (L - ov) + ov, L, ov, H, W, dev, seed=11)
+    assert len(chunks) == 3 and torch.equal(chunks[0][0, -ov:], chunks[1][0, :ov])
+    full = [{k: v.clone() for k, v in eng.forward(c).items()} for c in chunks]
+    assert eng.__dict__.get("_enc_tail_key") is None                    # plain calls keep nothing
+    for graphed in (False, True):
+        run = eng.forward_graphed if graphed else eng.forward
+        for i, c in enumerate(chunks):
+            out = run(c, reuse_head=ov if i else 0, keep_tail=ov)
+            torch.cuda.synchronize()
+            for k in full[i]:
+                assert torch.equal(out[k], full[i][k]), (graphed, i, k)
+        assert eng._enc_tail_key == (H, W, ov)
+        # a request the kept tail cannot serve (other count) falls back to the whole encoder, same bits
+        out = eng.forward(chunks[1], reuse_head=ov + 1)
+        torch.cuda.synchronize()
+        assert all(torch.equal(out[k], full[1][k]) for k in full[1])
+        assert eng._enc_tail_key is None
+    if which == "small":
+        assert len(eng._graphs) == 2                                    # (no reuse, keep) and (reuse, keep)
+
+
+def test_chunk_creator_reuses_the_overlap_only_for_the_same_files(dev, tmp_path):
+    """OfflineCreatorConfig.reuse_overlap_encoder: process_chunks() hands the engine reuse_head only when the first
+    `overlap` paths of a chunk ARE the last ones of the chunk launched before it; the chunk dictionaries are identical
+    to a run without the switch."""
+    from pi3_slam_amd.chunk_creator import OfflineChunkCreator, OfflineCreatorConfig
+    from pi3_slam_amd.engine import Pi3Engine
+    from pi3_slam_amd.weights import Pi3Config
+    eng = Pi3Engine(Pi3Config(dim=128, enc_depth=2, dec_depth=2, head_depth=1, cam_dim=128, pos_grid=5), str(dev))
+    L, ov, H, W = 4, 1, 56, 70
+    chunks = _sliding_chunks(3 * (L - ov) + ov, L, ov, H, W, dev, seed=5)
+    names = [f"f{i:03d}.png" for i in range(3 * (L - ov) + ov)]
+    items = [{"frames": c.cpu(), "paths": names[i * (L - ov): i * (L - ov) + L], "meta": {"chunk_index": i}}
+             for i, c in enumerate(chunks)]
+    items.append(dict(items[0], meta={"chunk_index": 3}))               # not contiguous with chunk 2: no reuse
+    results = {}
+    for reuse in (False, True):
+        cc = OfflineCreatorConfig(model_path="recipe", output_dir=str(tmp_path / str(reuse)), chunk_length=L, overlap=ov,
+                                  do_metric_depth=False, keypoint_type="grid", max_num_keypoints=20,
+                                  reuse_overlap_encoder=reuse)
+        creator = OfflineChunkCreator(cc, model=eng)
+        creator.target_size = (H, W)
+        results[reuse] = [r for _, r in creator.process_chunks(items)]
+        assert creator.reused_frames == (2 * ov if reuse else 0)
+    for a, b in zip(results[False], results[True]):
+        for k in ("points", "local_points", "conf", "masks", "camera_poses", "keypoints", "intrinsics"):
+            assert torch.equal(a[k], b[k]), k

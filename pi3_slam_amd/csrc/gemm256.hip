@@ -58,11 +58,26 @@ __device__ __forceinline__ float g2_sum_rows4(float s) {
   return __uint_as_float(b[0]) + __uint_as_float(b[1]);
 }
 
-// stage one half-tile (128 rows x 128 B) of a row-major bf16 matrix: 16 segments of 1 KiB, 2 per wave.
-// (Round 3 also tried the attention kernel's remedy here - the LDS-DMA issued from inline asm with a scalar base and a
-// 32-bit lane offset, so that hipcc's waitcnt pass cannot put s_waitcnt vmcnt(0) in front of fragment reads: the K loop
-// came out without any compiler-placed vmcnt wait and was NOT faster (block GEMMs 1.788 against 1.749 ms): this loop is
-// bound by LDS bandwidth, not by prefetch latency.)
+// LDS-DMA of one 1 KiB segment from inline asm: scalar base, 32-bit lane offset, LDS destination in M0.  hipcc does not
+// see the LDS write, so no compiler-placed s_waitcnt vmcnt(0) appears in front of later fragment reads: every wait on
+// these loads is a counted one written by hand.
+__device__ __forceinline__ void g4_glds16(const char* sbase, unsigned voff, unsigned lds_dst) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_dst)
+               : "memory", "m0");
+}
+
+// G2_ASM_DMA = 1 (shipped since round 4): gemm256_kernel's K loop stages through g4_glds16 with per-tile 32-bit lane
+// offsets instead of the builtin with a 64-bit pointer per piece.  Bit-identical output; 230-235 VGPRs and no vector
+// spills where the builtin form sat at 256 with 2-8 spills (nine 64-bit staging pointers become eight dwords, the wave
+// index and the LDS destinations are scalars), no compiler-placed vmcnt(0) at the top of the K loop; block GEMMs
+// 1.615 / 1.630 -> 1.580 / 1.573 ms in alternating processes on one card (profiles/r04_gemm_asm_dma_ab.log; round 3
+// measured the same idea on the four-phase loop as 2 % slower).  -DG2_ASM_DMA=0 builds the builtin form for A/B.
+// The 32-bit offsets bound the operand footprint: pi3_gemm256_try declines matrices of 4 GiB and more.
+#ifndef G2_ASM_DMA
+#define G2_ASM_DMA 1
+#endif
+
+// stage one half-tile (128 rows x 128 B) of a row-major bf16 matrix: 16 segments of 1 KiB, 2 per wave (builtin form).
 __device__ __forceinline__ void g2_stage_half(const char* gbase, long ld_bytes, int row0, int rows, long k_bytes,
                                               char* lds_half, int wave, int lane) {
 #pragma unroll
@@ -331,7 +346,13 @@ __device__ __forceinline__ void g2_epilogue_lds(const GemmParams& p, f32x4 (&acc
 template <bool OUT_BF16, int ACT, bool NOEPI = false, bool STAG = false, bool QK = false>
 __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+#if G2_ASM_DMA
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane(
+      (unsigned)(__UINTPTR_TYPE__)((__attribute__((address_space(3))) void*)(smem)));
+#else
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#endif
   const int wm = wave >> 2, wn = wave & 3;
 
   const int nbm = (p.M + G2_BM - 1) / G2_BM, nbn = p.N / G2_BN;
@@ -404,10 +425,39 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+#if G2_ASM_DMA
+  // 32-bit staging offsets of this tile: piece (half h, i) = rows h * 128 + (wave * 2 + i) * 8 .. + 7
+  unsigned aoff[4], woff[4];
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int row = (wave * 2 + i) * 8 + (lane >> 3);
+      const int c = (lane & 7) ^ ((row >> 1) & 7);
+      int ga = bm * G2_BM + h * 128 + row, gw = bn * G2_BN + h * 128 + row;
+      ga = ga < p.M ? ga : p.M - 1;
+      gw = gw < p.N ? gw : p.N - 1;
+      aoff[h * 2 + i] = (unsigned)((long)ga * lda_b + c * 16);
+      woff[h * 2 + i] = (unsigned)((long)gw * ldw_b + c * 16);
+    }
+#define STAGE_A(U, HALF)                                                                  \
+  {                                                                                       \
+    const unsigned sb_ = lds0 + ((U) & 1) * G2_BUF + (HALF) * G2_HALF + wave * 2048;      \
+    g4_glds16(Ab + (long)(U) * 128, aoff[(HALF) * 2], sb_);                               \
+    g4_glds16(Ab + (long)(U) * 128, aoff[(HALF) * 2 + 1], sb_ + 1024);                    \
+  }
+#define STAGE_W(U, HALF)                                                                  \
+  {                                                                                       \
+    const unsigned sb_ = lds0 + ((U) & 1) * G2_BUF + (2 + (HALF)) * G2_HALF + wave * 2048; \
+    g4_glds16(Wb + (long)(U) * 128, woff[(HALF) * 2], sb_);                               \
+    g4_glds16(Wb + (long)(U) * 128, woff[(HALF) * 2 + 1], sb_ + 1024);                    \
+  }
+#else
 #define STAGE_A(U, HALF) g2_stage_half(Ab, lda_b, bm * G2_BM + (HALF) * 128, p.M, (long)(U) * 128, \
                                        smem + ((U) & 1) * G2_BUF + (HALF) * G2_HALF, wave, lane)
 #define STAGE_W(U, HALF) g2_stage_half(Wb, ldw_b, bn * G2_BN + (HALF) * 128, p.N, (long)(U) * 128, \
                                        smem + ((U) & 1) * G2_BUF + (2 + (HALF)) * G2_HALF, wave, lane)
+#endif
 
 #if G2_TWO_PHASE == 2
   // prologue: tile 0 complete; W(1) and act(1) half 0 in flight (what cd(-1) would have staged)
@@ -543,25 +593,34 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
     }
   }
   const long pf_step = 32l * p.ldr * 4;       // instruction i covers rows 32 i .. 32 i + 31 of the wave's block
+#ifdef PI3_DEV_ABLATIONS   // timing-only, WRONG results (development builds): where a K tile's 1.5 us go
+  const bool abl_dma = (p.abl & 2) != 0, abl_rd = (p.abl & 4) != 0, abl_wait = (p.abl & 8) != 0;
+#else
+  constexpr bool abl_dma = false, abl_rd = false, abl_wait = false;
+#endif
   for (int u = 0; u < nk; ++u) {
     const char* bp = smem + (u & 1) * G2_BUF;
-    const bool pre1 = (u + 1 < nk), pre2 = (u + 2 < nk);
-    READ_W(bp, 0)
-    READ_W(bp, 1)
-    READ_A(bp, 0)
+    const bool pre1 = (u + 1 < nk) && !abl_dma, pre2 = (u + 2 < nk) && !abl_dma;
+    if (!abl_rd) {
+      READ_W(bp, 0)
+      READ_W(bp, 1)
+      READ_A(bp, 0)
+    }
     if (pre1) { STAGE_A(u + 1, 0); STAGE_A(u + 1, 1); }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     PHASE_MID()
     MFMA_Q(0, 0)
     MFMA_Q(0, 1)
     PHASE_END()
-    READ_A(bp, 1)
+    if (!abl_rd) {
+      READ_A(bp, 1)
+    }
     if (pre2) {
       STAGE_W(u + 2, 0);
       STAGE_W(u + 2, 1);
-      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      if (!abl_wait) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (!abl_wait) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     if constexpr (!OUT_BF16 && !NOEPI) {
       const int pi = u - (nk - 6);
@@ -810,10 +869,6 @@ static int launch3(const GemmParams& p, hipStream_t stream) {
 // LDS-DMA with a scalar base and a 32-bit lane offset: one VGPR per staged segment instead of a 64-bit pointer (with
 // 16 segments per wave and K tile the 64-bit pointers were hoisted out of the K loop, spilled, and their scratch reloads
 // brought vmcnt(0) waits in front of every DMA)
-__device__ __forceinline__ void g4_glds16(const char* sbase, unsigned voff, unsigned lds_dst) {
-  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_dst)
-               : "memory", "m0");
-}
 
 // fragment read from inline asm (immediate offset), so that its place between the asm MFMAs is the place it is issued
 // at: a C++ load may be hoisted by the scheduler to the top of the block, which is what leaves a lone wave's MFMAs waiting
@@ -1054,6 +1109,8 @@ int pi3_gemm256_try(const GemmParams& p, int out_dtype, int act, hipStream_t str
   if ((p.N % G2_BN) != 0 || (p.K % 64) != 0 || p.M < 1024) return 1;
   if (p.qcols % 16) return 1;          // the bf16 epilogue tests n < qcols per 16-column tile (wave-uniform)
   if (out_dtype == 0 && (p.resid || p.addtab)) return 1;   // the bf16 streaming pass carries no residual / table add
+  // the LDS-DMA addresses a row through a 32-bit byte offset from the matrix base
+  if ((long)p.M * p.lda * 2 >= (1l << 32) || (long)p.N * p.ldw * 2 >= (1l << 32)) return 1;
   static int gm_knob = -1;   // PI3_GEMM_GM: m-tiles per scheduling group (A/B knob; any value gives the same results)
   if (gm_knob < 0) {
     const char* e = getenv("PI3_GEMM_GM");
@@ -1106,11 +1163,9 @@ int pi3_gemm256_try(const GemmParams& p, int out_dtype, int act, hipStream_t str
     if (out_dtype == 1 && act == 0) return launch3<false, 0>(p, stream);
   }
 #ifdef PI3_DEV_ABLATIONS   // timing-only variant that writes NOTHING: development builds only
-  static int abl = -1;
-  if (abl < 0) {
-    const char* e = getenv("PI3_GEMM_ABL");
-    abl = e ? atoi(e) : 0;
-  }
+  // knob gemm_abl (bits): 1 = no epilogue at all, 2 = no LDS-DMA issues in the K loop, 4 = no fragment reads
+  const int abl = (int)PI3_KNOB("gemm_abl", 0);
+  const_cast<GemmParams&>(p).abl = abl;
 #else
   constexpr int abl = 0;
 #endif
@@ -1119,7 +1174,7 @@ int pi3_gemm256_try(const GemmParams& p, int out_dtype, int act, hipStream_t str
     const char* e = getenv("PI3_GEMM_STAG");
     stag = e ? atoi(e) : 1;
   }
-  if (abl == 1) return stag ? launch256<true, 0, true, true>(p, stream) : launch256<true, 0, true>(p, stream);
+  if (abl & 1) return stag ? launch256<true, 0, true, true>(p, stream) : launch256<true, 0, true>(p, stream);
   if (stag) {
     if (out_dtype == 0 && act == 0) return launch256<true, 0, false, true>(p, stream);
     if (out_dtype == 0 && act == 1) return launch256<true, 1, false, true>(p, stream);

@@ -20,6 +20,9 @@ struct GemmParams {
   int tile_order;            // gemm256: 0 = m-tiles first inside a group, 1 = column tiles first
   int stagger_ns;            // gemm256 (persistent form): workgroup b starts b * stagger_ns later (0 = all at once)
   int rpref;                 // gemm256, f32 output with a residual: touch the tile's residual lines during the last K tiles
+#ifdef PI3_DEV_ABLATIONS
+  int abl;                   // timing-only ablation bits (development builds; results are wrong)
+#endif
   // fused q/k epilogue of the packed qkv projection (gemm256 only; FlashAttentionRope.forward,
   // pi3/models/layers/attention.py:323-334): columns [0, H*64) = q, [H*64, 2*H*64) = k, rest = v.  For q and k heads:
   // per-head LayerNorm(64) (optional: qk_w != null), RoPE-2D (optional), softmax scale folded into q, and max_s |k|^2

@@ -343,7 +343,7 @@ __device__ __forceinline__ void g2_epilogue_lds(const GemmParams& p, f32x4 (&acc
 // other is in its load segment, instead of both loading and then both competing for the matrix pipe.  The staging
 // schedule already keeps every restage >= 2 phases after the last read of the region and reads a staged tile a phase
 // after the vmcnt wait that retires it, which is what the half-phase lag of the second group needs.
-template <bool OUT_BF16, int ACT, bool NOEPI = false, bool STAG = false, bool QK = false>
+template <bool OUT_BF16, int ACT, bool NOEPI = false, bool STAG = false, bool QK = false, bool ILVK = false>
 __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
 #if G2_ASM_DMA
@@ -459,6 +459,97 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
                                        smem + ((U) & 1) * G2_BUF + (2 + (HALF)) * G2_HALF, wave, lane)
 #endif
 
+  if constexpr (ILVK) {
+#if G2_ASM_DMA
+    // ---- Interleaved K loop (knob gemm_ilv, round 4 experiment): no ping-pong between the two waves of a SIMD.  A K tile
+    // is two phases of 32 MFMAs, one per 32-deep half (kk); every accumulator gets one MFMA per phase.  The fragments of a
+    // phase (8 act + 4 W, 48 registers) are double-buffered: while the MFMAs of phase kk0 run, the 12 fragment reads of
+    // kk1 are issued between them (one or two per group of four MFMAs); during kk1 the reads of the NEXT tile's kk0 and
+    // the eight LDS-DMA pieces of tile u + 2 (into the buffer tile u just left).  One barrier per K tile, between the two
+    // phases: by then every wave has its kk1 fragments (nobody reads tile u's buffer any more) and has retired its
+    // pieces of tile u + 1 (issued a whole phase earlier).  Everything whose order matters is inline asm.
+    const int frow = lane & 15;
+    const int swz = (lane >> 1) & 7;
+    const int cq = lane >> 4;
+    const unsigned off0 = ((cq) ^ swz) << 4, off1 = ((cq + 4) ^ swz) << 4;
+    const unsigned a_rd = lds0 + wm * G2_HALF + frow * 128;
+    const unsigned w_rd = lds0 + (2 + (wn >> 1)) * G2_HALF + ((wn & 1) * 64 + frow) * 128;
+    bf16x8 fa0[8], fw0[4], fa1[8], fw1[4];
+#define GI_RD(D, ADDR, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(D) : "v"(ADDR), "n"(OFF));
+#define GI_RD_GROUP(FA, FW, AADDR, WADDR, G)                 \
+  GI_RD(FA[G], AADDR, (G) * 2048)                            \
+  if constexpr ((G) < 4) { GI_RD(FW[G], WADDR, (G) * 2048) }
+// read number R of a phase's twelve: 0..7 = act fragment R, 8..11 = W fragment R - 8; two per group in groups 0..5
+#define GI_RD1(FA, FW, AADDR, WADDR, R)                                        \
+  if constexpr ((R) < 8) { GI_RD(FA[(R) & 7], AADDR, ((R) & 7) * 2048) }        \
+  else { GI_RD(FW[(R) & 3], WADDR, ((R) & 3) * 2048) }
+#define GI_RD2(FA, FW, AADDR, WADDR, G)                                                              \
+  if constexpr ((G) < 6) { GI_RD1(FA, FW, AADDR, WADDR, 2 * (G)) GI_RD1(FA, FW, AADDR, WADDR, 2 * (G) + 1) }
+#define GI_MF4(FA, FW, G)                                                                                        \
+  _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                   \
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[i][G]) : "v"(FW[i]), "v"(FA[G]));
+#define GI_DMA(U, G)                                                                                              \
+  {                                                                                                               \
+    const unsigned sb_ = lds0 + ((U) & 1) * G2_BUF + wave * 2048;                                                 \
+    if constexpr ((G) < 4) g4_glds16(Ab + (long)(U) * 128, aoff[G], sb_ + ((G) >> 1) * G2_HALF + ((G) & 1) * 1024); \
+    else g4_glds16(Wb + (long)(U) * 128, woff[(G) - 4], sb_ + (2 + (((G) - 4) >> 1)) * G2_HALF + ((G) & 1) * 1024);  \
+  }
+    // prologue: tiles 0 and 1 staged, tile 0 landed, its kk0 fragments in registers
+    STAGE_A(0, 0);
+    STAGE_A(0, 1);
+    STAGE_W(0, 0);
+    STAGE_W(0, 1);
+    if (nk > 1) {
+      STAGE_A(1, 0);
+      STAGE_A(1, 1);
+      STAGE_W(1, 0);
+      STAGE_W(1, 1);
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    {
+      const unsigned aa = a_rd + off0, ww = w_rd + off0;
+      GI_RD_GROUP(fa0, fw0, aa, ww, 0) GI_RD_GROUP(fa0, fw0, aa, ww, 1) GI_RD_GROUP(fa0, fw0, aa, ww, 2)
+      GI_RD_GROUP(fa0, fw0, aa, ww, 3) GI_RD_GROUP(fa0, fw0, aa, ww, 4) GI_RD_GROUP(fa0, fw0, aa, ww, 5)
+      GI_RD_GROUP(fa0, fw0, aa, ww, 6) GI_RD_GROUP(fa0, fw0, aa, ww, 7)
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    for (int u = 0; u < nk; ++u) {
+      const unsigned slot = (u & 1) * G2_BUF, nslot = slot ^ G2_BUF;
+      const bool more1 = (u + 1 < nk), more2 = (u + 2 < nk);
+      {   // phase kk0: MFMAs on (fa0, fw0); the kk1 fragments of this tile arrive
+        const unsigned aa = a_rd + slot + off1, ww = w_rd + slot + off1;
+#define GI_A(G) GI_MF4(fa0, fw0, G) GI_RD2(fa1, fw1, aa, ww, G)
+        GI_A(0) GI_A(1) GI_A(2) GI_A(3) GI_A(4) GI_A(5) GI_A(6) GI_A(7)
+#undef GI_A
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_waitcnt vmcnt(0)" ::: "memory");   // kk1 fragments; own pieces of tile u + 1
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      {   // phase kk1: MFMAs on (fa1, fw1); kk0 fragments of tile u + 1 arrive; tile u + 2 goes into tile u's buffer
+        const unsigned aa = a_rd + nslot + off0, ww = w_rd + nslot + off0;
+#define GI_B(G)                                           \
+  GI_MF4(fa1, fw1, G)                                     \
+  if (more1) { GI_RD2(fa0, fw0, aa, ww, G) }              \
+  if (more2) { GI_DMA(u + 2, G) }
+        GI_B(0) GI_B(1) GI_B(2) GI_B(3) GI_B(4) GI_B(5) GI_B(6) GI_B(7)
+#undef GI_B
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    // the hazard recogniser does not see into the asm MFMAs: let the last ones retire before the epilogue reads them
+    asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");
+#undef GI_RD
+#undef GI_RD_GROUP
+#undef GI_RD1
+#undef GI_RD2
+#undef GI_MF4
+#undef GI_DMA
+#endif
+  } else {
 #if G2_TWO_PHASE == 2
   // prologue: tile 0 complete; W(1) and act(1) half 0 in flight (what cd(-1) would have staged)
   STAGE_A(0, 0);
@@ -675,6 +766,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
   if constexpr (STAG) {
     if (wm == 0) { PHASE_END() }   // barrier counts match again; nobody touches the epilogue LDS before everyone is out
   }
+  }   // !ILVK
 
   // ---- epilogue
   if constexpr (NOEPI) {
@@ -696,10 +788,10 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
   }   // tiles of this workgroup
 }
 
-template <bool OUT_BF16, int ACT, bool NOEPI = false, bool STAG = false, bool QK = false>
+template <bool OUT_BF16, int ACT, bool NOEPI = false, bool STAG = false, bool QK = false, bool ILVK = false>
 static int launch256(const GemmParams& p, hipStream_t stream) {
   const int nbm = (p.M + G2_BM - 1) / G2_BM, nbn = p.N / G2_BN;
-  auto kern = gemm256_kernel<OUT_BF16, ACT, NOEPI, STAG, QK>;
+  auto kern = gemm256_kernel<OUT_BF16, ACT, NOEPI, STAG, QK, ILVK>;
   static unsigned long long optin = 0;
   constexpr int LDS_BYTES = QK ? G2_LDS_QK : G2_LDS_TOTAL;
   if (int rc = pi3_lds_optin((const void*)kern, LDS_BYTES, &optin, "gemm256")) return rc;
@@ -1145,6 +1237,9 @@ int pi3_gemm256_try(const GemmParams& p, int out_dtype, int act, hipStream_t str
     if (impl4 == 2) return launch4w<true, 0, true, true>(p, stream);
     if (impl4) return launch4w<true, 0, true>(p, stream);
     if (impl3 && (p.K % 32) == 0) return launch3<true, 0, true>(p, stream);
+#if G2_ASM_DMA
+    if ((int)PI3_KNOB("gemm_ilv", 0)) return launch256<true, 0, false, false, true, true>(p, stream);
+#endif
     return launch256<true, 0, false, true, true>(p, stream);
   }
   if (impl4 == 2) {      // interleaved K loop (reads and DMA issues between the MFMAs)
@@ -1174,6 +1269,14 @@ int pi3_gemm256_try(const GemmParams& p, int out_dtype, int act, hipStream_t str
     const char* e = getenv("PI3_GEMM_STAG");
     stag = e ? atoi(e) : 1;
   }
+#if G2_ASM_DMA
+  if ((int)PI3_KNOB("gemm_ilv", 0)) {     // interleaved K loop (experiment, see gemm256_kernel)
+    if (abl & 1) return launch256<true, 0, true, false, false, true>(p, stream);
+    if (out_dtype == 0 && act == 0) return launch256<true, 0, false, false, false, true>(p, stream);
+    if (out_dtype == 0 && (act == 1 || act == 3)) return launch256<true, 1, false, false, false, true>(p, stream);
+    if (out_dtype == 1 && act == 0) return launch256<false, 0, false, false, false, true>(p, stream);
+  }
+#endif
   if (abl & 1) return stag ? launch256<true, 0, true, true>(p, stream) : launch256<true, 0, true>(p, stream);
   if (stag) {
     if (out_dtype == 0 && act == 0) return launch256<true, 0, false, true>(p, stream);

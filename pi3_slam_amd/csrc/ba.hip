@@ -492,6 +492,165 @@ __global__ __launch_bounds__(BA_MAXN) void ba_schur_rows(BaProblem pb, const dou
     for (int a = 0; a < 6; ++a) rhs_part[((long)slice * N + j) * 6 + a] = rj[a];
 }
 
+// ---- pass 3b, matrix-core form (round 4).  S_part[slice] -= Y E^T is a GEMM over k = (track, coordinate): rows
+// (camera j, a) of Y = E Cinv against rows (camera k', b) of E.  In the [track][camera][6][3] layout of Eblk the 8
+// cameras of a tile block are one contiguous 1 152-byte run per track, so a wave that owns a 48 x 48 tile (8 x 8 cameras,
+// 3 x 3 MFMA tiles of v_mfma_f64_16x16x4_f64; the fourth k of an MFMA is padding) reads its operands straight from
+// global memory: lane (row r, coordinate c) takes Y[3 r + c] as the A operand and E[3 q + c] as the B operand, where
+// Y = E Cinv is written once per iteration by ba_y_blocks (with the track's damped inverse from ba_point_inverses),
+// which also zeroes E and Y where there is no observation: the loop has no validity test and no branch.  Same slices
+// and the same ascending track order inside a slice as ba_schur_rows, so the result is reproducible from run to run;
+// against that kernel it differs by the rounding of the 3-term dot products (the oracle gates are 1e-9).
+// 2.2 ms -> see profiles/EXPERIMENTS.md at 100 cameras x 20 000 tracks: the row form spends its time in 128-lane
+// workgroups of which one lane in five has an observation to work on.
+typedef double ba_v4f64 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256) void ba_point_inverses(long nk, const double* __restrict__ Cblk,
+                                                         double* __restrict__ Cinv, const BaState* st) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (st->done != 0.0 || i >= nk) return;
+  double Ci[6], D[3];
+  const bool good = ba_point_inverse(Cblk + 6 * i, st->radius, Ci, D);
+#pragma unroll
+  for (int q = 0; q < 6; ++q) Cinv[6 * i + q] = good ? Ci[q] : 0.0;
+}
+
+// Y = E Cinv per observation, zeros where there is no observation - in Y AND in E itself, so that the tile kernel below
+// needs no validity test at all (its loop is loads + MFMAs, which the compiler can pipeline across tracks).
+__global__ __launch_bounds__(256) void ba_y_blocks(long nobs, int N, double* __restrict__ Eblk,
+                                                   const uint8_t* __restrict__ ok, const double* __restrict__ Cinv,
+                                                   double* __restrict__ Yblk, const BaState* st) {
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;      // one row (observation o, a) of three doubles per thread
+  if (st->done != 0.0 || e >= 6 * nobs) return;
+  const long o = e / 6;
+  double* E = Eblk + 3 * e;
+  double* Y = Yblk + 3 * e;
+  if (ok[o]) {
+    const double* ci = Cinv + 6 * (o / N);
+    const double e0 = E[0], e1 = E[1], e2 = E[2];
+    Y[0] = e0 * ci[0] + e1 * ci[1] + e2 * ci[2];
+    Y[1] = e0 * ci[1] + e1 * ci[3] + e2 * ci[4];
+    Y[2] = e0 * ci[2] + e1 * ci[4] + e2 * ci[5];
+  } else {
+    E[0] = 0.0; E[1] = 0.0; E[2] = 0.0;
+    Y[0] = 0.0; Y[1] = 0.0; Y[2] = 0.0;
+  }
+}
+
+__global__ __launch_bounds__(64) void ba_schur_tiles(BaProblem pb, const double* __restrict__ Eblk,
+                                                     const double* __restrict__ Yblk, const double* __restrict__ gp,
+                                                     double* __restrict__ S_part, double* __restrict__ rhs_part,
+                                                     int nsl, const BaState* st) {
+  if (st->done != 0.0) return;
+  // (giving all tiles of a slice to one XCD, so that its L2 serves the 91 re-reads of the slice's operands, was measured
+  // and is slower: 1.94 against 1.64 ms before the pipelining - the memory side is not what bounds this kernel)
+  const int N = pb.N, K = pb.K, lane = threadIdx.x;
+  const int slice = blockIdx.y, tile = blockIdx.x;
+  int Jb = 0;
+  while ((Jb + 1) * (Jb + 2) / 2 <= tile) ++Jb;                 // lower-triangle tile number -> (Jb, Kb), Kb <= Jb
+  const int Kb = tile - Jb * (Jb + 1) / 2;
+  const int j0 = 8 * Jb, k0 = 8 * Kb, n6 = 6 * N;
+  const int r16 = lane & 15, c = lane >> 4;                      // row inside a 16-row MFMA tile; k index (3 = padding)
+  const long i0 = (long)((N * slice) / nsl) * K, i1 = (long)((N * (slice + 1)) / nsl) * K;
+  ba_v4f64 acc[3][3];
+  double racc[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int b = 0; b < 3; ++b) acc[a][b] = (ba_v4f64){0.0, 0.0, 0.0, 0.0};
+  // this lane's rows: r = 16 s + r16 of the block -> camera r / 6 (past the last camera in the last block: nothing to
+  // load, the run belongs to the next track), element 3 r + c of the block's run
+  bool inA[3], inB[3];
+#pragma unroll
+  for (int sb = 0; sb < 3; ++sb) {
+    const int r = 16 * sb + r16;
+    inA[sb] = j0 + r / 6 < N && c < 3;
+    inB[sb] = k0 + r / 6 < N && c < 3;
+  }
+  const int lo = 3 * r16 + (c < 3 ? c : 0);
+  const bool rhs_tile = Kb == 0;
+  // four tracks per trip: their 24 operand loads (and the rhs terms) are issued before the 36 MFMAs, so the loads of a
+  // trip overlap the matrix work of the one before (hipcc does not unroll a loop of unknown trip count by itself here,
+  // and a lone track per trip left every wave waiting on memory: 22 % of the f64 MFMA rate)
+  auto step = [&](long i, double (&Y)[3], double (&B)[3]) {
+    const double* Ya = Yblk + 18 * (i * N + j0) + lo;
+    const double* Eb = Eblk + 18 * (i * N + k0) + lo;
+    const double g = (rhs_tile && c < 3) ? gp[3 * i + c] : 0.0;
+    // unconditional loads at constant offsets from one pointer per operand (lanes past the last camera read the next
+    // track's run - the workspace is padded for the last track - and drop the value)
+#pragma unroll
+    for (int sb = 0; sb < 3; ++sb) {
+      const double y = Ya[48 * sb], b = Eb[48 * sb];
+      Y[sb] = inA[sb] ? y : 0.0;
+      B[sb] = inB[sb] ? b : 0.0;
+      racc[sb] += Y[sb] * g;
+    }
+  };
+  auto mma = [&](const double (&Y)[3], const double (&B)[3]) {
+#pragma unroll
+    for (int sa = 0; sa < 3; ++sa)
+#pragma unroll
+      for (int sb = 0; sb < 3; ++sb)
+        acc[sa][sb] = __builtin_amdgcn_mfma_f64_16x16x4f64(Y[sa], B[sb], acc[sa][sb], 0, 0, 0);
+  };
+  // software pipeline over groups of BA_TG tracks with two register sets: the loads of group t + 1 are in flight while
+  // the MFMAs of group t run
+#define BA_TG 2
+  auto loadg = [&](long i, double (&Y)[BA_TG][3], double (&B)[BA_TG][3]) {
+#pragma unroll
+    for (int u = 0; u < BA_TG; ++u) step(i + u, Y[u], B[u]);
+  };
+  auto mmag = [&](const double (&Y)[BA_TG][3], const double (&B)[BA_TG][3]) {
+#pragma unroll
+    for (int u = 0; u < BA_TG; ++u) mma(Y[u], B[u]);
+  };
+  long i = i0;
+  const long ngrp = (i1 - i0) / BA_TG;
+  if (ngrp > 0) {
+    double Ya4[BA_TG][3], Ba4[BA_TG][3], Yb4[BA_TG][3], Bb4[BA_TG][3];
+    loadg(i, Ya4, Ba4);
+    long gidx = 0;
+    for (; gidx + 2 <= ngrp; gidx += 2) {
+      loadg(i + BA_TG, Yb4, Bb4);
+      mmag(Ya4, Ba4);
+      if (gidx + 2 < ngrp) loadg(i + 2 * BA_TG, Ya4, Ba4);
+      mmag(Yb4, Bb4);
+      i += 2 * BA_TG;
+    }
+    if (gidx < ngrp) {       // an odd group left: its loads were issued by the last trip (or above when ngrp == 1)
+      mmag(Ya4, Ba4);
+      i += BA_TG;
+    }
+  }
+#undef BA_TG
+  for (; i < i1; ++i) {
+    double Y0[3], B0[3];
+    step(i, Y0, B0);
+    mma(Y0, B0);
+  }
+  // D[i][j] of a 16 x 16 tile: lane l holds i = l / 16 + 4 v, j = l % 16 in element v (tools/micro/mfma_f64_layout.hip)
+  double* out = S_part + (long)slice * n6 * n6;
+#pragma unroll
+  for (int sa = 0; sa < 3; ++sa)
+#pragma unroll
+    for (int sb = 0; sb < 3; ++sb)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const int row = 6 * j0 + 16 * sa + c + 4 * v, col = 6 * k0 + 16 * sb + r16;
+        if (row < n6 && col < n6) out[(long)row * n6 + col] = -acc[sa][sb][v];
+      }
+  if (rhs_tile) {     // rhs_j = sum_i Y_ij g_i: the three coordinate lanes of a row add up (lanes l, l + 16, l + 32)
+#pragma unroll
+    for (int sa = 0; sa < 3; ++sa) {
+      double v = racc[sa];
+      v += __shfl_xor(v, 16);
+      v += __shfl_xor(v, 32);
+      const int row = 6 * j0 + 16 * sa + r16;
+      if (c == 0 && row < n6) rhs_part[(long)slice * n6 + row] = v;
+    }
+  }
+}
+
 // ---- pass 4: the reduced camera system.  S = sum of slices + B + D (lower triangle used), rhs = -(g_c - sum slices),
 // then a BLOCKED right-looking Cholesky (panels of BA_NB columns: factor the diagonal block in LDS, solve the panel rows
 // against it, rank-BA_NB update of the trailing matrix by a grid of tiles) and blocked triangular solves.  The factor
@@ -503,7 +662,7 @@ __global__ __launch_bounds__(256) void ba_assemble_cameras(int N, const double* 
                                                            const double* __restrict__ rhs_part,
                                                            const double* __restrict__ Bblk, const double* __restrict__ gc,
                                                            double* __restrict__ S, double* __restrict__ dcam,
-                                                           double* __restrict__ Dcam, BaState* st) {
+                                                           double* __restrict__ Dcam, int nsl, BaState* st) {
   if (st->done != 0.0) return;
   const int n = 6 * N;
   const long e = (long)blockIdx.x * 256 + threadIdx.x;
@@ -511,7 +670,7 @@ __global__ __launch_bounds__(256) void ba_assemble_cameras(int N, const double* 
   if (e < (long)n * n) {
     const int r = (int)(e / n), c = (int)(e - (long)r * n);
     double v = 0.0;
-    for (int sl = 0; sl < BA_SLICES; ++sl) v += S_part[(long)sl * n * n + e];
+    for (int sl = 0; sl < nsl; ++sl) v += S_part[(long)sl * n * n + e];
     if (r / 6 == c / 6) {      // + B_t (symmetric, packed upper) + the LM diagonal
       const int t = r / 6, a6 = r - 6 * t, b6 = c - 6 * t;
       const int p = a6 < b6 ? a6 : b6, q = a6 < b6 ? b6 : a6;
@@ -527,83 +686,114 @@ __global__ __launch_bounds__(256) void ba_assemble_cameras(int N, const double* 
   }
   if (e < n) {
     double v = 0.0;
-    for (int sl = 0; sl < BA_SLICES; ++sl) v += rhs_part[(long)sl * n + e];
+    for (int sl = 0; sl < nsl; ++sl) v += rhs_part[(long)sl * n + e];
     dcam[e] = -(gc[e] - v);
   }
 }
 
-// diagonal block [c0, c0 + nb) of S -> its Cholesky factor in L (one workgroup, block in LDS)
-__global__ __launch_bounds__(256) void ba_chol_diag(int n, int c0, int nb, const double* __restrict__ S,
-                                                    double* __restrict__ L, BaState* st) {
-  __shared__ double blk[BA_NB][BA_NB + 1];
-  __shared__ int fail;
-  const int tid = threadIdx.x;
+// diagonal block [c0, c0 + nb) of S -> its Cholesky factor in L.  One wave, row r of the block in the registers of lane
+// r; per column the scaled column goes through 48 doubles of LDS and every lane folds it into its row (broadcast reads):
+// no workgroup barrier in the 48 steps (round 3's 256-thread form spent 20-50 us per block on three barriers a column).
+__global__ __launch_bounds__(64) void ba_chol_diag(int n, int c0, int nb, const double* __restrict__ S,
+                                                   double* __restrict__ L, BaState* st) {
+  __shared__ double col[64];
+  const int r = threadIdx.x;
   if (st->done != 0.0 || st->chol_fail != 0.0) return;
-  for (int e = tid; e < nb * nb; e += 256) {
-    const int i = e / nb, j = e - i * nb;
-    blk[i][j] = j <= i ? S[(long)(c0 + i) * n + c0 + j] : 0.0;
-  }
-  if (tid == 0) fail = 0;
-  __syncthreads();
-  for (int c = 0; c < nb; ++c) {
-    const double d = blk[c][c];
-    if (!(d > 0.0)) {                 // every thread reads the same value: a uniform exit
-      if (tid == 0) fail = 1;
-      break;
+  double a[BA_NB];
+  const bool mine = r < nb;
+  const double* srow = S + (long)(c0 + (mine ? r : 0)) * n + c0;
+#pragma unroll
+  for (int q = 0; q < BA_NB; ++q) a[q] = (mine && q <= r && q < nb) ? srow[q] : 0.0;
+  bool fail = false;
+#pragma unroll
+  for (int c = 0; c < BA_NB; ++c) {
+    if (c < nb && !fail) {          // uniform
+      col[r] = a[c];
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+      const double d = col[c];
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+      if (!(d > 0.0)) {
+        fail = true;
+      } else {
+        const double sd = sqrt(d), ip = 1.0 / sd;
+        const double l = (r == c) ? sd : a[c] * ip;
+        a[c] = l;
+        col[r] = l;
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+#pragma unroll
+        for (int q = c + 1; q < BA_NB; ++q) a[q] -= l * col[q];     // (entries above a lane's diagonal are never used)
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+      }
     }
-    const double ip = 1.0 / sqrt(d);
-    __syncthreads();
-    for (int r = c + tid; r < nb; r += 256) blk[r][c] = (r == c) ? sqrt(d) : blk[r][c] * ip;
-    __syncthreads();
-    const int m = nb - c - 1;
-    for (int e = tid; e < m * m; e += 256) {
-      const int r = c + 1 + e / m, q = c + 1 + e % m;
-      if (q <= r) blk[r][q] -= blk[r][c] * blk[q][c];
-    }
-    __syncthreads();
   }
-  __syncthreads();
   if (fail) {
-    if (tid == 0) st->chol_fail = 1.0;
+    if (r == 0) st->chol_fail = 1.0;
     return;
   }
-  for (int e = tid; e < nb * nb; e += 256) {
-    const int i = e / nb, j = e - i * nb;
-    if (j <= i) L[(long)(c0 + i) * n + c0 + j] = blk[i][j];
+  if (mine) {
+    double* lrow = L + (long)(c0 + r) * n + c0;
+#pragma unroll
+    for (int q = 0; q < BA_NB; ++q)
+      if (q <= r && q < nb) lrow[q] = a[q];
   }
 }
 
-// rows below the diagonal block: L[r][c0 + j] = (S[r][c0 + j] - sum_{k<j} L[r][c0 + k] L11[j][k]) / L11[j][j]
+// rows below the diagonal block: L[r][c0 + j] = (S[r][c0 + j] - sum_{k<j} L[r][c0 + k] L11[j][k]) / L11[j][j].
+// One thread per row with the row in registers, the diagonal block in LDS (broadcast reads at compile-time offsets), the
+// 1 128 multiply-adds straight-line code.  (Round 3 kept the rows in LDS as well: two dependent LDS reads per
+// multiply-add, 19-47 us per panel; scalar loads of the block from global memory serialise on their latency: 33 us.)
+// The right-hand side rides along as row n of the matrix (L y = rhs is then solved by the factorisation itself: the
+// panel step gives y's segment, the trailing update folds it into the rest of rhs): row index n reads and writes `rhs`.
 __global__ __launch_bounds__(64) void ba_chol_panel(int n, int c0, int nb, const double* __restrict__ S,
-                                                    double* __restrict__ L, const BaState* st) {
-  __shared__ double l11[BA_NB][BA_NB + 1];
-  __shared__ double xs[64][BA_NB + 1];
-  const int tid = threadIdx.x;
+                                                    const double* __restrict__ Ldiag, double* __restrict__ L,
+                                                    double* __restrict__ rhs, const BaState* st) {
+  __shared__ double l11[BA_NB][BA_NB];
   if (st->done != 0.0 || st->chol_fail != 0.0) return;
-  for (int e = tid; e < nb * nb; e += 64) {
+  for (int e = threadIdx.x; e < nb * nb; e += 64) {
     const int i = e / nb, j = e - i * nb;
-    l11[i][j] = j <= i ? L[(long)(c0 + i) * n + c0 + j] : 0.0;
+    l11[i][j] = j <= i ? Ldiag[(long)(c0 + i) * n + c0 + j] : 0.0;
   }
   __syncthreads();
-  const int r = c0 + nb + blockIdx.x * 64 + tid;
-  if (r >= n) return;
-  for (int j = 0; j < nb; ++j) {
-    double v = S[(long)r * n + c0 + j];
-    for (int k = 0; k < j; ++k) v -= xs[tid][k] * l11[j][k];
-    v /= l11[j][j];
-    xs[tid][j] = v;
-    L[(long)r * n + c0 + j] = v;
+  const int r = c0 + nb + blockIdx.x * 64 + threadIdx.x;
+  if (r > n) return;
+  double x[BA_NB];
+  const double* srow = r < n ? S + (long)r * n + c0 : rhs + c0;
+#pragma unroll
+  for (int j = 0; j < BA_NB; ++j) x[j] = j < nb ? srow[j] : 0.0;
+#pragma unroll
+  for (int j = 0; j < BA_NB; ++j) {
+    if (j < nb) {        // uniform
+      double v = x[j];
+#pragma unroll
+      for (int k = 0; k < j; ++k) v -= x[k] * l11[j][k];       // same address in every lane: a broadcast read
+      x[j] = v / l11[j][j];
+    }
   }
+  double* lrow = r < n ? L + (long)r * n + c0 : rhs + c0;
+#pragma unroll
+  for (int j = 0; j < BA_NB; ++j)
+    if (j < nb) lrow[j] = x[j];
 }
 
 // trailing update S[r][q] -= sum_k L[r][c0 + k] L[q][c0 + k] for c0 + nb <= q <= r: one 48 x 48 tile per workgroup
 __global__ __launch_bounds__(256) void ba_chol_update(int n, int c0, int nb, double* __restrict__ S,
-                                                      const double* __restrict__ L, const BaState* st) {
+                                                      const double* __restrict__ L, double* __restrict__ rhs,
+                                                      const BaState* st) {
   __shared__ double lr[BA_NB][BA_NB + 1], lq[BA_NB][BA_NB + 1];
   const int tid = threadIdx.x;
   if (blockIdx.x > blockIdx.y) return;       // tiles above the diagonal
   if (st->done != 0.0 || st->chol_fail != 0.0) return;
   const int t0 = c0 + nb, r0 = t0 + blockIdx.y * BA_NB, q0 = t0 + blockIdx.x * BA_NB;
+  if (blockIdx.y == gridDim.y - 1) {         // the rhs row: rhs[q] -= sum_k y[c0 + k] L[q][c0 + k]
+    const int q = q0 + tid;
+    if (tid < BA_NB && q < n) {
+      const double* lrow = L + (long)q * n + c0;
+      double acc = 0.0;
+      for (int k = 0; k < nb; ++k) acc += rhs[c0 + k] * lrow[k];
+      rhs[q] -= acc;
+    }
+    return;
+  }
   for (int e = tid; e < BA_NB * nb; e += 256) {
     const int i = e / nb, k = e - i * nb;
     lr[i][k] = r0 + i < n ? L[(long)(r0 + i) * n + c0 + k] : 0.0;
@@ -620,7 +810,8 @@ __global__ __launch_bounds__(256) void ba_chol_update(int n, int c0, int nb, dou
   }
 }
 
-// L y = rhs, L^T x = y, panel by panel; the solution lives in LDS, the diagonal blocks pass through LDS too
+// L^T x = y, panel by panel (y = L^-1 rhs came out of the factorisation, see ba_chol_panel); the solution lives in LDS,
+// the diagonal blocks pass through LDS too
 __global__ __launch_bounds__(1024) void ba_chol_solve(int n, const double* __restrict__ L, double* __restrict__ dcam,
                                                       const BaState* st) {
   __shared__ double x[6 * BA_MAXN];
@@ -633,29 +824,6 @@ __global__ __launch_bounds__(1024) void ba_chol_solve(int n, const double* __res
   }
   for (int e = tid; e < n; e += 1024) x[e] = dcam[e];
   __syncthreads();
-  for (int c0 = 0; c0 < n; c0 += BA_NB) {               // forward
-    const int nb = min(BA_NB, n - c0);
-    for (int e = tid; e < nb * nb; e += 1024) {
-      const int i = e / nb, j = e - i * nb;
-      blk[i][j] = j <= i ? L[(long)(c0 + i) * n + c0 + j] : 0.0;
-    }
-    __syncthreads();
-    if (tid < 64) {    // one wave, in program order (DS operations of a wave execute in order)
-      for (int r = 0; r < nb; ++r) {
-        double acc = tid < r ? blk[r][tid] * x[c0 + tid] : 0.0;
-        acc = wave_sum_f64(acc);
-        if (tid == 0) x[c0 + r] = (x[c0 + r] - acc) / blk[r][r];
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-      }
-    }
-    __syncthreads();
-    for (int r = c0 + nb + tid; r < n; r += 1024) {
-      double acc = 0.0;
-      for (int k = 0; k < nb; ++k) acc += L[(long)r * n + c0 + k] * x[c0 + k];
-      x[r] -= acc;
-    }
-    __syncthreads();
-  }
   for (int c0 = ((n - 1) / BA_NB) * BA_NB; c0 >= 0; c0 -= BA_NB) {   // backward
     const int nb = min(BA_NB, n - c0);
     for (int e = tid; e < nb * nb; e += 1024) {
@@ -1050,7 +1218,7 @@ extern "C" long pi3_ba_workspace_doubles(int N, int K) {
   const long n6 = 6L * N, nk = (long)N * K;
   return 16 /*state*/ + 6 * nk + 3 * nk + 3 * nk /*pts_new*/ + 12L * N /*poses_new*/ + 21L * N + 6L * N /*gc*/ +
          6L * N /*dcam*/ + 6L * N /*Dcam*/ + BA_SLICES * n6 * n6 + BA_SLICES * n6 + 2 * n6 * n6 + 18 * nk * N + (nk * N + 7) / 8 + 3L * ba_nblk(N, K) +
-         3L * N + 64 + nk /*inverse depth: rho_new*/ + 36L * N * N /*cross blocks*/;
+         3L * N + 64 + nk /*inverse depth: rho_new*/ + 36L * N * N /*cross blocks*/ + 6 * nk /*damped point inverses*/ + 18 * nk * N /*Y = E Cinv*/ + 256 /*tile reads past the last track*/;
 }
 
 static int ba_run(double* points, double* poses, const double* intr, const float* uv, const unsigned char* valid,
@@ -1096,7 +1264,26 @@ static int ba_run(double* points, double* poses, const double* intr, const float
   w += 64;      // (the spare doubles of the size formula)
   double* rho_new = w; w += nk;
   double* Xblk = w; w += 36L * N * N;
+  double* Cinv = w; w += 6 * nk;
+  double* Yblk = w; w += 18 * nk * N;
   const bool invd = mode == 2;
+  const bool schur_rows = (int)PI3_KNOB("ba_schur_rows", 0) != 0;     // 1: the round-3 row kernel (A/B)
+  // track slices (partial sums added in slice order by ba_assemble_cameras).  The tile kernel runs two single-wave
+  // workgroups per SIMD (216 registers): the slice count that puts every (tile, slice) wave on the chip at once, in one
+  // round - 22 for 100 cameras (91 tiles) instead of 32, which needed a second, half-empty round
+  const int nb8 = (N + 7) / 8, ntile = nb8 * (nb8 + 1) / 2;
+  int nsl = BA_SLICES;
+  if (!schur_rows) {
+    nsl = 2048 / ntile;
+    nsl = nsl < 1 ? 1 : (nsl > BA_SLICES ? BA_SLICES : nsl);
+    nsl = nsl > N ? N : nsl;
+  }
+  // the tile kernel writes the lower-triangle tiles only; the rest of S_part is read by ba_assemble_cameras and never
+  // used by the factorisation: defined once
+  if (!schur_rows && hipMemsetAsync(S_part, 0, sizeof(double) * BA_SLICES * n6 * n6, st) != hipSuccess) {
+    pi3_set_error("pi3_bundle_adjust: hipMemsetAsync failed");
+    return PI3_ERR_LAUNCH;
+  }
   if (hipMemsetAsync(state, 0, 16 * sizeof(double), st) != hipSuccess) {
     pi3_set_error("pi3_bundle_adjust: hipMemsetAsync failed");
     return PI3_ERR_LAUNCH;
@@ -1127,21 +1314,29 @@ static int ba_run(double* points, double* poses, const double* intr, const float
                          obs_ok, state);
     }
     hipLaunchKernelGGL(ba_camera_blocks, dim3(N), dim3(256), 0, st, pb, points, poses, Bblk, gc, prior_cost, state);
-    hipLaunchKernelGGL(ba_schur_rows, dim3(N, BA_SLICES), dim3(BA_MAXN), 0, st, pb, Eblk, obs_ok, Cblk, gp, S_part,
-                       rhs_part, state);
+    if (schur_rows) {
+      hipLaunchKernelGGL(ba_schur_rows, dim3(N, BA_SLICES), dim3(BA_MAXN), 0, st, pb, Eblk, obs_ok, Cblk, gp, S_part,
+                         rhs_part, state);
+    } else {
+      hipLaunchKernelGGL(ba_point_inverses, dim3(nblk), dim3(256), 0, st, nk, Cblk, Cinv, state);
+      hipLaunchKernelGGL(ba_y_blocks, dim3((unsigned)((6 * nk * N + 255) / 256)), dim3(256), 0, st, nk * N, N, Eblk, obs_ok,
+                         Cinv, Yblk, state);
+      hipLaunchKernelGGL(ba_schur_tiles, dim3(ntile, nsl), dim3(64), 0, st, pb, Eblk, Yblk, gp, S_part, rhs_part, nsl, state);
+    }
     const int n = (int)n6;
     hipLaunchKernelGGL(ba_assemble_cameras, dim3((unsigned)((n6 * n6 + 255) / 256)), dim3(256), 0, st, N, S_part, rhs_part,
-                       Bblk, gc, S, dcam, Dcam, state);
+                       Bblk, gc, S, dcam, Dcam, nsl, state);
     if (invd)
       hipLaunchKernelGGL(ba_id_add_cross, dim3((unsigned)((n6 * n6 + 255) / 256)), dim3(256), 0, st, N, Xblk, S, state);
     for (int c0 = 0; c0 < n; c0 += BA_NB) {
       const int nb = n - c0 < BA_NB ? n - c0 : BA_NB;
-      hipLaunchKernelGGL(ba_chol_diag, dim3(1), dim3(256), 0, st, n, c0, nb, S, Lfac, state);
-      const int below = n - c0 - nb;
+      hipLaunchKernelGGL(ba_chol_diag, dim3(1), dim3(64), 0, st, n, c0, nb, S, Lfac, state);
+      const int below = n - c0 - nb;      // (+ 1: the right-hand side as row n)
+      hipLaunchKernelGGL(ba_chol_panel, dim3((below + 1 + 63) / 64), dim3(64), 0, st, n, c0, nb, S, (const double*)Lfac, Lfac,
+                         dcam, state);
       if (below > 0) {
-        hipLaunchKernelGGL(ba_chol_panel, dim3((below + 63) / 64), dim3(64), 0, st, n, c0, nb, S, Lfac, state);
         const int nt = (below + BA_NB - 1) / BA_NB;
-        hipLaunchKernelGGL(ba_chol_update, dim3(nt, nt), dim3(256), 0, st, n, c0, nb, S, Lfac, state);
+        hipLaunchKernelGGL(ba_chol_update, dim3(nt, nt + 1), dim3(256), 0, st, n, c0, nb, S, Lfac, dcam, state);
       }
     }
     hipLaunchKernelGGL(ba_chol_solve, dim3(1), dim3(1024), 0, st, n, Lfac, dcam, state);

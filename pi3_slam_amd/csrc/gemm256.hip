@@ -542,6 +542,12 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
     }
     // the hazard recogniser does not see into the asm MFMAs: let the last ones retire before the epilogue reads them
     asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");
+    // (empty statements that redefine every accumulator: volatile asm keeps its order, so no instruction of the epilogue
+    // that reads an accumulator can be scheduled in front of the nops)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) asm volatile("" : "+v"(acc[i][j]));
 #undef GI_RD
 #undef GI_RD_GROUP
 #undef GI_RD1
@@ -1159,6 +1165,10 @@ __global__ __launch_bounds__(256) void gemm4w_kernel(GemmParams p) {
     }   // !ILV
     // the hazard recogniser does not see into the asm MFMAs: let the last ones retire before the epilogue reads AGPRs
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) asm volatile("" : "+a"(acc[i][j]));     // pins the epilogue's reads behind the nops
     // nobody reads the pipeline buffers after the last barrier: the epilogue may reuse them at once
     const int m_base = bm * G2_BM + wm * 128, n_base = bn * G2_BN + wn * 128;
     if constexpr (OUT_BF16) {

@@ -509,5 +509,35 @@ def test_gemm_four_wave_variant_is_bit_identical(dev, M, N, K):
                 got = run_all()
                 for i, (g, b) in enumerate(zip(got, base)):
                     assert torch.equal(g, b), (form, rep, i, (g.float() - b.float()).abs().max().item())
+        # the eight-wave kernel's interleaved K loop (knob gemm_ilv: K-half phases, double-buffered fragments, one barrier
+        # per K tile; 5 % slower, not the default): same products, same order
+        lib.set_knob("gemm_4w", 0)
+        lib.set_knob("gemm_ilv", 1)
+        for rep in range(3):
+            got = run_all()
+            for i, (g, b) in enumerate(zip(got, base)):
+                assert torch.equal(g, b), ("ilv", rep, i, (g.float() - b.float()).abs().max().item())
     finally:
         lib.set_knob("gemm_4w", 0)
+        lib.set_knob("gemm_ilv", 0)
+
+
+def test_gemm_operand_of_four_gib_takes_the_generic_kernel(dev):
+    """The 256 x 256 kernel addresses an operand row through a 32-bit byte offset from the matrix base (LDS-DMA from
+    inline asm, round 4) and declines operands whose footprint M x lda x 2 reaches 4 GiB: a strided view with that
+    footprint must come out right through the fallback (and the same rows, packed, through the 256 x 256 kernel)."""
+    from pi3_slam_amd import ops
+    M, N, K, lda = 1100, 256, 128, 2_000_000               # 1100 x 2e6 x 2 B = 4.4 GB
+    big = torch.empty(M, lda, device=dev, dtype=torch.bfloat16)
+    a = big[:, :K]
+    a.copy_(torch.randn(M, K, device=dev))
+    w = (torch.randn(N, K, device=dev) / math.sqrt(K)).bfloat16()
+    bias = torch.randn(N, device=dev)
+    ref = a.float() @ w.float().T + bias
+    out = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+    ops.gemm(a, w, out, bias=bias)
+    assert rel(out, ref)[0] < 6e-3
+    out2 = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+    ops.gemm(a.contiguous(), w, out2, bias=bias)
+    assert rel(out2, ref)[0] < 6e-3
+    del big

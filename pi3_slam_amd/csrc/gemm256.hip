@@ -609,14 +609,27 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
     fa[i][0] = *(const bf16x8*)((BUFP) + a_base + (4 * (MH) + i) * 2048 + off0);          \
     fa[i][1] = *(const bf16x8*)((BUFP) + a_base + (4 * (MH) + i) * 2048 + off1);          \
   }
+#ifndef G2_PRIO
+#define G2_PRIO 0      // development switch: 0 = MFMA segment at priority 1 (shipped), 1 = no priorities, 2 = load segment at priority 1
+#endif
+#if G2_PRIO == 0
+#define G2_PRIO_MFMA_ON() __builtin_amdgcn_s_setprio(1);
+#define G2_PRIO_MFMA_OFF() __builtin_amdgcn_s_setprio(0);
+#elif G2_PRIO == 1
+#define G2_PRIO_MFMA_ON()
+#define G2_PRIO_MFMA_OFF()
+#else
+#define G2_PRIO_MFMA_ON() __builtin_amdgcn_s_setprio(0);
+#define G2_PRIO_MFMA_OFF() __builtin_amdgcn_s_setprio(1);
+#endif
 #define MFMA_Q(MH, NH)                                                                                   \
-  __builtin_amdgcn_s_setprio(1);                                                                         \
+  G2_PRIO_MFMA_ON()                                                                                      \
   _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                                        \
   _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                           \
   _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                           \
     acc[2 * (NH) + i][4 * (MH) + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                            \
         fw[2 * (NH) + i][kk], fa[j][kk], acc[2 * (NH) + i][4 * (MH) + j], 0, 0, 0);                       \
-  __builtin_amdgcn_s_setprio(0);
+  G2_PRIO_MFMA_OFF()
 // raw barrier (no vmcnt drain); the empty asm statements with a memory clobber stop the compiler from moving LDS reads /
 // LDS-DMA issues across it (s_barrier itself is not a memory operation to LLVM)
 #define PHASE_END()                            \

@@ -30,7 +30,8 @@ const char* pi3_last_error(void);
 int pi3_abi_version(void);   /* 4 */
 
 /* Run-time A/B knob (speed only: every value selects a correct variant).  Names are the lower-case forms of the
- * PI3_* environment knobs that are read through it (gemm_stagger_ns, gemm_rpref, gelu_form); the
+ * PI3_* environment knobs that are read through it (gelu_form, gemm_4w, gemm_ilv, gemm_stagger_ns, gemm_rpref,
+ * attn_frame_nw, ba_schur_rows); the
  * environment variable is the initial value.  Used by tools/ to interleave variants in one process. */
 int pi3_set_knob(const char* name, long value);
 int pi3_device_count(void);

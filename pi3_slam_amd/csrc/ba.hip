@@ -703,7 +703,9 @@ __global__ __launch_bounds__(64) void ba_chol_diag(int n, int c0, int nb, const 
   const bool mine = r < nb;
   const double* srow = S + (long)(c0 + (mine ? r : 0)) * n + c0;
 #pragma unroll
-  for (int q = 0; q < BA_NB; ++q) a[q] = (mine && q <= r && q < nb) ? srow[q] : 0.0;
+  for (int q = 0; q < BA_NB; ++q) a[q] = srow[q < nb ? q : nb - 1];          // unconditional: 48 loads in flight
+#pragma unroll
+  for (int q = 0; q < BA_NB; ++q) a[q] = (mine && q <= r && q < nb) ? a[q] : 0.0;
   bool fail = false;
 #pragma unroll
   for (int c = 0; c < BA_NB; ++c) {
@@ -749,9 +751,21 @@ __global__ __launch_bounds__(64) void ba_chol_panel(int n, int c0, int nb, const
                                                     double* __restrict__ rhs, const BaState* st) {
   __shared__ double l11[BA_NB][BA_NB];
   if (st->done != 0.0 || st->chol_fail != 0.0) return;
-  for (int e = threadIdx.x; e < nb * nb; e += 64) {
-    const int i = e / nb, j = e - i * nb;
-    l11[i][j] = j <= i ? Ldiag[(long)(c0 + i) * n + c0 + j] : 0.0;
+  // (a predicated load followed by its LDS store costs one global round trip per element - hipcc puts the wait in front
+  // of every store: 36 round trips were 30 of this kernel's 37 us)
+  {
+    double tmp[BA_NB * BA_NB / 64];
+#pragma unroll
+    for (int q = 0; q < BA_NB * BA_NB / 64; ++q) {       // unconditional loads at clamped indices: in flight together
+      const int e = q * 64 + threadIdx.x, i = e / BA_NB, j = e - i * BA_NB;
+      const int ii = i < nb ? i : nb - 1, jj = j < ii ? j : ii;
+      tmp[q] = Ldiag[(long)(c0 + ii) * n + c0 + jj];
+    }
+#pragma unroll
+    for (int q = 0; q < BA_NB * BA_NB / 64; ++q) {
+      const int e = q * 64 + threadIdx.x, i = e / BA_NB, j = e - i * BA_NB;
+      l11[i][j] = (i < nb && j <= i) ? tmp[q] : 0.0;
+    }
   }
   __syncthreads();
   const int r = c0 + nb + blockIdx.x * 64 + threadIdx.x;
@@ -759,14 +773,19 @@ __global__ __launch_bounds__(64) void ba_chol_panel(int n, int c0, int nb, const
   double x[BA_NB];
   const double* srow = r < n ? S + (long)r * n + c0 : rhs + c0;
 #pragma unroll
-  for (int j = 0; j < BA_NB; ++j) x[j] = j < nb ? srow[j] : 0.0;
+  for (int j = 0; j < BA_NB; ++j) x[j] = srow[j < nb ? j : nb - 1];
 #pragma unroll
   for (int j = 0; j < BA_NB; ++j) {
     if (j < nb) {        // uniform
-      double v = x[j];
+      // two partial sums (even / odd k): half the length of the dependent multiply-add chain of a row
+      double v0 = x[j], v1 = 0.0;
 #pragma unroll
-      for (int k = 0; k < j; ++k) v -= x[k] * l11[j][k];       // same address in every lane: a broadcast read
-      x[j] = v / l11[j][j];
+      for (int k = 0; k + 1 < j; k += 2) {
+        v0 -= x[k] * l11[j][k];                                // same address in every lane: a broadcast read
+        v1 -= x[k + 1] * l11[j][k + 1];
+      }
+      if (j & 1) v0 -= x[j - 1] * l11[j][j - 1];
+      x[j] = (v0 + v1) / l11[j][j];
     }
   }
   double* lrow = r < n ? L + (long)r * n + c0 : rhs + c0;
@@ -794,10 +813,21 @@ __global__ __launch_bounds__(256) void ba_chol_update(int n, int c0, int nb, dou
     }
     return;
   }
-  for (int e = tid; e < BA_NB * nb; e += 256) {
-    const int i = e / nb, k = e - i * nb;
-    lr[i][k] = r0 + i < n ? L[(long)(r0 + i) * n + c0 + k] : 0.0;
-    lq[i][k] = q0 + i < n ? L[(long)(q0 + i) * n + c0 + k] : 0.0;
+  {
+    double tr[BA_NB * BA_NB / 256], tq[BA_NB * BA_NB / 256];
+#pragma unroll
+    for (int q = 0; q < BA_NB * BA_NB / 256; ++q) {      // unconditional loads at clamped indices (see ba_chol_panel)
+      const int e = q * 256 + tid, i = e / BA_NB, k = e - i * BA_NB, kk = k < nb ? k : nb - 1;
+      const int ri = r0 + i < n ? r0 + i : n - 1, qi = q0 + i < n ? q0 + i : n - 1;
+      tr[q] = L[(long)ri * n + c0 + kk];
+      tq[q] = L[(long)qi * n + c0 + kk];
+    }
+#pragma unroll
+    for (int q = 0; q < BA_NB * BA_NB / 256; ++q) {
+      const int e = q * 256 + tid, i = e / BA_NB, k = e - i * BA_NB;
+      lr[i][k] = (k < nb && r0 + i < n) ? tr[q] : 0.0;
+      lq[i][k] = (k < nb && q0 + i < n) ? tq[q] : 0.0;
+    }
   }
   __syncthreads();
   for (int e = tid; e < BA_NB * BA_NB; e += 256) {
@@ -826,9 +856,19 @@ __global__ __launch_bounds__(1024) void ba_chol_solve(int n, const double* __res
   __syncthreads();
   for (int c0 = ((n - 1) / BA_NB) * BA_NB; c0 >= 0; c0 -= BA_NB) {   // backward
     const int nb = min(BA_NB, n - c0);
-    for (int e = tid; e < nb * nb; e += 1024) {
-      const int i = e / nb, j = e - i * nb;
-      blk[i][j] = j <= i ? L[(long)(c0 + i) * n + c0 + j] : 0.0;
+    {
+      double tb[3];
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        const int e = q * 1024 + tid, ec = e < BA_NB * BA_NB ? e : 0, i = ec / BA_NB, j = ec - i * BA_NB;
+        const int ii = i < nb ? i : nb - 1, jj = j < ii ? j : ii;
+        tb[q] = L[(long)(c0 + ii) * n + c0 + jj];
+      }
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        const int e = q * 1024 + tid, i = e / BA_NB, j = e - i * BA_NB;
+        if (e < BA_NB * BA_NB) blk[i][j] = (i < nb && j <= i) ? tb[q] : 0.0;
+      }
     }
     __syncthreads();
     if (tid < 64) {

@@ -89,6 +89,34 @@ def test_umeyama_known_answers():
     assert abs(np.linalg.det(Rp) - 1.0) < 1e-9
 
 
+def test_umeyama_rotation_equals_scipys_kabsch():
+    """A third implementation nobody here wrote: scipy's `Rotation.align_vectors` (Kabsch with weights and the reflection
+    fix) on the centred point sets must return the oracle's rotation, weighted and unweighted, on noisy, planar and
+    mirrored data; scale and translation then follow from the closed form's own definitions (s = <R xc, yc> / |xc|^2,
+    t = my - s R mx), checked here as identities."""
+    from scipy.spatial.transform import Rotation
+    rng = np.random.default_rng(11)
+    for case in range(12):
+        n = int(rng.integers(4, 200))
+        x = rng.standard_normal((n, 3)) * rng.uniform(0.2, 3.0, 3) + rng.uniform(-2, 2, 3)
+        if case % 4 == 1:
+            x[:, 2] = x[:, 0] * 0.3 - 1.0                               # planar
+        R0 = Rotation.from_rotvec(rng.standard_normal(3)).as_matrix()
+        y = rng.uniform(0.3, 3.0) * x @ R0.T + rng.uniform(-3, 3, 3) + 0.02 * rng.standard_normal(x.shape)
+        if case % 4 == 2:
+            y[:, 0] *= -1.0                                             # mirrored: the best PROPER rotation is wanted
+        w = rng.random(n) + 0.05 if case % 2 else None
+        s, R, t, _ = post_ref.umeyama(x, y, w)
+        ww = np.ones(n) if w is None else w
+        mx, my = (ww[:, None] * x).sum(0) / ww.sum(), (ww[:, None] * y).sum(0) / ww.sum()
+        xc, yc = x - mx, y - my
+        Rs = Rotation.align_vectors(yc, xc, weights=ww)[0].as_matrix()   # yc ~ Rs xc
+        np.testing.assert_allclose(R, Rs, atol=1e-9)
+        s_def = (ww * ((xc @ R.T) * yc).sum(1)).sum() / (ww * (xc ** 2).sum(1)).sum()
+        assert abs(s - s_def) <= 1e-12 * abs(s_def)
+        np.testing.assert_allclose(t, my - s * R @ mx, atol=1e-12)
+
+
 def test_weighted_umeyama_known_answers():
     """The weighted closed form: integer weights equal repeated points; it is the minimiser of the
     weighted cost (scipy on the 7 similarity parameters cannot do better); uniform weights change nothing; and in

@@ -1,11 +1,15 @@
-"""Command line of the MI355X path.  Two sub-commands that take the flags of the reference's two offline scripts
-(create_offline_chunks.py:44-62, reconstruct_offline.py:21-29), declared as tables below, plus this build's own:
+"""Command line of the MI355X path.  Sub-commands that take the flags of the reference's two offline scripts
+(create_offline_chunks.py:44-62, reconstruct_offline.py:21-29) and of its online script
+(pi3_slam_online_modular.py:117-183, without the viser window), declared as tables below, plus this build's own:
 
   python -m pi3_slam_amd.cli create --images /data/seq --output /data/seq_chunks --chunk-length 100 --overlap 20 \\
          --model-path /ckpt/pi3 [--moge-model-path model.pt] [--cam-dist-path calib.json] [--device-resize] [--hip-graph]
   python -m pi3_slam_amd.cli reconstruct --chunks /data/seq_chunks --output /data/seq_chunks/reconstruction
 
-Under `python -m torch.distributed.run --nproc-per-node G -m pi3_slam_amd.cli ...` both stages shard over the G GPUs.
+  python -m pi3_slam_amd.cli online --image_dir /data/seq --output_path /data/seq_result --chunk_length 100 --overlap 20 \
+         --model_path /ckpt/pi3 --save_tum [--cam_dist_path calib.json] [--use_inverse_depth]
+
+Under `python -m torch.distributed.run --nproc-per-node G -m pi3_slam_amd.cli ...` every stage shards over the G GPUs.
 """
 from __future__ import annotations
 
@@ -58,6 +62,47 @@ RECON_SWITCHES = (("--save-per-chunk", "per-chunk ply files as well"),
                                           "camera moved by more than the scene extent)"))
 
 
+# pi3_slam_online_modular.py:117-183: same names (underscores), types and defaults; the reference's personal default paths
+# become required arguments, the three viser flags are accepted and ignored (no window in this build)
+ONLINE_FLAGS: Sequence[Tuple[str, Dict]] = (
+    ("--image_dir", dict(default=None, help="directory containing images")),
+    ("--video_path", dict(default=None, help="video file (not supported here: no decoder in this image)")),
+    ("--start_frame", dict(type=int, default=0)),
+    ("--end_frame", dict(type=int, default=None)),
+    ("--skip_start", dict(type=int, default=0, help="frames to drop at the beginning")),
+    ("--skip_end", dict(type=int, default=0, help="frames to drop at the end")),
+    ("--model_path", dict(default="recipe", help="local Pi3 checkpoint; 'recipe' = synthetic weights (no network)")),
+    ("--device", dict(default="cuda")),
+    ("--chunk_length", dict(type=int, default=30)),
+    ("--overlap", dict(type=int, default=5)),
+    ("--conf_threshold", dict(type=float, default=0.5)),
+    ("--cam_scale", dict(type=float, default=1.0)),
+    ("--cam_dist_path", dict(default=None, help="camera calibration JSON: undistort the frames first")),
+    ("--keypoint_type", dict(default="grid")),
+    ("--max_num_keypoints", dict(type=int, default=200)),
+    ("--keypoint_detection_threshold", dict(type=float, default=0.005)),
+    ("--max_observations_per_track", dict(type=int, default=6)),
+    ("--viz_port", dict(type=int, default=8080, help="ignored: no visualisation window in this build")),
+    ("--output_path", dict(REQ, help="directory (or .ply file) for trajectory.ply / trajectory.tum")),
+    ("--max_points", dict(type=int, default=1000000)),
+    # this build's additions
+    ("--moge_model_path", dict(default=None, help="local MoGe-2 model.pt; 'recipe' = synthetic weights")),
+    ("--num_workers", dict(type=int, default=4, help="decode threads")),
+)
+ONLINE_SWITCHES = (("--save_chunk_reconstructions", "save each chunk reconstruction to disk"),
+                   ("--save_transformed_reconstructions", "save transformed reconstructions as PLY files"),
+                   ("--save_debug_reconstructions", "accepted for compatibility"),
+                   ("--save_debug_projections", "accepted for compatibility"),
+                   ("--use_inverse_depth", "inverse-depth parametrization in both bundle adjustments"),
+                   ("--no_visualization", "accepted for compatibility (there is never a window)"),
+                   ("--keep_viz_open", "accepted for compatibility"),
+                   ("--save_tum", "save the trajectory in TUM format"),
+                   ("--tum_integer_timestamp", "integer timestamps in the TUM file (7-Scenes)"),
+                   ("--no_bundle_adjust", "closed-form Sim(3) chain only"),
+                   ("--no_hip_graph", "plain kernel launches instead of the captured per-chunk graph"),
+                   ("--reuse_overlap_encoder", "overlap frames take their encoder output from the previous chunk"))
+
+
 def list_images(root: str) -> List[str]:
     """Folder -> its png, jpg, jpeg, bmp files (each extension group sorted, groups in that order); file -> its
     non-empty lines; anything else is a glob pattern."""
@@ -71,7 +116,8 @@ def list_images(root: str) -> List[str]:
 def build_parser() -> argparse.ArgumentParser:
     top = argparse.ArgumentParser(prog="pi3_slam_amd.cli", description=__doc__.split("\n")[0])
     sub = top.add_subparsers(dest="command", required=True)
-    for name, flags, switches in (("create", CREATE_FLAGS, CREATE_SWITCHES), ("reconstruct", RECON_FLAGS, RECON_SWITCHES)):
+    for name, flags, switches in (("create", CREATE_FLAGS, CREATE_SWITCHES), ("reconstruct", RECON_FLAGS, RECON_SWITCHES),
+                                  ("online", ONLINE_FLAGS, ONLINE_SWITCHES)):
         p = sub.add_parser(name)
         for flag, kw in flags:
             p.add_argument(flag, **kw)
@@ -81,6 +127,10 @@ def build_parser() -> argparse.ArgumentParser:
             p.add_argument("--metric-depth", dest="metric_depth", action="store_true", default=True)
             p.add_argument("--no-metric-depth", dest="metric_depth", action="store_false")
             p.add_argument("--estimate-intrinsics", action="store_true", default=True)
+        if name == "online":   # store_true with default True in the reference: always on there, switchable here
+            p.add_argument("--estimate_camera_params", action="store_true", default=True)
+            p.add_argument("--do_metric_depth", dest="do_metric_depth", action="store_true", default=True)
+            p.add_argument("--no_metric_depth", dest="do_metric_depth", action="store_false")
     return top
 
 
@@ -113,9 +163,62 @@ def run_reconstruct(a: argparse.Namespace) -> None:
                          ba_sanity_gate=not a.no_ba_sanity_gate).run()
 
 
+def online_image_paths(a: argparse.Namespace) -> List[str]:
+    """load_image_paths of the reference's online script (pi3_slam_online_modular.py:66-113) for image directories:
+    skip_start / skip_end trim the sorted list; a video needs a decoder this image does not have."""
+    if bool(a.image_dir) == bool(a.video_path):
+        raise SystemExit("Must specify either --image_dir or --video_path" if not a.image_dir
+                         else "Cannot specify both --image_dir and --video_path")
+    if a.video_path:
+        raise SystemExit("--video_path: no video decoder (torchcodec / cv2) in this build; extract the frames and use --image_dir")
+    if a.skip_start < 0 or a.skip_end < 0:
+        raise SystemExit("--skip_start / --skip_end must be non-negative")
+    paths = list_images(a.image_dir)
+    lo, hi = a.skip_start, len(paths) - a.skip_end
+    if lo >= hi:
+        raise SystemExit(f"No images found after applying frame skipping ({len(paths)} images)")
+    return paths[lo:hi]
+
+
+def run_online(a: argparse.Namespace) -> None:
+    """main() of pi3_slam_online_modular.py:186-372 without the viser window: stream the images through Pi3SLAMOnline,
+    then trajectory.ply (+ trajectory.tum with --save_tum) under --output_path."""
+    from .online import Pi3SLAMOnline
+    from .undistortion import create_undistortion_maps
+    paths = online_image_paths(a)
+    print(f"✅ Total images/frames to process: {len(paths):,}")
+    maps = create_undistortion_maps(a.cam_dist_path, device=a.device) if a.cam_dist_path else None
+    out_is_dir = os.path.isdir(a.output_path) or a.output_path.endswith("/") or not a.output_path.endswith(".ply")
+    out_dir = a.output_path if out_is_dir else os.path.dirname(a.output_path)
+    os.makedirs(out_dir or ".", exist_ok=True)
+    slam = Pi3SLAMOnline(
+        chunk_length=a.chunk_length, overlap=a.overlap, device=a.device, conf_threshold=a.conf_threshold,
+        undistortion_maps=maps, cam_scale=a.cam_scale, estimate_camera_params=a.estimate_camera_params,
+        keypoint_type=a.keypoint_type, max_num_keypoints=a.max_num_keypoints,
+        keypoint_detection_threshold=a.keypoint_detection_threshold,
+        save_chunk_reconstructions=a.save_chunk_reconstructions, max_observations_per_track=a.max_observations_per_track,
+        do_metric_depth=a.do_metric_depth, model_path=a.model_path,
+        use_inverse_depth=a.use_inverse_depth, moge_model_path=a.moge_model_path, hip_graph=not a.no_hip_graph,
+        output_dir=out_dir, num_loader_workers=a.num_workers, bundle_adjust=not a.no_bundle_adjust,
+        reuse_overlap_encoder=a.reuse_overlap_encoder)
+    slam.save_transformed_reconstructions = a.save_transformed_reconstructions
+    slam.save_debug_reconstructions = a.save_debug_reconstructions
+    slam.process_chunks(paths)
+    stats = slam.get_statistics()
+    print(f"✅ Total chunks processed: {stats['num_chunks']}\n✅ Total frames processed: {stats['num_frames']}")
+    if slam.rank != 0:
+        return
+    ply = os.path.join(out_dir, "trajectory.ply") if out_is_dir else a.output_path
+    tum = os.path.join(out_dir, "trajectory.tum") if out_is_dir else a.output_path.replace(".ply", ".tum")
+    slam.save_final_result(ply, max_points=a.max_points)
+    if a.save_tum:
+        slam.save_trajectory_tum(tum, integer_timestamp=a.tum_integer_timestamp)
+    print(f"💾 Saved {ply}" + (f" and {tum}" if a.save_tum else ""))
+
+
 def main(argv=None) -> None:
     a = build_parser().parse_args(argv)
-    (run_create if a.command == "create" else run_reconstruct)(a)
+    {"create": run_create, "reconstruct": run_reconstruct, "online": run_online}[a.command](a)
 
 
 if __name__ == "__main__":

@@ -185,6 +185,32 @@ def test_cli_parsers_and_image_listing(tmp_path):
         cli.main(["create", "--images", str(tmp_path / "nothing_*.png"), "--output", str(tmp_path / "o")])
 
 
+def test_cli_online_parser_follows_the_reference_script(tmp_path):
+    """Flags, types and defaults of pi3_slam_online_modular.py:117-183 (underscore names); the frame trimming of its
+    load_image_paths; a video is refused with a reason (no decoder here)."""
+    from pi3_slam_amd import cli
+    a = cli.build_parser().parse_args(["online", "--image_dir", "d", "--output_path", "o"])
+    assert (a.start_frame, a.end_frame, a.skip_start, a.skip_end, a.device, a.chunk_length, a.overlap, a.conf_threshold,
+            a.cam_scale, a.estimate_camera_params, a.cam_dist_path, a.keypoint_type, a.max_num_keypoints,
+            a.keypoint_detection_threshold, a.save_chunk_reconstructions, a.save_transformed_reconstructions,
+            a.save_debug_reconstructions, a.save_debug_projections, a.max_observations_per_track, a.do_metric_depth,
+            a.use_inverse_depth, a.viz_port, a.no_visualization, a.keep_viz_open, a.max_points, a.save_tum,
+            a.tum_integer_timestamp) == \
+        (0, None, 0, 0, "cuda", 30, 5, 0.5, 1.0, True, None, "grid", 200, 0.005, False, False, False, False, 6, True,
+         False, 8080, False, False, 1000000, False, False)
+    for i in range(7):
+        (tmp_path / f"f{i}.png").write_bytes(b"")
+    a = cli.build_parser().parse_args(["online", "--image_dir", str(tmp_path), "--output_path", "o", "--skip_start", "2",
+                                       "--skip_end", "1"])
+    assert [os.path.basename(p) for p in cli.online_image_paths(a)] == ["f2.png", "f3.png", "f4.png", "f5.png"]
+    for argv in (["online", "--output_path", "o"],
+                 ["online", "--image_dir", "d", "--video_path", "v.mp4", "--output_path", "o"],
+                 ["online", "--video_path", "v.mp4", "--output_path", "o"],
+                 ["online", "--image_dir", str(tmp_path), "--output_path", "o", "--skip_start", "7"]):
+        with pytest.raises(SystemExit):
+            cli.online_image_paths(cli.build_parser().parse_args(argv))
+
+
 def test_in_order_drain_releases_chunks_in_chunk_order():
     """Reorder buffer of the chunk-parallel online path (reference: slam/online_reconstructor.py:852-920)."""
     import random

@@ -483,6 +483,24 @@ def test_cli_entry_points_full_model(tmp_path, built_lib):
     assert os.path.exists(tmp_path / "rec" / "final_points.ply")
 
 
+def test_cli_online_entry_point_full_model(tmp_path, built_lib):
+    """python -m pi3_slam_amd.cli online with the reference online script's flags (pi3_slam_online_modular.py:117-183):
+    full-size pi3 with recipe weights, 14 frames in sliding windows of 6 / overlap 2, trajectory.ply + trajectory.tum
+    under --output_path as the reference writes them."""
+    from pi3_slam_amd import cli
+    frames = tmp_path / "frames"
+    frames.mkdir()
+    _write_frames(str(frames), n=14)
+    out = tmp_path / "result"
+    cli.main(["online", "--image_dir", str(frames), "--output_path", str(out), "--chunk_length", "6", "--overlap", "2",
+              "--model_path", "recipe", "--no_metric_depth", "--max_num_keypoints", "64", "--num_workers", "0",
+              "--save_tum", "--tum_integer_timestamp", "--no_visualization", "--skip_end", "1", "--no_bundle_adjust"])
+    tum = np.loadtxt(out / "trajectory.tum")
+    assert tum.shape == (13, 8) and np.isfinite(tum).all()
+    assert np.array_equal(tum[:, 0], np.round(tum[:, 0]))                        # integer time stamps
+    assert os.path.getsize(out / "trajectory.ply") > 0
+
+
 def test_online_sliding_window_matches_offline_two_stage(tmp_path, built_lib):
     """BASELINE config 5 plumbing: the online facade (stream -> chunks -> progressive alignment, hipGraph forward) must
     give the trajectory of the offline two-stage flow (same kernels, no disk round trip)."""

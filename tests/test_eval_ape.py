@@ -106,3 +106,36 @@ def test_command_line_and_json(tmp_path):
     bad.write_text("0 1 2 3\n")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "eval_ape.py"), GT, str(bad)], capture_output=True, text=True)
     assert r.returncode != 0 and "8 entries" in r.stderr
+
+
+def test_eval_sequences_plans_the_reference_scripts_runs(capsys):
+    """tools/eval_sequences.py --dry-run: the command lines of scripts/eval_7scenes.sh (offline: K = 400 grid keypoints,
+    metric depth, intrinsics, 10 observations per track; online: integer time stamps) and scripts/eval_euroc.sh (cam0
+    folder, calibration, per-sequence start frame, 7 observations, inverse depth) for this build's CLI."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("eval_sequences", os.path.join(ROOT, "tools", "eval_sequences.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    mod.main(["7scenes", "--dataset-path", "/d", "--groundtruth-dir", "/gt", "--dry-run"])
+    out = capsys.readouterr().out.strip().split("\n")
+    assert len(out) == 7 * 3
+    assert out[0] == ("python -m pi3_slam_amd.cli create --images /d/chess/seq-01/color --model-path recipe --output "
+                      "logs/7scenes/chess --chunk-length 50 --overlap 5 --device cuda --metric-depth --keypoints grid "
+                      "--max-kp 400 --estimate-intrinsics --num-workers 2")
+    assert out[1].endswith("--output logs/7scenes/chess/reconstruction --max-observations-per-track 10")
+    assert out[2] == "python tools/eval_ape.py /gt/chess.txt logs/7scenes/chess/reconstruction/trajectory_tum.txt"
+    mod.main(["euroc", "--dataset-path", "/d", "--groundtruth-dir", "/gt", "--calib-file", "c.json", "--mode", "online",
+              "--chunk-length", "100", "--overlap", "20", "--dry-run"])
+    out = capsys.readouterr().out.strip().split("\n")
+    assert len(out) == 5 * 2 and "--skip_start 885" in out[0] and "--use_inverse_depth" in out[0]
+    assert "--max_observations_per_track 7" in out[0] and "--cam_dist_path c.json" in out[0]
+    assert "--tum_integer_timestamp" not in out[0] and "--chunk_length 100 --overlap 20" in out[0]
+    assert out[1] == "python tools/eval_ape.py /gt/MH_01_easy.txt logs/euroc/MH_01_easy/online/trajectory.tum"
+    # the planned argv parse with the CLI's own parser
+    from pi3_slam_amd import cli
+    for seq, images, steps, traj, gt in mod.plan("euroc", type("A", (), dict(
+            dataset_path="/d", output_dir="o", moge_model_path="m.pt", mode="offline", model_path="ckpt", chunk_length=50,
+            overlap=5, calib_file="c.json", groundtruth_dir="/gt"))()):
+        for st in steps:
+            cli.build_parser().parse_args(st)
+

@@ -517,9 +517,11 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
       GI_RD_GROUP(fa0, fw0, aa, ww, 6) GI_RD_GROUP(fa0, fw0, aa, ww, 7)
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
+    if (p.ilv_prio == 1 && wm == 1) __builtin_amdgcn_s_setprio(1);
     for (int u = 0; u < nk; ++u) {
       const unsigned slot = (u & 1) * G2_BUF, nslot = slot ^ G2_BUF;
       const bool more1 = (u + 1 < nk), more2 = (u + 2 < nk);
+      if (p.ilv_prio == 2) { if (wm == 0) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
       {   // phase kk0: MFMAs on (fa0, fw0); the kk1 fragments of this tile arrive
         const unsigned aa = a_rd + slot + off1, ww = w_rd + slot + off1;
 #define GI_A(G) GI_MF4(fa0, fw0, G) GI_RD2(fa1, fw1, aa, ww, G)
@@ -529,6 +531,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_waitcnt vmcnt(0)" ::: "memory");   // kk1 fragments; own pieces of tile u + 1
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
+      if (p.ilv_prio == 2) { if (wm == 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
       {   // phase kk1: MFMAs on (fa1, fw1); kk0 fragments of tile u + 1 arrive; tile u + 2 goes into tile u's buffer
         const unsigned aa = a_rd + nslot + off0, ww = w_rd + nslot + off0;
 #define GI_B(G)                                           \
@@ -540,6 +543,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
+    if (p.ilv_prio) __builtin_amdgcn_s_setprio(0);
     // the hazard recogniser does not see into the asm MFMAs: let the last ones retire before the epilogue reads them
     asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");
     // (empty statements that redefine every accumulator: volatile asm keeps its order, so no instruction of the epilogue
@@ -1244,6 +1248,7 @@ int pi3_gemm256_try(const GemmParams& p, int out_dtype, int act, hipStream_t str
   const_cast<GemmParams&>(p).tile_order = order_knob >= 0 ? order_knob : (p.N / G2_BN <= 4 ? 1 : 0);
   // run-time knobs (pi3_set_knob / PI3_GEMM_STAGGER_NS, PI3_GEMM_RPREF, PI3_GELU_FORM): see the kernel
   const_cast<GemmParams&>(p).stagger_ns = (int)PI3_KNOB("gemm_stagger_ns", 0);
+  const_cast<GemmParams&>(p).ilv_prio = 0;
   const_cast<GemmParams&>(p).rpref = (int)PI3_KNOB("gemm_rpref", 0);
   if (act == 1 && PI3_KNOB("gelu_form", 0) == 1) act = 3;
   static int impl3 = -1;     // PI3_GEMM_IMPL=3: the two-workgroups-per-CU 128x256 kernel for every large GEMM (A/B knob)
@@ -1261,7 +1266,10 @@ int pi3_gemm256_try(const GemmParams& p, int out_dtype, int act, hipStream_t str
     if (impl4) return launch4w<true, 0, true>(p, stream);
     if (impl3 && (p.K % 32) == 0) return launch3<true, 0, true>(p, stream);
 #if G2_ASM_DMA
-    if ((int)PI3_KNOB("gemm_ilv", 0)) return launch256<true, 0, false, false, true, true>(p, stream);
+    if (const int ilv = (int)PI3_KNOB("gemm_ilv", 0)) {
+      const_cast<GemmParams&>(p).ilv_prio = ilv - 1;
+      return launch256<true, 0, false, false, true, true>(p, stream);
+    }
 #endif
     return launch256<true, 0, false, true, true>(p, stream);
   }
@@ -1293,7 +1301,8 @@ int pi3_gemm256_try(const GemmParams& p, int out_dtype, int act, hipStream_t str
     stag = e ? atoi(e) : 1;
   }
 #if G2_ASM_DMA
-  if ((int)PI3_KNOB("gemm_ilv", 0)) {     // interleaved K loop (experiment, see gemm256_kernel)
+  if (const int ilv = (int)PI3_KNOB("gemm_ilv", 0)) {     // interleaved K loop (experiment, see gemm256_kernel); 2 / 3: wave priorities
+    const_cast<GemmParams&>(p).ilv_prio = ilv - 1;
     if (abl & 1) return launch256<true, 0, true, false, false, true>(p, stream);
     if (out_dtype == 0 && act == 0) return launch256<true, 0, false, false, false, true>(p, stream);
     if (out_dtype == 0 && (act == 1 || act == 3)) return launch256<true, 1, false, false, false, true>(p, stream);

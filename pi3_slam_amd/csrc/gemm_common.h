@@ -19,6 +19,7 @@ struct GemmParams {
   int tile_gm;               // gemm256: m-tiles per scheduling group (0 = default 8); consecutive ids walk a group's m-tiles
   int tile_order;            // gemm256: 0 = m-tiles first inside a group, 1 = column tiles first
   int stagger_ns;            // gemm256 (persistent form): workgroup b starts b * stagger_ns later (0 = all at once)
+  int ilv_prio;              // interleaved K loop (knob gemm_ilv = 2 / 3): 1 = waves 4-7 at priority 1, 2 = the two waves of a SIMD take turns
   int rpref;                 // gemm256, f32 output with a residual: touch the tile's residual lines during the last K tiles
 #ifdef PI3_DEV_ABLATIONS
   int abl;                   // timing-only ablation bits (development builds; results are wrong)

@@ -55,20 +55,23 @@ for (N, K, kind) in [(3072, 1024, "qkv"), (3072, 1024, "qkv_fused"), (1024, 1024
         fn = (lambda a=a, w=w, out=out, bias=bias: ops.gemm(a, w, out, bias=bias))
     runs[kind] = (fn, reset, out)
 
+VARS = (0, 1, 2, 3)     # 0 shipped ping-pong; 1 interleaved; 2 interleaved + waves 4-7 at priority 1; 3 + alternating priority
+NAMES = {0: "ping-pong", 1: "ilv", 2: "ilv prio-static", 3: "ilv prio-alt"}
 bad = 0
 for kind, (fn, reset, out) in runs.items():
     got = []
-    for v in (0, 1):
+    for v in VARS:
         lib.set_knob("gemm_ilv", v)
         reset()
         fn()
         torch.cuda.synchronize()
         got.append(out.clone())
     it = torch.int16 if out.dtype == torch.bfloat16 else torch.int32
-    if not torch.equal(got[0].view(it), got[1].view(it)):
-        bad += 1
-        d = (got[0].float() - got[1].float()).abs()
-        print(f"!! {kind}: interleaved loop differs: max {d.max().item():.3e}, {(d > 0).float().mean().item():.3e} of the elements")
+    for v, g_ in zip(VARS[1:], got[1:]):
+        if not torch.equal(got[0].view(it), g_.view(it)):
+            bad += 1
+            d = (got[0].float() - g_.float()).abs()
+            print(f"!! {kind}: gemm_ilv={v} differs: max {d.max().item():.3e}, {(d > 0).float().mean().item():.3e} of the elements")
 print("BIT-IDENTITY", "ok" if bad == 0 else f"FAILED on {bad} shapes")
 
 
@@ -82,18 +85,18 @@ def timed(fn, n):
     return e0.elapsed_time(e1) / n
 
 
-res = {(k, v): [] for k in runs for v in (0, 1)}
+res = {(k, v): [] for k in runs for v in VARS}
 for r in range(R):
     for kind, (fn, reset, out) in runs.items():
-        for v in (0, 1):
+        for v in VARS:
             lib.set_knob("gemm_ilv", v)
             res[(kind, v)].append(timed(fn, NL))
 lib.set_knob("gemm_ilv", 0)
-tot = [0.0, 0.0]
+tot = {v: 0.0 for v in VARS}
 for kind in runs:
-    t0, t1 = statistics.median(res[(kind, 0)]), statistics.median(res[(kind, 1)])
-    print(f"{kind:10s} ping-pong {t0:.4f} ms   interleaved {t1:.4f} ms   ({100 * (t1 / t0 - 1):+.1f} %)")
+    ts = {v: statistics.median(res[(kind, v)]) for v in VARS}
+    print(f"{kind:10s} " + "   ".join(f"{NAMES[v]} {ts[v]:.4f}" for v in VARS))
     if kind != "qkv":
-        tot[0] += t0
-        tot[1] += t1
-print(f"block (fused qkv + proj + fc1 + fc2): {tot[0]:.4f} -> {tot[1]:.4f} ms ({100 * (tot[1] / tot[0] - 1):+.1f} %)")
+        for v in VARS:
+            tot[v] += ts[v]
+print("block (fused qkv + proj + fc1 + fc2): " + "   ".join(f"{NAMES[v]} {tot[v]:.4f} ms ({100 * (tot[v] / tot[0] - 1):+.1f} %)" for v in VARS))

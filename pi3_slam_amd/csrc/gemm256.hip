@@ -66,6 +66,17 @@ __device__ __forceinline__ void g4_glds16(const char* sbase, unsigned voff, unsi
                : "memory", "m0");
 }
 
+// two pieces 1 KiB apart in LDS behind ONE write of M0 (development switch G2_DMA_PAIR): the second load carries
+// `offset:1024`, which the hardware adds to the global AND the LDS address - the caller passes its lane offset less 1 024
+__device__ __forceinline__ void g4_glds16x2(const char* sbase, unsigned voff0, unsigned voff1_less_1k, unsigned lds_dst) {
+  asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2\n\tglobal_load_lds_dwordx4 %1, %2 offset:1024"
+               ::"v"(voff0), "v"(voff1_less_1k), "s"(sbase), "s"(lds_dst)
+               : "memory", "m0");
+}
+#ifndef G2_DMA_PAIR
+#define G2_DMA_PAIR 0
+#endif
+
 // G2_ASM_DMA = 1 (shipped since round 4): gemm256_kernel's K loop stages through g4_glds16 with per-tile 32-bit lane
 // offsets instead of the builtin with a 64-bit pointer per piece.  Bit-identical output; 230-235 VGPRs and no vector
 // spills where the builtin form sat at 256 with 2-8 spills (nine 64-bit staging pointers become eight dwords, the wave
@@ -440,6 +451,18 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
       aoff[h * 2 + i] = (unsigned)((long)ga * lda_b + c * 16);
       woff[h * 2 + i] = (unsigned)((long)gw * ldw_b + c * 16);
     }
+#if G2_DMA_PAIR
+#define STAGE_A(U, HALF)                                                                  \
+  {                                                                                       \
+    const unsigned sb_ = lds0 + ((U) & 1) * G2_BUF + (HALF) * G2_HALF + wave * 2048;      \
+    g4_glds16x2(Ab + (long)(U) * 128, aoff[(HALF) * 2], aoff[(HALF) * 2 + 1] - 1024u, sb_); \
+  }
+#define STAGE_W(U, HALF)                                                                  \
+  {                                                                                       \
+    const unsigned sb_ = lds0 + ((U) & 1) * G2_BUF + (2 + (HALF)) * G2_HALF + wave * 2048; \
+    g4_glds16x2(Wb + (long)(U) * 128, woff[(HALF) * 2], woff[(HALF) * 2 + 1] - 1024u, sb_); \
+  }
+#else
 #define STAGE_A(U, HALF)                                                                  \
   {                                                                                       \
     const unsigned sb_ = lds0 + ((U) & 1) * G2_BUF + (HALF) * G2_HALF + wave * 2048;      \
@@ -452,6 +475,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
     g4_glds16(Wb + (long)(U) * 128, woff[(HALF) * 2], sb_);                               \
     g4_glds16(Wb + (long)(U) * 128, woff[(HALF) * 2 + 1], sb_ + 1024);                    \
   }
+#endif
 #else
 #define STAGE_A(U, HALF) g2_stage_half(Ab, lda_b, bm * G2_BM + (HALF) * 128, p.M, (long)(U) * 128, \
                                        smem + ((U) & 1) * G2_BUF + (HALF) * G2_HALF, wave, lane)

@@ -76,6 +76,12 @@ __device__ __forceinline__ void g4_glds16x2(const char* sbase, unsigned voff0, u
 #ifndef G2_DMA_PAIR
 #define G2_DMA_PAIR 0
 #endif
+#ifndef G2_NT_STORES
+#define G2_NT_STORES 1     // bf16 output rows stored with the non-temporal hint (round 4: qkv -3.8 %, fused qkv -4.8 %, fc1 -3.5 %
+                           // in alternating processes on one card, 3-4 ms per chunk end to end: the 0.4-0.5 GB an output takes
+                           // no longer passes through the L2 the operand panels live in; the f32 outputs gain nothing: the
+                           // LayerNorm that follows reads them) - profiles/r04_gemm_ab_nontemporal_stores.log
+#endif
 
 // G2_ASM_DMA = 1 (shipped since round 4): gemm256_kernel's K loop stages through g4_glds16 with per-tile 32-bit lane
 // offsets instead of the builtin with a 64-bit pointer per piece.  Bit-identical output; 230-235 VGPRs and no vector
@@ -324,7 +330,11 @@ __device__ __forceinline__ void g2_epilogue_lds(const GemmParams& p, f32x4 (&acc
       }
       if constexpr (OUT_BF16) {
         const u32x4 v = *(const u32x4*)(wl + lrow * PITCH + ch * 16);
+#if G2_NT_STORES
+        __builtin_nontemporal_store(v, (u32x4*)((bf16_t*)p.out + orow * p.ldo + n_base + ch * 8));
+#else
         *(u32x4*)((bf16_t*)p.out + orow * p.ldo + n_base + ch * 8) = v;
+#endif
       } else {
         f32x4 v = *(const f32x4*)(wl + lrow * PITCH + ch * 16);
         const int n0 = n_base + ch * 4;

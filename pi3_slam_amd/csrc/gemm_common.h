@@ -105,11 +105,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
         o[1] = pack_bf16x2(v[2], v[3]);
         *(u32x2*)((bf16_t*)p.out + orow * p.ldo + n0) = o;
       } else {
-#ifdef G2_NT_STORES_F32
-        __builtin_nontemporal_store(v, (f32x4*)((float*)p.out + orow * p.ldo + n0));
-#else
         *(f32x4*)((float*)p.out + orow * p.ldo + n0) = v;
-#endif
       }
     }
   }

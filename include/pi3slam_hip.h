@@ -27,7 +27,7 @@ extern "C" {
 #define PI3_ERR_WORKSPACE (-3)
 
 const char* pi3_last_error(void);
-int pi3_abi_version(void);   /* 4 */
+int pi3_abi_version(void);   /* 5 */
 
 /* Run-time A/B knob (speed only: every value selects a correct variant).  Names are the lower-case forms of the
  * PI3_* environment knobs that are read through it (gelu_form, gemm_4w, gemm_ilv, gemm_stagger_ns, gemm_rpref,
@@ -83,10 +83,24 @@ int pi3_layernorm(const float* x, long ldx, int rows, int D, const float* w, con
 
 /* In place on packed qkv bf16 [rows][3][H][64]: optional LayerNorm(64) of q and k (attention.py:330), RoPE-2D
  * (pos_embed.py:142-159 == curope.cpp:11-47; pos int32 [T][2] (y, x) indexed by row % T; cs f32 [npos][16][2] =
- * (cos, sin) of pos * base^(-j/16)), then q *= qscale.  This is the replacement of the reference's `curope.rope_2d`. */
+ * (cos, sin) of pos * base^(-j/16)), then q *= qscale.  The two-pass form of pi3_gemm_qkv's epilogue (a different
+ * contract from the reference's `curope.rope_2d`: that one is pi3_rope_2d below). */
 int pi3_qknorm_rope(void* qkv, long rows, int H, int T, const int* pos, const float* cs, const float* qw,
                     const float* qb, const float* kw, const float* kb, float eps, float qscale, int do_rope,
                     void* stream);
+
+/* The reference's one native FFI entry under its own contract: `curope.rope_2d(tokens, positions, base, fwd)`
+ * (pi3/models/curope/curope.cpp:49-68, kernels.cu:17-108), what `cuRoPE2D.forward` (curope2d.py:33-40) calls.
+ * In place on tokens (B, N, H, D): element (b, n, h, d) at tokens[b*stride_b + n*stride_n + h*D + d] (the last two
+ * dims contiguous as kernels.cu:91 demands; stride_n = 0 -> H*D, stride_b = 0 -> N*stride_n: a contiguous tensor);
+ * positions int64 (B, N, 2) = (y, x), contiguous; D % 4 == 0.  With Q = D/4 a token vector is [u_Y | v_Y | u_X | v_X]:
+ *   freq = pos * fwd / base^(d/Q);   u' = u cos(freq) - v sin(freq);   v' = v cos(freq) + u sin(freq)     (fp32)
+ * fwd = F0 (1.0) rotates forward, -F0 is the reference's backward pass = the inverse rotation.
+ * dtype of tokens: 0 = bf16, 1 = f32, 2 = f16 (kernels.cu:103 dispatches over floating types + Half + BFloat16).
+ * The hot path does not call it (the rotation rides in pi3_gemm_qkv's epilogue); it exists so that a `cuRoPE2D`
+ * caller binds to this library unchanged. */
+int pi3_rope_2d(void* tokens, const long* positions, int B, int N, int H, int D, long stride_b, long stride_n,
+                float base, float fwd, int dtype, void* stream);
 
 /* f32 -> bf16/f32 strided row copy (concat of the last two decoder outputs, pi3.py:168-171). */
 int pi3_cast_rows(const float* in, long ldi, void* out, long ldo, long rows, int cols, int out_dtype, void* stream);

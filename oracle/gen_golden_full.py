@@ -1,0 +1,168 @@
+"""ORACLE tooling — generates tests/golden/pi3_full.npz: the REAL reference at the HEADLINE size (BASELINE configs[1]:
+100 frames at 308x406, chunk_length 100, grid K = 200), run in the build container only (imports /root/reference).
+
+    python oracle/gen_golden_full.py [--no-bf16]        (~17 min per forward on 8 cores, ~12 GB RAM)
+
+What runs, unmodified: `Pi3.forward` (pi3/models/pi3.py:173-216) INSIDE `OfflineChunkCreator._process_single_chunk`
+(slam/offline_chunk_creator.py:161-256) - masks, intrinsics LM, grid keypoints (234-point grid -> per-frame
+`torch.randperm` subset of 200, keypoint_extraction.py:140-143, global CPU RNG seeded with SEED right before the call),
+gather, fp16 pack.  No MoGe (quirk 6 of SURVEY §8: hard-wired to 'cuda').  The one change, as in
+tools/cpu_reference_timing.py: the `sdpa_kernel([MATH, EFFICIENT])` context of attention.py:339-341 is not entered -
+the MATH backend would materialise 16 x 64 300^2 x 4 B = 265 GB of scores; torch's fused CPU SDPA differs from it by
+1.8e-7.  The object is built with object.__new__ (its __init__ fetches checkpoints by name); weights are
+the recipe weights; frames are `golden_images("pi3_full", ...)`.
+
+Stored: the whole chunk dictionary as it is written to disk; the network's dense outputs every 7th pixel (captured by a
+forward hook on the model, before the caller touches them); eight intermediate activations every 512th token row;
+and - unless --no-bf16 - the reference's OWN bf16-autocast deviation from its fp32 run at this size (`bf16err_*`, full
+arrays), the tolerance anchor of tests/test_engine_gpu.py.
+"""
+from __future__ import annotations
+
+import contextlib
+import os
+import sys
+import time
+import types
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"
+sys.path.insert(0, REPO)
+
+from oracle.gen_golden import golden_images  # noqa: E402
+from oracle.gen_golden_post import _Placeholder  # noqa: E402
+from pi3_slam_amd.weights import Pi3Config, recipe_state_dict_cpu  # noqa: E402
+
+CASE = ("pi3_full", 100, 308, 406, 200)      # name, frames, H, W, max_num_keypoints
+SUB, ROWS = 7, 512                            # pixel stride of the dense maps, token-row stride of the intermediates
+SEED = 20261005                               # torch.manual_seed before _process_single_chunk (the keypoint subsets)
+
+
+def main() -> None:
+    name, N, H, W, max_kp = CASE
+    want_bf16 = "--no-bf16" not in sys.argv
+    torch.set_num_threads(os.cpu_count() or 8)
+    for mod in ("cv2", "natsort", "plyfile", "torchvision", "torchvision.transforms", "torchcodec",
+                "torchcodec.decoders", "pytheia"):
+        if mod not in sys.modules:
+            sys.modules[mod] = _Placeholder(mod)
+    sys.modules["torchvision"].transforms = sys.modules["torchvision.transforms"]
+    u3, u3t = types.ModuleType("utils3d"), types.ModuleType("utils3d.torch")
+
+    def intrinsics_from_focal_center(fx, fy, cx, cy):      # restated from utils/camera_estimation.py:56-57
+        K = torch.zeros(*fx.shape, 3, 3, dtype=fx.dtype)
+        K[..., 0, 0], K[..., 1, 1], K[..., 0, 2], K[..., 1, 2], K[..., 2, 2] = fx, fy, cx, cy, 1.0
+        return K
+
+    u3t.intrinsics_from_focal_center = intrinsics_from_focal_center
+    u3.torch = u3t
+    sys.modules["utils3d"], sys.modules["utils3d.torch"] = u3, u3t
+    os.environ.setdefault("TORCHDYNAMO_DISABLE", "1")
+    sys.path.insert(0, REF)
+    os.chdir(REF)
+    from pi3.models.pi3 import Pi3
+    from slam.offline_chunk_creator import OfflineChunkCreator, OfflineCreatorConfig
+    from utils.keypoint_extraction import create_keypoint_extractor
+
+    torch.nn.attention.sdpa_kernel = lambda *a, **k: contextlib.nullcontext()      # the one change (docstring)
+
+    model = Pi3().eval()
+    missing, unexpected = model.load_state_dict(recipe_state_dict_cpu(Pi3Config()), strict=False)
+    assert not unexpected and set(missing) <= {"image_mean", "image_std"}
+    cr = object.__new__(OfflineChunkCreator)
+    cr.config = OfflineCreatorConfig(model_path="unused", output_dir="/tmp/pi3_full_golden", chunk_length=N, overlap=20,
+                                     device="cpu", do_metric_depth=False, keypoint_type="grid",
+                                     max_num_keypoints=max_kp, estimate_camera_params=True)
+    cr.model, cr.moge_model, cr.undistortion_maps = model, None, None
+    cr.keypoint_extractor = create_keypoint_extractor(keypoint_type="grid", max_num_keypoints=max_kp,
+                                                      detection_threshold=0.005, device="cpu")
+    cr.target_size = (H, W)
+    imgs = golden_images(name, 1, N, H, W)
+
+    cap, dense = {}, {}
+
+    def keep(key):
+        return lambda m, a, o=None: cap.__setitem__(
+            key, (a[0] if o is None else o).detach().reshape(-1, (a[0] if o is None else o).shape[-1])[::ROWS].clone())
+
+    hooks = [
+        model.encoder.blocks[0].register_forward_pre_hook(keep("tokens")),
+        model.decoder[0].register_forward_pre_hook(keep("enc_out")),
+        model.decoder[0].register_forward_hook(keep("dec0")),
+        model.decoder[1].register_forward_hook(keep("dec1")),
+        model.point_decoder.register_forward_pre_hook(keep("dec_cat")),
+        model.point_decoder.register_forward_hook(keep("point_decoder")),
+        model.conf_decoder.register_forward_hook(keep("conf_decoder")),
+        model.camera_decoder.register_forward_hook(keep("camera_decoder")),
+        model.register_forward_hook(lambda m, a, o: dense.update({k: v.detach().clone() for k, v in o.items()})),
+    ]
+    t0 = time.time()
+    torch.manual_seed(SEED)
+    res = cr._process_single_chunk(imgs, [[f"frame_{i:03d}.png"] for i in range(N)])
+    for h in hooks:
+        h.remove()
+    print(f"{name}: reference _process_single_chunk {time.time() - t0:.1f}s (forward {res['_metrics']['infer_s']:.1f}s)",
+          flush=True)
+
+    save = {"shape": np.array([N, H, W, max_kp]), "strides": np.array([SUB, ROWS]), "seed": np.array([SEED])}
+    for k in ("points", "local_points", "conf", "camera_poses"):
+        save[k] = dense[k].numpy() if k == "camera_poses" else dense[k][:, :, ::SUB, ::SUB].contiguous().numpy()
+    for k, v in cap.items():
+        save["i_" + k] = v.numpy()
+    # the reference's dense masks of its fp32 run (offline_chunk_creator.py:114-119), same pixel stride
+    save["masks_dense"] = OfflineChunkCreator._compute_masks(dense)[0][:, ::SUB, ::SUB].contiguous().numpy()
+    schema = []
+    for k, v in res.items():
+        if torch.is_tensor(v):
+            schema.append(f"{k}:{str(v.dtype).replace('torch.', '')}:{'x'.join(str(d) for d in v.shape)}")
+            save["c_" + k] = v.view(torch.int16).numpy() if v.dtype == torch.float16 else v.numpy()
+        elif isinstance(v, dict) and k == "camera_params":
+            for kk, vv in v.items():
+                schema.append(f"camera_params.{kk}:{str(vv.dtype).replace('torch.', '')}:{'x'.join(str(d) for d in vv.shape)}")
+                save["c_camera_params." + kk] = vv.numpy()
+        else:
+            schema.append(f"{k}:{type(v).__name__}")
+    save["schema"] = np.array(sorted(schema))
+    print("\n".join(sorted(schema)))
+    print("mask fraction at keypoints", float(res["masks"].float().mean()), "K", res["keypoints"].shape[1], flush=True)
+    out_path = os.path.join(REPO, "tests", "golden", name + ".npz")
+    np.savez_compressed(out_path, **save)          # written now: the bf16 pass below only adds the anchors
+    print("wrote", out_path, os.path.getsize(out_path) / 2 ** 20, "MiB", flush=True)
+
+    if want_bf16:
+        orig_autocast = torch.amp.autocast
+
+        class _CpuAutocast(orig_autocast):      # honour the reference's autocast('cuda', enabled=False) regions on the CPU
+            def __init__(self, device_type, *a, **k):
+                super().__init__("cpu" if device_type == "cuda" else device_type, *a, **k)
+
+        torch.amp.autocast = _CpuAutocast
+        t0 = time.time()
+        try:
+            with torch.no_grad(), torch.autocast("cpu", dtype=torch.bfloat16):
+                ref16 = model(imgs)
+        finally:
+            torch.amp.autocast = orig_autocast
+        print(f"{name}: reference bf16-autocast forward {time.time() - t0:.1f}s", flush=True)
+        for k in ("points", "local_points", "conf", "camera_poses"):
+            d = (ref16[k].float() - dense[k]).abs()
+            save["bf16err_" + k] = np.array([d.mean().item(), d.max().item()], dtype=np.float64)
+            print(f"   {k:14s} reference bf16-autocast vs fp32: mean|d| {d.mean().item():.3e} max|d| {d.max().item():.3e}")
+        Ra, Rb = ref16["camera_poses"][0, :, :3, :3].double(), dense["camera_poses"][0, :, :3, :3].double()
+        tr = ((Ra @ Rb.transpose(-1, -2)).diagonal(dim1=-2, dim2=-1).sum(-1) - 1) / 2
+        save["bf16err_rot_deg"] = np.array([torch.rad2deg(torch.acos(tr.clamp(-1, 1))).max().item()])
+        print("   reference bf16 rotation error (deg):", save["bf16err_rot_deg"])
+        # masks of the reference's own bf16 run against its fp32 run: the anchor of the mask-flip gate
+        masks_of = OfflineChunkCreator._compute_masks      # offline_chunk_creator.py:114-119
+        flips = (masks_of({k: v.float() for k, v in ref16.items()}) != masks_of(dense)).float().mean().item()
+        save["bf16err_mask_flips"] = np.array([flips])
+        print("   reference bf16 dense-mask flips:", flips)
+        np.savez_compressed(out_path, **save)
+        print("wrote", out_path, os.path.getsize(out_path) / 2 ** 20, "MiB", flush=True)
+
+
+if __name__ == "__main__":
+    main()

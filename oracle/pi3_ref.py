@@ -49,6 +49,30 @@ def rope2d(tokens: torch.Tensor, positions: torch.Tensor, base: float = 100.0) -
     return torch.cat((y, x), dim=-1)
 
 
+def rope_2d_cpu(tokens, positions, base: float, fwd: float):
+    """`rope_2d_cpu` of pi3/models/curope/curope.cpp:11-47, the CPU branch of the reference's one native FFI entry,
+    restated in numpy fp32 with its operation order: tokens (B, N, H, D) fp32 modified IN PLACE, positions (B, N, 2)
+    integer (y, x); per token, axis x in (0, 1), d < D/4:  inv_freq = fwd * p / powf(base, d / float(D/4)),
+    (u, v) = tok[d + x*2Q], tok[d + Q + x*2Q]  ->  (u c - v s, v c + u s).  (The loop order of the C code - axis outside
+    the tokens - does not matter: every element is touched once.)"""
+    import numpy as np
+    tok = tokens.numpy() if isinstance(tokens, torch.Tensor) else tokens
+    pos = positions.numpy() if isinstance(positions, torch.Tensor) else positions
+    assert tok.dtype == np.float32 and tok.ndim == 4 and pos.ndim == 3 and pos.shape[2] == 2 and tok.shape[3] % 4 == 0
+    Q = tok.shape[3] // 4
+    d = np.arange(Q, dtype=np.float32)
+    pw = np.power(np.float32(base), d / np.float32(Q)).astype(np.float32)            # powf(base, d / float(D))
+    for x in range(2):
+        p = pos[:, :, x].astype(np.int32).astype(np.float32)                         # `const int p`, then fwd * p in float
+        ang = ((np.float32(fwd) * p)[:, :, None] / pw[None, None, :]).astype(np.float32)[:, :, None, :]   # (B, N, 1, Q)
+        c, s = np.cos(ang).astype(np.float32), np.sin(ang).astype(np.float32)
+        u = tok[..., x * 2 * Q: x * 2 * Q + Q].copy()
+        v = tok[..., x * 2 * Q + Q: x * 2 * Q + 2 * Q].copy()
+        tok[..., x * 2 * Q: x * 2 * Q + Q] = u * c - v * s
+        tok[..., x * 2 * Q + Q: x * 2 * Q + 2 * Q] = v * c + u * s
+    return tokens
+
+
 # bench.py's CPU baseline sets this: softmax(q k^T) v through torch's fused CPU kernel (flash) instead of materialising
 # the S x S scores - the "reference model + CPU flash SDPA" configuration of BASELINE.md §3.2 (max-abs-diff 1.8e-7 vs
 # the written-out form, which needs 16 S^2 floats and cannot run at 32+ frames).  Tests keep the written-out form.

@@ -116,6 +116,59 @@ def qknorm_rope(qkv: torch.Tensor, rows: int, H: int, T: int, pos: Optional[torc
     return qkv
 
 
+_ROPE_DT = {torch.bfloat16: 0, torch.float32: 1, torch.float16: 2}
+
+
+def rope_2d(tokens: torch.Tensor, positions: torch.Tensor, base: float, fwd: float) -> None:
+    """`curope.rope_2d(tokens, positions, base, fwd)` (pi3/models/curope/curope.cpp:49-68): IN PLACE on tokens
+    (B, N, H, D) - any outer strides, last two dims contiguous - with positions (B, N, 2) int64 = (y, x).  The argument
+    checks and their messages are the reference's TORCH_CHECKs (curope.cpp:54-59, kernels.cu:11-14, 91-94), raised as
+    RuntimeError like a failing TORCH_CHECK is."""
+    lib = _L.load()
+    if tokens.dim() != 4:
+        raise RuntimeError("tokens must have 4 dimensions")
+    if positions.dim() != 3:
+        raise RuntimeError("positions must have 3 dimensions")
+    if tokens.size(0) != positions.size(0):
+        raise RuntimeError("batch size differs between tokens & positions")
+    if tokens.size(1) != positions.size(1):
+        raise RuntimeError("seq_length differs between tokens & positions")
+    if positions.size(2) != 2:
+        raise RuntimeError("positions.shape[2] must be equal to 2")
+    if tokens.is_cuda != positions.is_cuda:
+        raise RuntimeError("tokens and positions are not on the same device")
+    if not tokens.is_cuda:
+        raise _L.Pi3HipError("pi3_rope_2d runs on the GPU only (the reference's rope_2d_cpu is restated in oracle/)")
+    B, N, H, D = tokens.shape
+    if tokens.stride(3) != 1 or tokens.stride(2) != D:
+        raise RuntimeError("tokens are not contiguous")
+    if not positions.is_contiguous():
+        raise RuntimeError("positions are not contiguous")
+    if D % 4 != 0:
+        raise RuntimeError("token dim must be multiple of 4")
+    if tokens.dtype not in _ROPE_DT or positions.dtype != torch.int64:
+        raise RuntimeError(f"rope_2d: unsupported dtypes {tokens.dtype} / {positions.dtype}")
+    rc = lib.pi3_rope_2d(tokens.data_ptr(), positions.data_ptr(), B, N, H, D, tokens.stride(0), tokens.stride(1),
+                         float(base), float(fwd), _ROPE_DT[tokens.dtype], _L.stream_ptr())
+    _L.check(rc, "pi3_rope_2d")
+
+
+class cuRoPE2D(torch.nn.Module):
+    """Drop-in for `models.curope.cuRoPE2D` (pi3/models/curope/curope2d.py:33-40; selected by pos_embed.py:104-106 when
+    the extension is importable): forward(tokens (B, heads, ntokens, dim), positions (B, ntokens, 2)) rotates `tokens` in
+    place through the transposed view and returns it.  Inference only (the reference's autograd wrapper calls the same
+    entry with fwd = -F0 for the backward pass; `rope_2d(..., -F0)` is available for that)."""
+
+    def __init__(self, freq: float = 100.0, F0: float = 1.0):
+        super().__init__()
+        self.base = freq
+        self.F0 = F0
+
+    def forward(self, tokens: torch.Tensor, positions: torch.Tensor) -> torch.Tensor:
+        rope_2d(tokens.transpose(1, 2), positions, self.base, self.F0)
+        return tokens
+
+
 def cast_rows(x: torch.Tensor, out: torch.Tensor, rows: Optional[int] = None, cols: Optional[int] = None,
               in_cols: Optional[int] = None):
     """out[r, :cols] = x[r, :cols]; with in_cols < cols only x[r, :in_cols] is read and out[r, in_cols:cols] = 0."""

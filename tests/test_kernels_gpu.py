@@ -208,6 +208,59 @@ def test_qknorm_rope_matches_fp32_reference(dev):
         assert torch.equal(qkv.view(rows, 3, H, 64)[:, 2], qkv0.view(rows, 3, H, 64)[:, 2])     # v untouched
 
 
+@pytest.mark.parametrize("tag", ["d64", "d32"])
+def test_rope_2d_ffi_entry_against_the_reference_vectors(dev, tag):
+    """pi3_rope_2d = the reference's `curope.rope_2d(tokens, positions, base, fwd)` contract (curope.cpp:49-68): in place
+    on (B, N, H, D) with free outer strides, int64 positions.  Against tests/golden/rope2d.npz (the reference's own torch
+    RoPE2D, oracle/gen_golden_rope.py) and the restated CPU branch `rope_2d_cpu`: fp32 storage to 2e-5 absolute (angles
+    up to 29 rad evaluated in fp32: the reference's two implementations differ by 1e-5 among themselves); bf16 / f16
+    storage to one rounding of the stored type; fwd = -F0 is the inverse; through the `cuRoPE2D` module (transposed
+    view of a (B, heads, N, D) tensor) and on q / k slices of a packed qkv buffer; the reference's argument errors."""
+    import os
+    from conftest import GOLDEN
+    from oracle import pi3_ref
+    from pi3_slam_amd import lib, ops
+    g = np.load(os.path.join(GOLDEN, "rope2d.npz"))
+    tok, pos, want = (torch.from_numpy(g[tag + k]) for k in ("_tokens", "_positions", "_out"))
+    B, Hh, N, D = tok.shape
+    posd = pos.to(dev)
+    # (1) module form, fp32
+    t = tok.to(dev).clone()
+    out = ops.cuRoPE2D(freq=100.0, F0=1.0)(t, posd)
+    assert out.data_ptr() == t.data_ptr()                                    # in place, returns its argument
+    assert (out.cpu() - want).abs().max().item() < 2e-5
+    cpu = np.ascontiguousarray(tok.numpy().transpose(0, 2, 1, 3)).copy()
+    pi3_ref.rope_2d_cpu(cpu, pos.numpy(), 100.0, 1.0)
+    assert (out.cpu().numpy().transpose(0, 2, 1, 3) - cpu).max() < 2e-5
+    # (2) inverse rotation restores the input
+    ops.rope_2d(t.transpose(1, 2), posd, 100.0, -1.0)
+    assert (t.cpu() - tok).abs().max().item() < 2e-5
+    # (3) 16-bit storage: fp32 arithmetic on the stored values, one rounding on the way out
+    for dt, ulp in ((torch.bfloat16, 2.0 ** -8), (torch.float16, 2.0 ** -11)):
+        t16 = tok.to(dt).to(dev)
+        ref = pi3_ref.rope2d(t16.float().cpu(), pos)
+        ops.cuRoPE2D()(t16, posd)
+        err = (t16.float().cpu() - ref).abs()
+        assert (err <= ulp * ref.abs().clamp_min(2.0 ** -14) * 1.01 + 2e-5).all(), (dt, err.max().item())
+    # (4) q and k inside a packed (B, N, 3, H, D) qkv buffer (what FlashAttentionRope hands to the module, attention.py:325-334)
+    qkv = torch.randn(B, N, 3, Hh, D, device=dev)
+    q, k, v = [qkv.transpose(1, 3)[:, :, i] for i in range(3)]              # (B, H, N, D) views
+    ref_q, ref_k, v0 = pi3_ref.rope2d(q.cpu(), pos), pi3_ref.rope2d(k.cpu(), pos), v.clone()
+    rope = ops.cuRoPE2D()
+    rope(q, posd), rope(k, posd)
+    assert (q.cpu() - ref_q).abs().max() < 3e-5 and (k.cpu() - ref_k).abs().max() < 3e-5 and torch.equal(v, v0)
+    # (5) the reference's TORCH_CHECKs
+    for bad, msg in ((lambda: ops.rope_2d(t[0], posd, 100.0, 1.0), "tokens must have 4 dimensions"),
+                     (lambda: ops.rope_2d(t.transpose(1, 2), posd[:, :-1], 100.0, 1.0), "seq_length differs"),
+                     (lambda: ops.rope_2d(t.transpose(1, 2), posd[..., :1], 100.0, 1.0), "positions.shape[2]"),
+                     (lambda: ops.rope_2d(t, posd[:, :Hh], 100.0, 1.0), "tokens are not contiguous"),
+                     (lambda: ops.rope_2d(t.transpose(1, 2)[..., :D - 2].contiguous(), posd, 100.0, 1.0), "multiple of 4")):
+        with pytest.raises(RuntimeError, match=msg.replace("[", r"\[").replace("]", r"\]")):
+            bad()
+    assert lib.load().pi3_rope_2d(None, None, 1, 1, 1, 6, 0, 0, 100.0, 1.0, 1, None) == -1      # C-ABI level: PI3_ERR_ARG
+    torch.cuda.synchronize()
+
+
 @pytest.mark.parametrize("use_norm,use_rope", [(True, True), (False, True), (True, False)])
 def test_fused_qkv_epilogue_matches_fp32_reference_and_two_pass_form(dev, use_norm, use_rope):
     """pi3_gemm_qkv on the 256x256 kernel (q/k LayerNorm(64) + RoPE-2D + scale + max|k|^2 fused into the projection's

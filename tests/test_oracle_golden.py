@@ -258,3 +258,21 @@ def test_sim3_closed_forms_on_collinear_points():
         assert abs(np.linalg.det(R) - 1.0) < 1e-9 and np.abs(R @ R.T - np.eye(3)).max() < 1e-9
         assert abs(s - 0.8) < 1e-9
         np.testing.assert_allclose(s * x @ R.T + t, y, atol=1e-9)
+
+
+@pytest.mark.parametrize("tag", ["d64", "d32"])
+def test_rope_2d_cpu_restatement_matches_the_reference_rope2d_class(tag):
+    """`oracle.pi3_ref.rope_2d_cpu` restates the CPU branch of the reference's native FFI entry (curope.cpp:11-47);
+    tests/golden/rope2d.npz holds what the reference's OWN torch `RoPE2D` (pos_embed.py:112-159, the class it runs when
+    the extension is absent) returns on the same tokens (oracle/gen_golden_rope.py).  SURVEY §8 a5: the two agree to
+    1e-5; so does the oracle's table form `rope2d`, and fwd = -1 undoes fwd = +1 (curope2d.py:24-29)."""
+    g = np.load(os.path.join(GOLDEN, "rope2d.npz"))
+    tok, pos, want = g[tag + "_tokens"], g[tag + "_positions"], g[tag + "_out"]            # tokens (B, heads, N, D)
+    got = np.ascontiguousarray(tok.transpose(0, 2, 1, 3)).copy()                              # the FFI layout (B, N, H, D)
+    pi3_ref.rope_2d_cpu(got, pos, 100.0, 1.0)
+    np.testing.assert_allclose(got.transpose(0, 2, 1, 3), want, rtol=0, atol=1e-5)
+    np.testing.assert_allclose(pi3_ref.rope2d(torch.from_numpy(tok), torch.from_numpy(pos)).numpy(), want, rtol=0, atol=1e-5)
+    pi3_ref.rope_2d_cpu(got, pos, 100.0, -1.0)
+    np.testing.assert_allclose(got.transpose(0, 2, 1, 3), tok, rtol=0, atol=1e-5)
+    # position 0 (pi3's special tokens) is the identity
+    assert np.array_equal(want[0, :, 0], tok[0, :, 0])

@@ -75,6 +75,13 @@ int pi3_attention(const void* q, const void* k, const void* v, long tok_stride, 
                   long o_tok_stride, long o_batch_stride, int B, int S, int H, int head_dim, float* k2max_ws,
                   int k2max_ready, void* stream);
 
+/* Diagnostic of pi3_attention's long-sequence kernel: which softmax loop its waves took.  counters: caller-owned DEVICE
+ * memory of 128 uint32, zeroed by the caller, laid out [kind][path][32 slots] (sum the slots): kind 0 = eight-wave
+ * workgroups (global attention), 1 = four-/two-wave workgroups (frame-wise attention); path 0 = bounded-score loop,
+ * 1 = online-max loop.  One no-return atomic per wave while registered; NULL (the default) switches it off.
+ * Process-wide; change it only while no attention launch is in flight.  bench.py reports the fractions with it. */
+int pi3_attention_path_counters(unsigned int* counters);
+
 /* nn.LayerNorm(D, eps) over rows of x (block.py:282,296; vision_transformer.py:271).  If nspecial > 0 (f32 out only),
  * rows with (row % T) < nspecial are replaced by special[row % T][:]: Pi3.decode's register-token concat
  * (pi3/models/pi3.py:140-144). */

@@ -62,8 +62,8 @@ Knob* knob_slot(const char* name) {
       for (const char* c = name; *c && i + 1 < sizeof(env); ++c, ++i) env[i] = (*c >= 'a' && *c <= 'z') ? *c - 32 : *c;
       env[i] = 0;
       const char* e = getenv(env);
-      k.value = e ? atol(e) : 0;         // value before state: a lock-free reader (PI3_KNOB) tests the state first
-      k.state = e ? 2 : 1;
+      k.value = e ? atol(e) : 0;         // value, then state with release order: a lock-free reader (PI3_KNOB)
+      __atomic_store_n(&k.state, e ? 2 : 1, __ATOMIC_RELEASE);   // acquires the state before it reads the value
       return &k;
     }
   }
@@ -94,7 +94,7 @@ extern "C" int pi3_set_knob(const char* name, long value) {
     return PI3_ERR_ARG;
   }
   k->value = value;
-  k->state = 2;
+  __atomic_store_n(&k->state, 2, __ATOMIC_RELEASE);
   return PI3_OK;
 }
 

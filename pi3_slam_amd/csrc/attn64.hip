@@ -52,6 +52,7 @@ struct Attn64Params {
   int prio;             // 1: waves NW/2 .. NW-1 (the later-dispatched wave of every SIMD) run at s_setprio 1 (A/B knob)
   int tailopt;          // 1: short-sequence waves skip query blocks / key halves that do not exist (A/B knob, default 1)
   unsigned long long* dbg;   // -DPI3_ATTN_STAMPS builds only: s_memtime stamps of workgroup 0
+  unsigned* stats;      // optional caller-owned path counters (pi3_attention_path_counters), else null
 };
 #ifndef A64_ABL   // development builds only (-DA64_ABL=n, a separate .so): timing ablations with WRONG results.
 #define A64_ABL 0   // 1 no exp, 3 no P.V MFMAs, 4 no Q.K^T MFMAs, 5 no barrier / DMA wait, 6 no row-sum MFMAs, 7 one LDS fragment reused
@@ -472,6 +473,10 @@ __global__ __launch_bounds__(NW * 64, (NW == 2 ? 4 : 2)) void attn_fwd64_kernel(
 #ifdef PI3_ATTN_STAMPS
   if (st_on) st[3] = a64_realtime();
 #endif
+  // which softmax loop this wave ran (diagnostic, off unless the caller registered a counter block): one no-return
+  // atomic per wave after its stores, spread over 32 slots so that same-address atomics do not queue up in L2
+  if (p.stats && lane == 0 && nb > 0)
+    atomicAdd(p.stats + (NW == 8 ? 0 : 64) + (fast ? 0 : 32) + (blockIdx.x & 31), 1u);
 }
 
 // max over keys of |k|^2 per (batch, head) for the bounded-score test; out must be zeroed (non-negative floats order
@@ -529,6 +534,18 @@ int pi3_attention_knorm_launch(const void* k, long tok_stride, long batch_stride
 
 int pi3_attention64p_launch(const Attn64Params& p, long nwg, hipStream_t stream);   // attn64p.hip: software-pipelined form
 
+// Diagnostic: counters of the softmax loop each wave of the 64-row kernel took.  counters = caller-owned DEVICE memory of
+// 128 uint32, zeroed by the caller: [kind][path][32 slots], kind 0 = eight-wave workgroups (the long / global sequences),
+// 1 = four- and two-wave workgroups (frame-wise sequences); path 0 = bounded-score loop (no running max), 1 = online-max
+// loop.  Sum the 32 slots.  NULL switches it off (the default).  Process-wide; set it while no attention launch is in
+// flight.  The pointer is read at launch time (a captured hipGraph keeps the value it was captured with).
+static unsigned* g_attn_stats = nullptr;
+extern "C" int pi3_attention_path_counters(unsigned int* counters) {
+  g_attn_stats = counters;
+  return PI3_OK;
+}
+
+
 // Called by pi3_attention (attn.hip); same argument meaning, plus nw_req (0: the knob's choice, 4: four-wave workgroups).
 // k2max_ws: caller-provided [B*H] floats (or null -> online-max loop); k2max_ready: already filled by the producer.
 int pi3_attention64_launch(const void* q, const void* k, const void* v, long tok_stride, long batch_stride, void* o,
@@ -556,13 +573,12 @@ int pi3_attention64_launch(const void* q, const void* k, const void* v, long tok
     const char* e = getenv("PI3_ATTN_GLDS");
     glds = e ? atoi(e) : 1;
   }
-  static int nomax = -1;   // PI3_ATTN_NOMAX: 0 = always online max (A/B knob, and how the tests reach that loop)
-  if (nomax < 0) {
-    const char* e = getenv("PI3_ATTN_NOMAX");
-    nomax = e ? atoi(e) : 1;
-  }
+  // knob attn_nomax (PI3_ATTN_NOMAX): 0 = always the online-max loop (A/B knob, how the tests reach that loop, and the
+  // worst case bench.py reports beside the headline: real weights may not keep |q| max|k| inside the bound)
+  const int nomax = (int)PI3_KNOB("attn_nomax", 1);
   p.k2max = nullptr;
   p.dbg = nullptr;
+  p.stats = g_attn_stats;
   static int prio = -1;   // PI3_ATTN_PRIO: 1 = static s_setprio 1 for the second half of a workgroup's waves (A/B knob)
   if (prio < 0) {
     const char* e = getenv("PI3_ATTN_PRIO");

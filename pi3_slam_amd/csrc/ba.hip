@@ -1258,7 +1258,7 @@ extern "C" long pi3_ba_workspace_doubles(int N, int K) {
   const long n6 = 6L * N, nk = (long)N * K;
   return 16 /*state*/ + 6 * nk + 3 * nk + 3 * nk /*pts_new*/ + 12L * N /*poses_new*/ + 21L * N + 6L * N /*gc*/ +
          6L * N /*dcam*/ + 6L * N /*Dcam*/ + BA_SLICES * n6 * n6 + BA_SLICES * n6 + 2 * n6 * n6 + 18 * nk * N + (nk * N + 7) / 8 + 3L * ba_nblk(N, K) +
-         3L * N + 64 + nk /*inverse depth: rho_new*/ + 36L * N * N /*cross blocks*/ + 6 * nk /*damped point inverses*/ + 18 * nk * N /*Y = E Cinv*/ + 256 /*tile reads past the last track*/;
+         3L * N + 64 + nk /*inverse depth: rho_new*/ + 36L * N * N /*cross blocks*/ + 6 * nk /*damped point inverses*/ + 18 * nk * N /*Y = E Cinv*/ + 256 /*tile reads past the last track of Y*/ + 144 /*the same past Eblk*/;
 }
 
 static int ba_run(double* points, double* poses, const double* intr, const float* uv, const unsigned char* valid,
@@ -1293,7 +1293,7 @@ static int ba_run(double* points, double* poses, const double* intr, const float
   double* rhs_part = w; w += BA_SLICES * n6;
   double* S = w; w += n6 * n6;
   double* Lfac = w; w += n6 * n6;
-  double* Eblk = w; w += 18 * nk * N;
+  double* Eblk = w; w += 18 * nk * N + 144;   // ba_schur_tiles prefetches up to 126 doubles past the last track's run
   uint8_t* obs_ok = (uint8_t*)w; w += (nk * N + 7) / 8;
   double* cost_part = w; w += nblk;
   double* model_part = w; w += nblk;
@@ -1320,7 +1320,7 @@ static int ba_run(double* points, double* poses, const double* intr, const float
   }
   // the tile kernel writes the lower-triangle tiles only; the rest of S_part is read by ba_assemble_cameras and never
   // used by the factorisation: defined once
-  if (!schur_rows && hipMemsetAsync(S_part, 0, sizeof(double) * BA_SLICES * n6 * n6, st) != hipSuccess) {
+  if (!schur_rows && hipMemsetAsync(S_part, 0, sizeof(double) * nsl * n6 * n6, st) != hipSuccess) {   // only nsl are read
     pi3_set_error("pi3_bundle_adjust: hipMemsetAsync failed");
     return PI3_ERR_LAUNCH;
   }

@@ -32,13 +32,14 @@ int pi3_check_launch(const char* what);
 // Returns PI3_OK or PI3_ERR_LAUNCH with the runtime's message in pi3_last_error().
 // run-time A/B knob (api.hip): pi3_set_knob value, else env PI3_<NAME>, else dflt.  Slots live in a static table, so a
 // launch path resolves the name once (PI3_KNOB: a function-local static pointer) and then reads two words per launch.
-struct Pi3Knob { char name[32]; volatile long value; volatile int state; };   // state 0 free, 1 unset, 2 has a value
+struct Pi3Knob { char name[32]; long value; int state; };   // state 0 free, 1 unset, 2 has a value (release / acquire)
 const Pi3Knob* pi3_knob_slot(const char* name);
 long pi3_knob(const char* name, long dflt);
 #define PI3_KNOB(NAME, DFLT)                                                     \
   ([]() -> long {                                                                \
     static const Pi3Knob* k_ = pi3_knob_slot(NAME);                              \
-    return (k_ && k_->state == 2) ? k_->value : (long)(DFLT);                    \
+    return (k_ && __atomic_load_n(&k_->state, __ATOMIC_ACQUIRE) == 2)            \
+               ? __atomic_load_n(&k_->value, __ATOMIC_RELAXED) : (long)(DFLT);   \
   }())
 int pi3_lds_optin(const void* kern, int bytes, unsigned long long* done_mask, const char* what);
 
@@ -87,7 +88,9 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 // 8 FMAs + one v_exp_f32 + max + fma: no v_rcp, and the FMAs pack (v_pk_fma_f32) - 9.5 issue slots per element where
 // the Abramowitz-Stegun form below takes 14.5; the fc1 epilogue runs with the matrix pipe idle, so VALU issue is its
 // critical path.  Beyond t = 5 the polynomial keeps falling (leading coefficient < 0; checked to t = 40,
-// then -inf), so q -> 0 and y -> relu(x) with no clamp; NaN in -> NaN out; +inf -> NaN (inf * 0), the erf form gives inf.
+// then -inf), so q -> 0 and y -> relu(x) with no clamp; NaN in -> NaN out; |x| is clamped to 40 inside the product
+// |x| q only (q = 0 there already), so that +-inf - an overflowed fc1 accumulator - gives relu(x) = +inf / 0 like the erf
+// form and torch instead of inf * 0 = NaN (one v_pk_min_f32 per pair).
 // Accuracy (tools/dev_gelu.py, 1e7 samples, bf16(y) against bf16 of the fp64 truth x Phi(x)): 9.6e-5 of N(0, 1) samples
 // differ (torch's own fp32 gelu: 9.3e-5 - the floor set by fp32 rounding), 1.1e-3 of N(0, 2) samples (torch fp32: 1.8e-2,
 // the A-S form: 1.4e-2); against bf16(torch fp32 gelu) on N(0, 1): 1.8e-4 (A-S form 1.3e-4), i.e. 99.98 % identical.
@@ -110,7 +113,8 @@ __device__ __forceinline__ f32x2 gelu_erf2(f32x2 x) {
   q[1] = __builtin_amdgcn_exp2f(p[1]);
   r[0] = fmaxf(x[0], 0.0f);
   r[1] = fmaxf(x[1], 0.0f);
-  return __builtin_elementwise_fma(t, -q, r);        // the negation folds into the instruction's neg modifiers
+  const f32x2 tc = __builtin_elementwise_min(t, (f32x2)(40.0f));   // inf * 0 guard; the Horner chain keeps the true |x|
+  return __builtin_elementwise_fma(tc, -q, r);       // the negation folds into the instruction's neg modifiers
 }
 __device__ __forceinline__ f32x4 gelu_erf4(f32x4 v) {
   const f32x2 a = gelu_erf2((f32x2){v[0], v[1]}), b = gelu_erf2((f32x2){v[2], v[3]});
@@ -128,7 +132,7 @@ __device__ __forceinline__ float gelu_erf(float x) {
   p = fmaf(p, t, -1.151171446e+00f);
   p = fmaf(p, t, -9.999981523e-01f);
   const float q = __builtin_amdgcn_exp2f(p);
-  return fmaf(-t, q, fmaxf(x, 0.0f));
+  return fmaf(-fminf(t, 40.0f), q, fmaxf(x, 0.0f));
 }
 
 // The round 1-3 form (Abramowitz-Stegun 7.1.26, |abs error of erf| <= 1.5e-7; one v_rcp, one v_exp and 11 regular vector

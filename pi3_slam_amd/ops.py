@@ -91,6 +91,16 @@ def attention(qkv: torch.Tensor, out: torch.Tensor, B: int, S: int, H: int,
     return out
 
 
+def attention_path_counters(counters: Optional[torch.Tensor]) -> None:
+    """Register (or, with None, remove) the diagnostic counter block of pi3_attention's 64-row kernel: int32 [2, 2, 32]
+    on the device, zeroed by the caller = [eight-wave (global) | four-wave (frame-wise)] x [bounded-score loop |
+    online-max loop] x 32 slots; `counters.sum(-1)` are waves.  Synchronise before changing it."""
+    lib = _L.load()
+    if counters is not None:
+        assert counters.is_cuda and counters.dtype == torch.int32 and counters.numel() == 128 and counters.is_contiguous()
+    _L.check(lib.pi3_attention_path_counters(_L.ptr(counters)), "pi3_attention_path_counters")
+
+
 def layernorm(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, out: torch.Tensor, eps: float = 1e-6, *,
               rows: Optional[int] = None, T: int = 0, nspecial: int = 0,
               special: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -567,13 +577,14 @@ def bundle_adjust(points: torch.Tensor, poses: torch.Tensor, intr: torch.Tensor,
     if prior_flag is not None:
         assert prior_flag.dtype == torch.uint8 and prior_R.dtype == torch.float64 and prior_C.dtype == torch.float64
         prior_R, prior_C, prior_flag = prior_R.contiguous(), prior_C.contiguous(), prior_flag.contiguous()
-    fn = (lib.pi3_bundle_adjust_inverse_depth if inverse_depth else
-          lib.pi3_bundle_adjust_homogeneous if homogeneous else lib.pi3_bundle_adjust)
+    fn, fn_name = ((lib.pi3_bundle_adjust_inverse_depth, "pi3_bundle_adjust_inverse_depth") if inverse_depth else
+                   (lib.pi3_bundle_adjust_homogeneous, "pi3_bundle_adjust_homogeneous") if homogeneous else
+                   (lib.pi3_bundle_adjust, "pi3_bundle_adjust"))
     rc = fn(points.data_ptr(), poses.data_ptr(), intr.data_ptr(), uv.data_ptr(), valid.data_ptr(),
             uvT.data_ptr(), validT.data_ptr(), N, K, float(huber_width), int(max_iters),
             _L.ptr(prior_R), _L.ptr(prior_C), _L.ptr(prior_flag), float(sqrt_info_rot),
             float(sqrt_info_pos), summary.data_ptr(), ws.data_ptr(), n_ws, _L.stream_ptr())
-    _L.check(rc, "pi3_bundle_adjust_homogeneous" if homogeneous else "pi3_bundle_adjust")
+    _L.check(rc, fn_name)
     return summary
 
 
@@ -611,7 +622,7 @@ def _guarded(fn):
 
 
 for _name, _fn in list(globals().items()):
-    if callable(_fn) and getattr(_fn, "__module__", None) == __name__ and not _name.startswith("_") \
-            and _fn.__code__.co_flags is not None and _name not in ("undistort_maps",):
+    if isinstance(_fn, type(_guarded)) and getattr(_fn, "__module__", None) == __name__ and not _name.startswith("_") \
+            and _name not in ("undistort_maps",):          # plain functions only (cuRoPE2D is a module class)
         globals()[_name] = _guarded(_fn)
 del _name, _fn

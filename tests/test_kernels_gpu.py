@@ -45,6 +45,23 @@ def test_gemm_bf16_epilogues(dev, M, N, K):
     assert rel(out, ref2)[0] < 6e-3
 
 
+@pytest.mark.parametrize("M,N,K", [(300, 256, 128), (2048, 4096, 1024)])
+def test_gelu_epilogue_of_an_overflowed_accumulator(dev, M, N, K):
+    """nn.GELU of +inf is +inf, of -inf the limit 0 (mlp.py:36); the shipped form relu(x) - |x| exp2(P8(|x|)) must not
+    turn an overflowed fc1 accumulator into NaN (inf * 0).  Both GEMM families (small-shape kernel, 256 x 256 kernel);
+    huge finite pre-activations give relu(x) exactly."""
+    from pi3_slam_amd import ops
+    a = torch.randn(M, K, device=dev).bfloat16()
+    w = (torch.randn(N, K, device=dev) / math.sqrt(K)).bfloat16()
+    bias = torch.zeros(N, device=dev)
+    bias[0], bias[1], bias[2], bias[3] = float("inf"), float("-inf"), 3e38, -3e38
+    out = torch.empty(M, N, device=dev, dtype=torch.bfloat16)       # fc1's output type (the only GELU instance built)
+    ops.gemm(a, w, out, bias=bias, act=ops.ACT_GELU)
+    o = out.float()
+    assert torch.isposinf(o[:, 0]).all() and (o[:, 1] == 0).all(), o[0, :4]
+    assert (o[:, 2] > 2.9e38).all() and (o[:, 3] == 0).all() and torch.isfinite(o[:, 4:]).all()
+
+
 @pytest.mark.parametrize("M,N,K", [(300, 256, 128), (777, 640, 1024), (5, 128, 32)])
 def test_gemm_f32_exact_mfma(dev, M, N, K):
     from pi3_slam_amd import ops
@@ -485,13 +502,34 @@ def test_attention_bounded_score_and_online_max_paths(dev):
     qkv[101, H * 64 + 64: H * 64 + 128] = -q700 * (70.0 / (q700 @ q700))
     qkv = qkv.bfloat16()
     out = torch.empty(B * S, H * 64, device=dev, dtype=torch.bfloat16)
-    ops.attention(qkv, out, B, S, H)
-    ref = attn_ref(qkv, B, S, H)
-    mx, mean = rel(out, ref)
-    assert mx < 8e-3 and mean < 5e-3
-    assert (out.float()[700, 64:] - ref[700, 64:]).abs().max() < 2e-2      # row dominated by the 2^70 term
-    assert (out.float()[:64, :64] - ref[:64, :64]).abs().max() < 2e-2
-    assert torch.isfinite(out.float()).all()
+    counters = torch.zeros(2, 2, 32, device=dev, dtype=torch.int32)      # pi3_attention_path_counters (what bench.py reports)
+    ops.attention_path_counters(counters)
+    try:
+        ops.attention(qkv, out, B, S, H)
+        torch.cuda.synchronize()
+        waves = counters.sum(-1).cpu()
+        assert waves[0].sum().item() == 9 * 8 * H and waves[1].sum().item() == 0     # 9 workgroups x 8 waves per head
+        assert waves[0, 1].item() == 1                                                 # head 0's first wave: online max
+        ref = attn_ref(qkv, B, S, H)
+        mx, mean = rel(out, ref)
+        assert mx < 8e-3 and mean < 5e-3
+        assert (out.float()[700, 64:] - ref[700, 64:]).abs().max() < 2e-2      # row dominated by the 2^70 term
+        assert (out.float()[:64, :64] - ref[:64, :64]).abs().max() < 2e-2
+        assert torch.isfinite(out.float()).all()
+        # knob attn_nomax = 0: every wave on the online-max loop, the same softmax
+        from pi3_slam_amd import lib
+        counters.zero_()
+        out2 = torch.empty_like(out)
+        lib.set_knob("attn_nomax", 0)
+        ops.attention(qkv, out2, B, S, H)
+        torch.cuda.synchronize()
+        assert counters.sum(-1)[0].tolist() == [0, 9 * 8 * H]
+        assert rel(out2, ref)[0] < 8e-3 and rel(out2, out)[0] < 8e-3
+    finally:
+        from pi3_slam_amd import lib
+        lib.set_knob("attn_nomax", 1)
+        torch.cuda.synchronize()
+        ops.attention_path_counters(None)
 
 
 @pytest.mark.parametrize("M,N,K,reps", [(5000, 256, 4096, 40), (2049, 1024, 1024, 40), (1024, 256, 64, 60), (33000, 512, 192, 20)])

@@ -12,7 +12,8 @@
  *     (0 = default stream); calls are asynchronous and re-entrant per stream;
  *   - return 0 on success, negative on error (PI3_ERR_*); pi3_last_error() returns the thread-local message;
  *   - row-major tensors; `ld*` / strides are in ELEMENTS; bf16 = 16-bit brain float, f16 = IEEE half;
- *   - dtype codes: 0 = bf16, 1 = f32.
+ *   - dtype codes: 0 = bf16, 1 = f32, 2 = f16 (IEEE half: the MoGe path, which the reference runs under fp16
+ *     autocast; entries that take it say so).
  */
 #ifndef PI3SLAM_HIP_H
 #define PI3SLAM_HIP_H
@@ -27,7 +28,7 @@ extern "C" {
 #define PI3_ERR_WORKSPACE (-3)
 
 const char* pi3_last_error(void);
-int pi3_abi_version(void);   /* 5 */
+int pi3_abi_version(void);   /* 6 */
 
 /* Run-time A/B knob (speed only: every value selects a correct variant).  Names are the lower-case forms of the
  * PI3_* environment knobs that are read through it (gelu_form, gemm_4w, gemm_ilv, gemm_stagger_ns, gemm_rpref,
@@ -43,8 +44,8 @@ int pi3_device_count(void);
  *   out[orow(m)][n] = resid[orow(m)][n] + gamma[n] * act((A[m] . W[n] + bias[n]) * (n < qcols ? qscale : 1))
  *                     + addtab[m % rpg][n]
  *   orow(m) = rpg ? (m / rpg) * gstride + goff + m % rpg : m.   bias/gamma/resid/addtab may be NULL.
- * A [M][K] and W [N][K] share in_dtype (0: bf16 MFMA, 1: exact-fp32 MFMA); N % 128 == 0, or with bf16 operands any
- * N % 32 == 0 (32 / 64-column tiles: the narrow maps of the MoGe pyramid); K % 64 (bf16) / 32 (f32).
+ * A [M][K] and W [N][K] share in_dtype (0: bf16 MFMA, 1: exact-fp32 MFMA, 2: f16 MFMA - then out_dtype is 2 or 1);
+ * N % 128 == 0, or with 16-bit operands any N % 32 == 0 (32 / 64-column tiles: the narrow maps of the MoGe pyramid); K % 64 (bf16) / 32 (f32).
  * act: 0 none, 1 GELU(erf), 2 ReLU. */
 int pi3_gemm(const void* A, long lda, const void* W, long ldw, int M, int N, int K, int in_dtype, const float* bias,
              const float* gamma, const float* resid, long ldr, void* out, long ldo, int out_dtype, int act, int rpg,
@@ -70,9 +71,11 @@ int pi3_gemm_qkv(const void* A, long lda, const void* W, long ldw, int M, int K,
  * NULL.  With it the long-sequence kernel takes its bounded-score path (no running max) for every wave whose scores
  * are provably inside the fp32/bf16 exponent range, otherwise - and always when NULL - the online-max loop; both are
  * exact.  k2max_ready = 0: the call zeroes the workspace and fills it with a pre-pass over k; 1: the workspace already
- * holds the maxima (written by pi3_gemm's fused q/k epilogue, see pi3_gemm_qkv). */
+ * holds the maxima (written by pi3_gemm's fused q/k epilogue, see pi3_gemm_qkv).
+ * dtype: 0 = q/k/v/o bf16 (pi3), 2 = IEEE half (MoGe: the reference runs it under fp16 autocast, moge/model/v2.py:228):
+ * the same kernel on v_mfma_f32_32x32x16_f16, online-max loop only (half has 5 exponent bits), k2max_ws unused. */
 int pi3_attention(const void* q, const void* k, const void* v, long tok_stride, long batch_stride, void* o,
-                  long o_tok_stride, long o_batch_stride, int B, int S, int H, int head_dim, float* k2max_ws,
+                  long o_tok_stride, long o_batch_stride, int B, int S, int H, int head_dim, int dtype, float* k2max_ws,
                   int k2max_ready, void* stream);
 
 /* Diagnostic of pi3_attention's long-sequence kernel: which softmax loop its waves took.  counters: caller-owned DEVICE
@@ -117,8 +120,9 @@ int pi3_cast_rows_pad(const float* in, long ldi, int in_cols, void* out, long ld
                       void* stream);
 
 /* frames f32 [F][3][H][W] -> ImageNet-normalised (pi3.py:174) bf16 patch rows [F*P][KP], column c*196 + ky*14 + kx,
- * zero padded to KP: the im2col of PatchEmbed's Conv2d (patch_embed.py:65,75).  mean3/std3 are HOST arrays. */
-int pi3_patch_gather(const float* img, int F, int H, int W, void* out, int KP, const float* mean3_host,
+ * zero padded to KP: the im2col of PatchEmbed's Conv2d (patch_embed.py:65,75).  mean3/std3 are HOST arrays.
+ * out_dtype: 0 bf16, 2 f16. */
+int pi3_patch_gather(const float* img, int F, int H, int W, void* out, int KP, int out_dtype, const float* mean3_host,
                      const float* std3_host, void* stream);
 
 /* dst[oy][ox][:] = sum_ij wy[oy][i] wx[ox][j] src[i][j][:]: bicubic-antialias resample of pos_embed
@@ -184,9 +188,10 @@ int pi3_focal_shift(const float* local_points, const float* conf, const unsigned
 /* nn.Conv2d(C, N, 3, padding=1, padding_mode='replicate') as an implicit GEMM on a bf16 NHWC image [B][H][W][ldc];
  * out rows = pixels; epilogue bias / resid / act; N % 32 == 0.
  *   C % 64 == 0: wgt bf16 [N][9*C], k = (ky*3+kx)*C + ci;
- *   C == 32:     wgt bf16 [N][10*32], k = tap*32 + ci with a tenth, all-zero tap (two taps per 64-wide K-step). */
+ *   C == 32:     wgt bf16 [N][10*32], k = tap*32 + ci with a tenth, all-zero tap (two taps per 64-wide K-step).
+ * in_dtype: 0 = image and weights bf16, 2 = IEEE half; out_dtype: 1 = f32, or the image's 16-bit type. */
 int pi3_conv3x3(const void* img, long ldc, int B, int H, int W, int C, const void* wgt, int N, const float* bias,
-                const float* resid, long ldr, void* out, long ldo, int out_dtype, int act, void* stream);
+                const float* resid, long ldr, void* out, long ldo, int in_dtype, int out_dtype, int act, void* stream);
 
 /* nn.GroupNorm(G, C) statistics of x f32 [B][HW][ldx] -> stats f64 [B][G][2] (sum, sum of squares).  Deterministic
  * two-pass reduction (no floating-point atomics) through the caller's workspace ws of at least
@@ -198,17 +203,18 @@ int pi3_groupnorm_stats(const float* x, long ldx, int B, int HW, int C, int G, d
 /* Norm + activation in front of a ResidualConvBlock convolution (moge/model/modules.py:47-58) -> bf16 NHWC staging
  * image [B][HW][ldo], channels [C, Cpad) zeroed (Cpad % 4 == 0, ldo % 4 == 0).  G groups (GroupNorm(C/32), 'layer_norm' = 1 group, InstanceNorm2d =
  * C groups with gamma = beta = NULL); G = 0: no normalisation ('none').  act: 0 none, 2 ReLU, 3 LeakyReLU(0.2),
- * 4 SiLU, 5 ELU. */
+ * 4 SiLU, 5 ELU.  out_dtype: 0 bf16, 2 f16. */
 int pi3_groupnorm_apply(const float* x, long ldx, int B, int HW, int C, int Cpad, int G, const double* stats,
-                        const float* gamma, const float* beta, float eps, int act, void* out, long ldo, void* stream);
+                        const float* gamma, const float* beta, float eps, int act, void* out, long ldo, int out_dtype,
+                        void* stream);
 
 /* x[r][0..C) += y[r][0..C) on fp32 maps: ConvStack with an identity input block (modules.py:245-249). */
 int pi3_add_rows(float* x, long ldx, const float* y, long ldy, long rows, int C, void* stream);
 
 /* ConvTranspose2d(k=2, s=2) scatter: g f32 [B*H*W][(dy*2+dx)*Cs + co] -> bf16 NHWC [B][2H][2W][ldo], channels
- * [Cout, Cpad) zeroed (Cpad % 4 == 0, ldo % 4 == 0). */
+ * [Cout, Cpad) zeroed (Cpad % 4 == 0, ldo % 4 == 0).  out_dtype: 0 bf16, 2 f16. */
 int pi3_convt_scatter(const float* g, long ldg, int B, int H, int W, int Cout, int Cs, int Cpad, void* out, long ldo,
-                      void* stream);
+                      int out_dtype, void* stream);
 
 /* x[b][y][x][c] (+)= w[c][wofs] * uvx[x] + w[c][wofs+1] * uvy[y] + bias[c]: 1x1 conv of the UV planes (v2.py:141-147). */
 int pi3_uv_affine(float* x, long ldx, int B, int H, int W, int C, const float* w, long ldw, int wofs,

@@ -100,7 +100,7 @@ extern "C" int pi3_set_knob(const char* name, long value) {
 
 extern "C" const char* pi3_last_error(void) { return g_err; }
 
-extern "C" int pi3_abi_version(void) { return 5; }   // 5: pi3_rope_2d (the reference's curope.rope_2d contract); 4: pi3_sim3_umeyama_weighted (real-valued pair weights); 2: caller-provided workspaces (attention, group-norm statistics); 3: narrow-N GEMM / conv forms, pi3_cast_rows_pad, 4-channel granularity of the MoGe staging kernels
+extern "C" int pi3_abi_version(void) { return 6; }   // 6: dtype code 2 = IEEE half through the MoGe entries (pi3_attention / pi3_conv3x3 / pi3_patch_gather / pi3_groupnorm_apply / pi3_convt_scatter take a dtype); 5: pi3_rope_2d (the reference's curope.rope_2d contract); 4: pi3_sim3_umeyama_weighted (real-valued pair weights); 2: caller-provided workspaces (attention, group-norm statistics); 3: narrow-N GEMM / conv forms, pi3_cast_rows_pad, 4-channel granularity of the MoGe staging kernels
 
 // Number of visible devices (does not create a context); used by the loader to fail loudly on a box without a GPU.
 extern "C" int pi3_device_count(void) {

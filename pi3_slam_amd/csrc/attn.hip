@@ -268,13 +268,14 @@ __global__ __launch_bounds__(256, MIN_WAVES) void attn_fwd_kernel(AttnParams p) 
 
 int pi3_attention64_launch(const void* q, const void* k, const void* v, long tok_stride, long batch_stride, void* o,
                            long o_tok_stride, long o_batch_stride, int B, int S, int H, float* k2max_ws,
-                           int k2max_ready, int nw_req, hipStream_t stream);
+                           int k2max_ready, int nw_req, hipStream_t stream, int f16);
 
 extern "C" int pi3_attention(const void* q, const void* k, const void* v, long tok_stride, long batch_stride,
                              void* o, long o_tok_stride, long o_batch_stride, int B, int S, int H, int head_dim,
-                             float* k2max_ws, int k2max_ready, void* stream) {
-  if (!q || !k || !v || !o || B <= 0 || S <= 0 || H <= 0 || head_dim != 64) {
-    pi3_set_error("pi3_attention: bad arguments B=%d S=%d H=%d head_dim=%d (head_dim must be 64)", B, S, H, head_dim);
+                             int dtype, float* k2max_ws, int k2max_ready, void* stream) {
+  if (!q || !k || !v || !o || B <= 0 || S <= 0 || H <= 0 || head_dim != 64 || (dtype != 0 && dtype != 2)) {
+    pi3_set_error("pi3_attention: bad arguments B=%d S=%d H=%d head_dim=%d (head_dim must be 64) dtype=%d (0 bf16, 2 f16)", B,
+                  S, H, head_dim, dtype);
     return PI3_ERR_ARG;
   }
   if ((tok_stride % 8) || (batch_stride % 8) || (o_tok_stride % 4) || ((uintptr_t)q & 15) || ((uintptr_t)k & 15) ||
@@ -282,6 +283,9 @@ extern "C" int pi3_attention(const void* q, const void* k, const void* v, long t
     pi3_set_error("pi3_attention: q/k/v must be 16-byte aligned with strides that are multiples of 8 elements");
     return PI3_ERR_ARG;
   }
+  if (dtype == 2)   // IEEE half (MoGe under the reference's fp16 autocast): the 64-row kernel, any sequence length
+    return pi3_attention64_launch(q, k, v, tok_stride, batch_stride, o, o_tok_stride, o_batch_stride, B, S, H, nullptr, 0,
+                                  S >= 4096 ? 0 : 4, (hipStream_t)stream, 1);
   // PI3_ATTN_IMPL: 0 = automatic (64-row kernel for long sequences), 1 = 32-row kernel, 2 = 64-row kernel (A/B knob)
   static int impl = -1;
   if (impl < 0) {
@@ -290,7 +294,7 @@ extern "C" int pi3_attention(const void* q, const void* k, const void* v, long t
   }
   if (impl == 2 || (impl == 0 && S >= 4096))
     return pi3_attention64_launch(q, k, v, tok_stride, batch_stride, o, o_tok_stride, o_batch_stride, B, S, H,
-                                  k2max_ws, k2max_ready, 0, (hipStream_t)stream);
+                                  k2max_ws, k2max_ready, 0, (hipStream_t)stream, 0);
   // frame-wise sequences (643 tokens): the 64-row kernel with four-wave workgroups (256 query rows share a staged
   // tile, LDS-DMA staging, and - when the producer supplies max |k|^2 - the bounded-score loop) measured 8-10 % ahead
   // of the 32-row kernel below.  PI3_ATTN_SHORT=0 keeps the 32-row kernel (A/B knob).
@@ -301,7 +305,7 @@ extern "C" int pi3_attention(const void* q, const void* k, const void* v, long t
   }
   if (impl == 0 && shortk && S >= 256)
     return pi3_attention64_launch(q, k, v, tok_stride, batch_stride, o, o_tok_stride, o_batch_stride, B, S, H,
-                                  k2max_ws, k2max_ready, 4, (hipStream_t)stream);
+                                  k2max_ws, k2max_ready, 4, (hipStream_t)stream, 0);
   AttnParams p;
   p.q = (const bf16_t*)q; p.k = (const bf16_t*)k; p.v = (const bf16_t*)v;
   p.tok_stride = tok_stride; p.batch_stride = batch_stride;

@@ -96,6 +96,22 @@ __device__ __forceinline__ void a64_glds16(const void* gsrc, const void* lds_dst
   asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(m0v) : "memory", "m0");
 }
 
+// F16: q / k / v / o are IEEE half instead of bf16 (MoGe, which the reference runs under fp16 autocast, moge/model/v2.py:228):
+// the same fragments through v_mfma_f32_32x32x16_f16 (same rate), probabilities packed as half.  Half has 5 exponent
+// bits, so that form always runs the online-max loop (p <= 2^A64_THR = 64); the bounded-score loop is bf16 only.
+template <bool F16>
+__device__ __forceinline__ f32x16 a64_mfma(bf16x8 a, bf16x8 b, f32x16 c) {
+  if constexpr (F16)
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  else
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+template <bool F16>
+__device__ __forceinline__ uint32_t a64_pack(float lo, float hi) {
+  if constexpr (F16) return pack_f16x2(lo, hi);
+  else return pack_bf16x2(lo, hi);
+}
+
 // online-softmax step of one 32-row block on its two raw score tiles; m is the per-lane running max (exp2 domain).
 // MSUM (bounded-score path only): the row sum is taken by the matrix pipe, which idles through most of this VALU-bound
 // phase: v_mfma_f32_4x4x4_16B_bf16 with an all-ones A operand adds the lane's own four packed bf16 probabilities into
@@ -103,7 +119,7 @@ __device__ __forceinline__ void a64_glds16(const void* gsrc, const void* lds_dst
 // replace 68 v_add_f32 per tile, and l sums exactly the bf16 values that P.V multiplies.
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 // NKT = 1: only the first 32 keys of the tile exist (a short last tile): sc[1] / pf[1] are not touched.
-template <bool FIRST, bool NOMAX, bool MSUM, int NKT = 2>
+template <bool FIRST, bool NOMAX, bool MSUM, int NKT = 2, bool F16 = false>
 __device__ __forceinline__ void a64_softmax(f32x16 (&sc)[2], float& m, f32x16 (&o)[2], float& l, f32x4& lacc,
                                             bf16x8 (&pf)[2][2]) {
   if constexpr (NOMAX) {
@@ -167,7 +183,7 @@ __device__ __forceinline__ void a64_softmax(f32x16 (&sc)[2], float& m, f32x16 (&
         const float p0 = __builtin_amdgcn_exp2f(sc[kt][8 * s2 + 2 * jj] - m);
         const float p1 = __builtin_amdgcn_exp2f(sc[kt][8 * s2 + 2 * jj + 1] - m);
         psum += p0 + p1;
-        pw[jj] = pack_bf16x2(p0, p1);
+        pw[jj] = a64_pack<F16>(p0, p1);
       }
       pf[kt][s2] = __builtin_bit_cast(bf16x8, pw);
     }
@@ -176,7 +192,7 @@ __device__ __forceinline__ void a64_softmax(f32x16 (&sc)[2], float& m, f32x16 (&
 
 // NW = waves per workgroup (4 or 8): NW * 64 query rows share one staged K/V tile.
 // GLDS: stage K/V with LDS-DMA (global_load_lds, swizzle on the source address) instead of registers + ds_write.
-template <int NW, bool GLDS = false, bool MSUM = false>
+template <int NW, bool GLDS = false, bool MSUM = false, bool F16 = false>
 __global__ __launch_bounds__(NW * 64, (NW == 2 ? 4 : 2)) void attn_fwd64_kernel(Attn64Params p) {
   __shared__ __attribute__((aligned(16))) char lds[32768];  // K ring [2][64][128 B] then V ring [2][64][128 B]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -342,30 +358,30 @@ __global__ __launch_bounds__(NW * 64, (NW == 2 ? 4 : 2)) void attn_fwd64_kernel(
       {                                                                                                           \
         const int off = (h ^ kswz) << 4;                                                                          \
         const bf16x8 a0 = *(const bf16x8*)(kl + off);                                                             \
-        scA[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, qfA[0], (f32x16)(0.f), 0, 0, 0);                     \
-        if ((NB) == 2) scB[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, qfB[0], (f32x16)(0.f), 0, 0, 0);      \
+        scA[0] = a64_mfma<F16>(a0, qfA[0], (f32x16)(0.f));                     \
+        if ((NB) == 2) scB[0] = a64_mfma<F16>(a0, qfB[0], (f32x16)(0.f));      \
         if ((NKT) == 2) {                                                                                         \
           const bf16x8 a1 = *(const bf16x8*)(kl + 32 * 128 + off);                                                \
-          scA[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, qfA[0], (f32x16)(0.f), 0, 0, 0);                   \
-          if ((NB) == 2) scB[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, qfB[0], (f32x16)(0.f), 0, 0, 0);    \
+          scA[1] = a64_mfma<F16>(a1, qfA[0], (f32x16)(0.f));                   \
+          if ((NB) == 2) scB[1] = a64_mfma<F16>(a1, qfB[0], (f32x16)(0.f));    \
         }                                                                                                         \
       }                                                                                                           \
       if (A64_ABL != 4)                                                                                           \
       _Pragma("unroll") for (int s = 1; s < 4; ++s) {                                                             \
         const int off = A64_ABL == 7 ? ((h ^ kswz) << 4) : (((2 * s + h) ^ kswz) << 4);                           \
         const bf16x8 a0 = *(const bf16x8*)(kl + off);                                                             \
-        scA[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, qfA[s], scA[0], 0, 0, 0);                            \
-        if ((NB) == 2) scB[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, qfB[s], scB[0], 0, 0, 0);             \
+        scA[0] = a64_mfma<F16>(a0, qfA[s], scA[0]);                            \
+        if ((NB) == 2) scB[0] = a64_mfma<F16>(a0, qfB[s], scB[0]);             \
         if ((NKT) == 2) {                                                                                         \
           const bf16x8 a1 = *(const bf16x8*)(kl + 32 * 128 + off);                                                \
-          scA[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, qfA[s], scA[1], 0, 0, 0);                          \
-          if ((NB) == 2) scB[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, qfB[s], scB[1], 0, 0, 0);           \
+          scA[1] = a64_mfma<F16>(a1, qfA[s], scA[1]);                          \
+          if ((NB) == 2) scB[1] = a64_mfma<F16>(a1, qfB[s], scB[1]);           \
         }                                                                                                         \
       }                                                                                                           \
       if (masktail) { A64_MASK(T, scA, NKT) if ((NB) == 2) { A64_MASK(T, scB, NKT) } }                            \
       A64_STAMP(T, 1)                                                                                             \
-      a64_softmax<FIRST, NOMAX, MSUM, NKT>(scA, mA, oA, lA, laccA, pfA);                                          \
-      if ((NB) == 2) a64_softmax<FIRST, NOMAX, MSUM, NKT>(scB, mB, oB, lB, laccB, pfB);                           \
+      a64_softmax<FIRST, NOMAX, MSUM, NKT, F16>(scA, mA, oA, lA, laccA, pfA);                                          \
+      if ((NB) == 2) a64_softmax<FIRST, NOMAX, MSUM, NKT, F16>(scB, mB, oB, lB, laccB, pfB);                           \
       _Pragma("unroll") for (int kt = 0; kt < (NKT); ++kt)                                                        \
       _Pragma("unroll") for (int s2 = 0; s2 < 2; ++s2) {                                                          \
         const int row0 = 32 * kt + 16 * s2 + vrow_l;                                                              \
@@ -378,8 +394,8 @@ __global__ __launch_bounds__(NW * 64, (NW == 2 ? 4 : 2)) void attn_fwd64_kernel(
           const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(                                             \
               (__attribute__((address_space(3))) bf16x4*)LDS_PTR(a + 8 * 128));                                   \
           const bf16x8 vf = a64_cat4(lo, hi);                                                                     \
-          oA[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pfA[kt][s2], oA[dt], 0, 0, 0);                     \
-          if ((NB) == 2) oB[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pfB[kt][s2], oB[dt], 0, 0, 0);      \
+          oA[dt] = a64_mfma<F16>(vf, pfA[kt][s2], oA[dt]);                     \
+          if ((NB) == 2) oB[dt] = a64_mfma<F16>(vf, pfB[kt][s2], oB[dt]);      \
         }                                                                                                         \
       }                                                                                                           \
     }                                                                                                             \
@@ -418,7 +434,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 2 ? 4 : 2)) void attn_fwd64_kernel(
   const int nb = (NW <= 4 && p.tailopt) ? (q0 >= S ? 0 : (q0 + 32 >= S ? 1 : 2)) : 2;
   // bounded-score test (see header): wave-uniform
   bool fast = false;
-  if (p.k2max && nb > 0) {
+  if (!F16 && p.k2max && nb > 0) {
     const float k2 = p.k2max[b * p.H + head];
     float qa = 0.f, qb = 0.f;
 #pragma unroll
@@ -436,7 +452,9 @@ __global__ __launch_bounds__(NW * 64, (NW == 2 ? 4 : 2)) void attn_fwd64_kernel(
   // static priority for the second-dispatched half (MI355X_MICROARCH.md, two waves per SIMD, item 4): the younger
   // wave of a SIMD loses every VALU arbitration at equal priority
   if (p.prio && wave >= NW / 2) __builtin_amdgcn_s_setprio(1);
-  if (nb == 2) {
+  if constexpr (F16) {       // online-max loop only (see a64_mfma)
+    if (nb == 2) A64_SWEEP(false, 2) else if (nb == 1) A64_SWEEP(false, 1) else A64_SWEEP(false, 0)
+  } else if (nb == 2) {
     if (fast) A64_SWEEP(true, 2) else A64_SWEEP(false, 2)
   } else if (nb == 1) {
     if (fast) A64_SWEEP(true, 1) else A64_SWEEP(false, 1)
@@ -464,8 +482,8 @@ __global__ __launch_bounds__(NW * 64, (NW == 2 ? 4 : 2)) void attn_fwd64_kernel(
         for (int g = 0; g < 4; ++g) {
           const f32x16& ov = blk ? oB[dt] : oA[dt];
           u32x2 w;
-          w[0] = pack_bf16x2(ov[4 * g + 0] * inv, ov[4 * g + 1] * inv);
-          w[1] = pack_bf16x2(ov[4 * g + 2] * inv, ov[4 * g + 3] * inv);
+          w[0] = a64_pack<F16>(ov[4 * g + 0] * inv, ov[4 * g + 1] * inv);
+          w[1] = a64_pack<F16>(ov[4 * g + 2] * inv, ov[4 * g + 3] * inv);
           *(u32x2*)(optr + 32 * dt + 8 * g + 4 * h) = w;
         }
     }
@@ -550,7 +568,7 @@ extern "C" int pi3_attention_path_counters(unsigned int* counters) {
 // k2max_ws: caller-provided [B*H] floats (or null -> online-max loop); k2max_ready: already filled by the producer.
 int pi3_attention64_launch(const void* q, const void* k, const void* v, long tok_stride, long batch_stride, void* o,
                            long o_tok_stride, long o_batch_stride, int B, int S, int H, float* k2max_ws,
-                           int k2max_ready, int nw_req, hipStream_t stream) {
+                           int k2max_ready, int nw_req, hipStream_t stream, int f16) {
   Attn64Params p;
   p.q = (const bf16_t*)q; p.k = (const bf16_t*)k; p.v = (const bf16_t*)v;
   p.tok_stride = tok_stride; p.batch_stride = batch_stride;
@@ -599,6 +617,14 @@ int pi3_attention64_launch(const void* q, const void* k, const void* v, long tok
   static_assert(1100 + 100 * 4 <= 2048, "phase stamps fit the debug buffer");
   p.dbg = dbgbuf;
 #endif
+  if (f16) {      // IEEE-half operands: LDS-DMA staging, online-max loop, eight- or four-wave workgroups
+    p.stats = g_attn_stats;
+    if (nw_req == 4)
+      hipLaunchKernelGGL((attn_fwd64_kernel<4, true, false, true>), dim3((unsigned)nwg), dim3(256), 0, stream, p);
+    else
+      hipLaunchKernelGGL((attn_fwd64_kernel<8, true, false, true>), dim3((unsigned)nwg), dim3(512), 0, stream, p);
+    return pi3_check_launch("attn_fwd64 (f16)");
+  }
   if (nomax && k2max_ws) {
     if (!k2max_ready) {
       if (hipMemsetAsync(k2max_ws, 0, (size_t)B * H * sizeof(float), stream) != hipSuccess) {

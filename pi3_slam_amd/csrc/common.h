@@ -55,6 +55,23 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
   return __builtin_bit_cast(uint32_t, v);
 }
 
+// fp32 -> IEEE half, round-to-nearest-even (v_cvt_pk_f16_f32 on gfx950); overflow -> inf like torch's .half()
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ uint32_t pack_f16x2(float lo, float hi) {
+  f16x2 v;
+  v[0] = (_Float16)lo;
+  v[1] = (_Float16)hi;
+  return __builtin_bit_cast(uint32_t, v);
+}
+
+// the 16-bit storage format as a run-time (wave-uniform) choice: the HBM-bound staging kernels of the MoGe path write
+// bf16 or IEEE half with one code path
+__device__ __forceinline__ uint32_t pack16x2(float lo, float hi, int f16) {
+  return f16 ? pack_f16x2(lo, hi) : pack_bf16x2(lo, hi);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -13,7 +13,7 @@ template <bool OUT_BF16, int VPL>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, long ldx, int rows, int D,
                                                         const float* __restrict__ w, const float* __restrict__ b,
                                                         float eps, void* out, long ldo, int T, int nspecial,
-                                                        const float* __restrict__ special) {
+                                                        const float* __restrict__ special, int f16) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -58,8 +58,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     if (c < nv) {
       if constexpr (OUT_BF16) {
         u32x2 o;
-        o[0] = pack_bf16x2(y[0], y[1]);
-        o[1] = pack_bf16x2(y[2], y[3]);
+        o[0] = pack16x2(y[0], y[1], f16);
+        o[1] = pack16x2(y[2], y[3], f16);
         *(u32x2*)((bf16_t*)out + (long)row * ldo + 4 * c) = o;
       } else {
         *(f32x4*)((float*)out + (long)row * ldo + 4 * c) = y;
@@ -72,15 +72,17 @@ extern "C" int pi3_layernorm(const float* x, long ldx, int rows, int D, const fl
                              void* out, long ldo, int out_dtype, int T, int nspecial, const float* special,
                              void* stream) {
   if (!x || !w || !b || !out || rows <= 0 || D <= 0 || (D % 4) || D > 2048 || (ldx % 4) || (ldo % 4) ||
-      (nspecial > 0 && (out_dtype != 1 || !special || T <= 0))) {
-    pi3_set_error("pi3_layernorm: bad arguments rows=%d D=%d (D %% 4 == 0, D <= 2048)", rows, D);
+      (nspecial > 0 && (out_dtype != 1 || !special || T <= 0)) || out_dtype < 0 || out_dtype > 2) {
+    pi3_set_error("pi3_layernorm: bad arguments rows=%d D=%d (D %% 4 == 0, D <= 2048) out_dtype=%d", rows, D, out_dtype);
     return PI3_ERR_ARG;
   }
+  const int f16 = out_dtype == 2;      // IEEE-half output: the bf16 instance with the other conversion
+  if (f16) out_dtype = 0;
   const dim3 grid((rows + 3) / 4), block(256);
   const int vpl = (D / 4 + 63) / 64;
 #define LN_LAUNCH(OB, V)                                                                                         \
   hipLaunchKernelGGL((layernorm_kernel<OB, V>), grid, block, 0, (hipStream_t)stream, x, ldx, rows, D, w, b, eps, \
-                     out, ldo, T, nspecial, special)
+                     out, ldo, T, nspecial, special, f16)
   if (out_dtype == 0) {
     if (vpl <= 1) LN_LAUNCH(true, 1); else if (vpl <= 2) LN_LAUNCH(true, 2);
     else if (vpl <= 4) LN_LAUNCH(true, 4); else LN_LAUNCH(true, 8);
@@ -255,7 +257,7 @@ extern "C" int pi3_rope_2d(void* tokens, const long* positions, int B, int N, in
 // beyond in_cols are written as zeros (K padding of a following GEMM) and are not read.
 template <bool OUT_BF16>
 __global__ __launch_bounds__(256) void cast_rows_kernel(const float* __restrict__ in, long ldi, int in_cols, void* out,
-                                                        long ldo, long rows, int cols) {
+                                                        long ldo, long rows, int cols, int f16) {
   const int nv = cols >> 2;
   const long stride = (long)gridDim.x * 256;
   const long i0 = (long)blockIdx.x * 256 + threadIdx.x;
@@ -269,8 +271,8 @@ __global__ __launch_bounds__(256) void cast_rows_kernel(const float* __restrict_
     if (4 * c < in_cols) v = *(const f32x4*)(in + r * ldi + 4 * c);
     if constexpr (OUT_BF16) {
       u32x2 o;
-      o[0] = pack_bf16x2(v[0], v[1]);
-      o[1] = pack_bf16x2(v[2], v[3]);
+      o[0] = pack16x2(v[0], v[1], f16);
+      o[1] = pack16x2(v[2], v[3], f16);
       *(u32x2*)((bf16_t*)out + r * ldo + 4 * c) = o;
     } else {
       *(f32x4*)((float*)out + r * ldo + 4 * c) = v;
@@ -284,19 +286,20 @@ __global__ __launch_bounds__(256) void cast_rows_kernel(const float* __restrict_
 extern "C" int pi3_cast_rows_pad(const float* in, long ldi, int in_cols, void* out, long ldo, long rows, int cols,
                                  int out_dtype, void* stream) {
   if (!in || !out || rows <= 0 || cols <= 0 || in_cols <= 0 || in_cols > cols || (cols % 4) || (in_cols % 4) ||
-      (ldi % 4) || (ldo % 4) || ((uintptr_t)in & 15) || ((uintptr_t)out & (out_dtype == 0 ? 7 : 15))) {
+      (ldi % 4) || (ldo % 4) || ((uintptr_t)in & 15) || ((uintptr_t)out & (out_dtype != 1 ? 7 : 15)) || out_dtype < 0 ||
+      out_dtype > 2) {
     pi3_set_error("pi3_cast_rows: bad arguments rows=%ld cols=%d in_cols=%d (multiples of 4, 16-byte aligned)", rows, cols,
                   in_cols);
     return PI3_ERR_ARG;
   }
   long blocks = (rows * (cols >> 2) + 255) / 256;
   if (blocks > 256 * 16) blocks = 256 * 16;
-  if (out_dtype == 0)
+  if (out_dtype != 1)      // 0 bf16, 2 IEEE half
     hipLaunchKernelGGL(cast_rows_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, in, ldi,
-                       in_cols, out, ldo, rows, cols);
+                       in_cols, out, ldo, rows, cols, out_dtype == 2);
   else
     hipLaunchKernelGGL(cast_rows_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, in, ldi,
-                       in_cols, out, ldo, rows, cols);
+                       in_cols, out, ldo, rows, cols, 0);
   return pi3_check_launch("cast_rows");
 }
 
@@ -313,7 +316,7 @@ extern "C" int pi3_cast_rows(const float* in, long ldi, void* out, long ldo, lon
 // ---------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void patch_gather_kernel(const float* __restrict__ img, int F, int H, int W,
                                                            bf16_t* __restrict__ out, int KP, float m0, float m1,
-                                                           float m2, float is0, float is1, float is2) {
+                                                           float m2, float is0, float is1, float is2, int f16) {
   const int ph = H / 14, pw = W / 14, P = ph * pw;
   const long total = (long)F * P * 42;  // 3 channels * 14 rows
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
@@ -331,23 +334,24 @@ __global__ __launch_bounds__(256) void patch_gather_kernel(const float* __restri
 #pragma unroll
   for (int kx = 0; kx < 14; kx += 2) {
     const float a = (src[kx] - mean) * istd, b = (src[kx + 1] - mean) * istd;
-    *(uint32_t*)(dst + kx) = pack_bf16x2(a, b);
+    *(uint32_t*)(dst + kx) = pack16x2(a, b, f16);
   }
   if (ck == 0) {  // zero the K padding once per patch row
     for (int k = 588; k < KP; k += 2) *(uint32_t*)(out + patch * KP + k) = 0u;
   }
 }
 
-extern "C" int pi3_patch_gather(const float* img, int F, int H, int W, void* out, int KP, const float* mean3,
-                                const float* std3, void* stream) {
-  if (!img || !out || F <= 0 || H <= 0 || W <= 0 || (H % 14) || (W % 14) || KP < 588 || (KP % 2)) {
+extern "C" int pi3_patch_gather(const float* img, int F, int H, int W, void* out, int KP, int out_dtype,
+                                const float* mean3, const float* std3, void* stream) {
+  if (!img || !out || F <= 0 || H <= 0 || W <= 0 || (H % 14) || (W % 14) || KP < 588 || (KP % 2) ||
+      (out_dtype != 0 && out_dtype != 2)) {
     pi3_set_error("pi3_patch_gather: bad arguments F=%d H=%d W=%d KP=%d (H, W multiples of 14)", F, H, W, KP);
     return PI3_ERR_ARG;
   }
   const long total = (long)F * (H / 14) * (W / 14) * 42;
   hipLaunchKernelGGL(patch_gather_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                      img, F, H, W, (bf16_t*)out, KP, mean3[0], mean3[1], mean3[2], 1.0f / std3[0], 1.0f / std3[1],
-                     1.0f / std3[2]);
+                     1.0f / std3[2], out_dtype == 2);
   return pi3_check_launch("patch_gather");
 }
 

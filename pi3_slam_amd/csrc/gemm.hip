@@ -125,11 +125,20 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmParams p) {
           fa[i] = *(const bf16x8*)(la + i * 16 * 128 + off);
           fw[i] = *(const bf16x8*)(lw + i * 16 * 128 + off);
         }
+        if (p.f16) {       // wave-uniform: the same fragments as IEEE half
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni)
+          for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
-          for (int mi = 0; mi < 4; ++mi)
-            acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[ni], fa[mi], acc[ni][mi], 0, 0, 0);
+            for (int mi = 0; mi < 4; ++mi)
+              acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, fw[ni]),
+                                                                   __builtin_bit_cast(f16x8, fa[mi]), acc[ni][mi], 0, 0, 0);
+        } else {
+#pragma unroll
+          for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+              acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[ni], fa[mi], acc[ni][mi], 0, 0, 0);
+        }
       } else {
         f32x4 fa[4], fw[4];
 #pragma unroll
@@ -152,7 +161,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmParams p) {
   }
 
   // ---- epilogue: lane holds rows n = nb + 4*(lane>>4) + r (r = 0..3) of column m = mb + (lane & 15)
-  gemm_epilogue<OUT_BF16, ACT, 4, 4>(p, acc, bm * BM + wm * 64, bn * BN + wn * 64, lane);
+  gemm_epilogue<OUT_BF16, ACT, 4, 4, true>(p, acc, bm * BM + wm * 64, bn * BN + wn * 64, lane);
 }
 
 template <bool IS_BF16, bool OUT_BF16, int ACT, bool CONV = false>
@@ -266,16 +275,25 @@ __global__ __launch_bounds__(256) void gemm_narrow_kernel(GemmParams p) {
       for (int i = 0; i < 4; ++i) fa[i] = *(const bf16x8*)(la + i * 16 * 128 + off);
 #pragma unroll
       for (int i = 0; i < NT; ++i) fw[i] = *(const bf16x8*)(lw + i * 16 * 128 + off);
+      if (p.f16) {
 #pragma unroll
-      for (int ni = 0; ni < NT; ++ni)
+        for (int ni = 0; ni < NT; ++ni)
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi)
-          acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[ni], fa[mi], acc[ni][mi], 0, 0, 0);
+          for (int mi = 0; mi < 4; ++mi)
+            acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, fw[ni]),
+                                                                 __builtin_bit_cast(f16x8, fa[mi]), acc[ni][mi], 0, 0, 0);
+      } else {
+#pragma unroll
+        for (int ni = 0; ni < NT; ++ni)
+#pragma unroll
+          for (int mi = 0; mi < 4; ++mi)
+            acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[ni], fa[mi], acc[ni][mi], 0, 0, 0);
+      }
     }
     __syncthreads();
     cur ^= 1;
   }
-  gemm_epilogue<OUT_BF16, ACT, NT, 4>(p, acc, bm * NBM + wave * 64, bn * 16 * NT, lane);
+  gemm_epilogue<OUT_BF16, ACT, NT, 4, true>(p, acc, bm * NBM + wave * 64, bn * 16 * NT, lane);
 }
 
 template <bool OUT_BF16, int ACT, bool CONV>
@@ -304,6 +322,17 @@ extern "C" int pi3_gemm(const void* A, long lda, const void* W, long ldw, int M,
                         const float* bias, const float* gamma, const float* resid, long ldr, void* out, long ldo,
                         int out_dtype, int act, int rpg, int gstride, int goff, const float* addtab, long ldadd,
                         float qscale, int qcols, void* stream) {
+  // in_dtype 2 = IEEE-half operands, out_dtype 2 = IEEE-half output: the bf16 code paths with the f16 MFMA / conversion
+  // selected at run time (GemmParams.f16).  A 16-bit output has the operands' format (one flag).
+  const int f16 = (in_dtype == 2 || out_dtype == 2) ? 1 : 0;
+  if (in_dtype < 0 || in_dtype > 2 || out_dtype < 0 || out_dtype > 2 || (f16 && (in_dtype == 0 || out_dtype == 0)) ||
+      (f16 && in_dtype == 1)) {
+    pi3_set_error("pi3_gemm: unsupported dtypes in=%d out=%d (0 bf16, 1 f32, 2 f16; f16 operands give f16 or f32 output, "
+                  "bf16 operands bf16 or f32)", in_dtype, out_dtype);
+    return PI3_ERR_ARG;
+  }
+  if (in_dtype == 2) in_dtype = 0;
+  if (out_dtype == 2) out_dtype = 0;
   const int bk = in_dtype == 0 ? 64 : 32;
   const bool narrow = in_dtype == 0 && (N % BN) != 0 && (N % 32) == 0;     // bf16 operands, N = 32, 64, 96, 160, ...
   if (!A || !W || !out || M <= 0 || N <= 0 || K <= 0 || ((N % BN) != 0 && !narrow) || (K % bk) != 0 || act < 0 || act > 2) {
@@ -321,7 +350,7 @@ extern "C" int pi3_gemm(const void* A, long lda, const void* W, long ldw, int M,
   p.bias = bias; p.gamma = gamma; p.resid = resid; p.ldr = ldr; p.out = out; p.ldo = ldo;
   p.rpg = rpg; p.gstride = gstride; p.goff = goff; p.addtab = addtab; p.ldadd = ldadd;
   p.qscale = qscale; p.qcols = qcols;
-  p.cH = 0; p.cW = 0; p.cC = 0;
+  p.cH = 0; p.cW = 0; p.cC = 0; p.f16 = f16;
   p.qk_mode = 0; p.qk_k2max = nullptr; p.tile_gm = 0;
   hipStream_t s = (hipStream_t)stream;
   if (narrow) {
@@ -332,7 +361,7 @@ extern "C" int pi3_gemm(const void* A, long lda, const void* W, long ldw, int M,
     pi3_set_error("pi3_gemm: unsupported (out_dtype=%d, act=%d) for a narrow N", out_dtype, act);
     return PI3_ERR_ARG;
   }
-  if (in_dtype == 0) {  // large bf16 GEMMs: 256x256 pipelined kernel (PI3_GEMM_IMPL=1 forces the 128x128 kernel)
+  if (in_dtype == 0 && !f16) {  // large bf16 GEMMs: 256x256 pipelined kernel (PI3_GEMM_IMPL=1 forces the 128x128 kernel)
     static int impl = -1;
     if (impl < 0) {
       const char* e = getenv("PI3_GEMM_IMPL");
@@ -394,7 +423,7 @@ extern "C" int pi3_gemm_qkv(const void* A, long lda, const void* W, long ldw, in
   p.A = A; p.lda = lda; p.W = W; p.ldw = ldw; p.M = M; p.N = N; p.K = K;
   p.bias = bias; p.gamma = nullptr; p.resid = nullptr; p.ldr = 0; p.out = qkv; p.ldo = ldo;
   p.rpg = 0; p.gstride = 0; p.goff = 0; p.addtab = nullptr; p.ldadd = 0; p.qscale = 1.f; p.qcols = 0;
-  p.cH = 0; p.cW = 0; p.cC = 0; p.tile_gm = 0;
+  p.cH = 0; p.cW = 0; p.cC = 0; p.tile_gm = 0; p.f16 = 0;
   p.qk_mode = 1; p.qk_H = H; p.qk_T = T; p.qk_pos = pos; p.qk_cs = cs;
   p.qk_qw = qw; p.qk_qb = qb; p.qk_kw = kw; p.qk_kb = kb; p.qk_eps = eps; p.qk_qscale = qscale;
   p.qk_k2max = k2max; p.qk_attnS = attn_S > 0 ? attn_S : M;
@@ -430,8 +459,15 @@ extern "C" int pi3_gemm_qkv(const void* A, long lda, const void* W, long ldw, in
 // padding_mode='replicate') in moge/model/modules.py:47-60,146-164).  img: bf16 [B][H][W][ldc] with C % 64 == 0 used
 // channels; wgt: bf16 [N][9*C], k = (ky*3 + kx)*C + ci; out rows = pixels.  Epilogue as pi3_gemm (bias, resid, act).
 extern "C" int pi3_conv3x3(const void* img, long ldc, int B, int H, int W, int C, const void* wgt, int N,
-                           const float* bias, const float* resid, long ldr, void* out, long ldo, int out_dtype, int act,
-                           void* stream) {
+                           const float* bias, const float* resid, long ldr, void* out, long ldo, int in_dtype,
+                           int out_dtype, int act, void* stream) {
+  // in_dtype: 0 = bf16 image and weights, 2 = IEEE half; out_dtype: 1 = f32, else the image's 16-bit type
+  if ((in_dtype != 0 && in_dtype != 2) || (out_dtype != 1 && out_dtype != in_dtype)) {
+    pi3_set_error("pi3_conv3x3: unsupported dtypes in=%d out=%d (in: 0 bf16 / 2 f16; out: 1 f32 or the input type)", in_dtype,
+                  out_dtype);
+    return PI3_ERR_ARG;
+  }
+  if (out_dtype == 2) out_dtype = 0;
   const bool narrow = (N % BN) != 0 || C == 32;
   if (!img || !wgt || !out || B <= 0 || H <= 0 || W <= 0 || C <= 0 || ((C % 64) && C != 32) || N <= 0 || (N % 32) ||
       (ldc % 8) || ((uintptr_t)img & 15) || ((uintptr_t)wgt & 15) || ((uintptr_t)out & 15) || (ldo % 4) || act < 0 ||
@@ -445,7 +481,7 @@ extern "C" int pi3_conv3x3(const void* img, long ldc, int B, int H, int W, int C
   p.A = img; p.lda = ldc; p.W = wgt; p.ldw = kw; p.M = B * H * W; p.N = N; p.K = (int)kw;
   p.bias = bias; p.gamma = nullptr; p.resid = resid; p.ldr = ldr; p.out = out; p.ldo = ldo;
   p.rpg = 0; p.gstride = 0; p.goff = 0; p.addtab = nullptr; p.ldadd = 0; p.qscale = 1.f; p.qcols = 0;
-  p.cH = H; p.cW = W; p.cC = C;
+  p.cH = H; p.cW = W; p.cC = C; p.f16 = in_dtype == 2;
   p.qk_mode = 0; p.qk_k2max = nullptr; p.tile_gm = 0;
   hipStream_t s = (hipStream_t)stream;
   if (narrow) {

@@ -16,6 +16,8 @@ struct GemmParams {
   // implicit-GEMM 3x3 convolution, replicate padding (moge/model/modules.py:47-60): A is an NHWC image
   // [B][cH][cW][cC] (cC % 64 == 0), row m = pixel, K = 9 * cC with k = (ky*3 + kx) * cC + ci; cW == 0 -> plain GEMM
   int cH, cW, cC;
+  int f16;                   // gemm.hip kernels only: the 16-bit operands (and a 16-bit output) are IEEE half, not bf16:
+                             // v_mfma_f32_16x16x32_f16, same rate - MoGe, which the reference runs under fp16 autocast
   int tile_gm;               // gemm256: m-tiles per scheduling group (0 = default 8); consecutive ids walk a group's m-tiles
   int tile_order;            // gemm256: 0 = m-tiles first inside a group, 1 = column tiles first
   int stagger_ns;            // gemm256 (persistent form): workgroup b starts b * stagger_ns later (0 = all at once)
@@ -42,7 +44,9 @@ struct GemmParams {
 // per n-tile ni, the 4 consecutive columns n0(ni) .. n0(ni)+3.  Per-column vectors (bias, LayerScale) are loaded once
 // for all NI tiles; per-row operands (residual, table) once per row, all NI at a time, so each optional operand costs
 // one uniform branch and one wait per row instead of one per tile.
-template <bool OUT_BF16, int ACT, int NI, int MI>
+// RT16: the 16-bit output type is a run-time choice (p.f16: IEEE half instead of bf16) - the kernels of gemm.hip; the
+// 256x256 kernel of the pi3 hot path instantiates RT16 = false and pays nothing for it.
+template <bool OUT_BF16, int ACT, int NI, int MI, bool RT16 = false>
 __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[NI][MI], int m_base, int n_base,
                                               int lane) {
   const int frow = lane & 15;
@@ -101,8 +105,13 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
       v = v * gamma4[ni] + extra[ni];
       if constexpr (OUT_BF16) {
         u32x2 o;
-        o[0] = pack_bf16x2(v[0], v[1]);
-        o[1] = pack_bf16x2(v[2], v[3]);
+        if (RT16 && p.f16) {
+          o[0] = pack_f16x2(v[0], v[1]);
+          o[1] = pack_f16x2(v[2], v[3]);
+        } else {
+          o[0] = pack_bf16x2(v[0], v[1]);
+          o[1] = pack_bf16x2(v[2], v[3]);
+        }
         *(u32x2*)((bf16_t*)p.out + orow * p.ldo + n0) = o;
       } else {
         *(f32x4*)((float*)p.out + orow * p.ldo + n0) = v;

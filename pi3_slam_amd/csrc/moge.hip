@@ -192,7 +192,7 @@ __global__ __launch_bounds__(256) void groupnorm_apply_kernel(const float* __res
                                                               int Cpad, int G, const double* __restrict__ stats,
                                                               const float* __restrict__ gamma,
                                                               const float* __restrict__ beta, float eps, int act,
-                                                              bf16_t* __restrict__ out, long ldo) {
+                                                              bf16_t* __restrict__ out, long ldo, int f16) {
   __shared__ float gmean[64 * GN_MAXJ], grstd[64 * GN_MAXJ];
   const int b = blockIdx.y, tid = threadIdx.x;
   const int cpg = G > 0 ? C / G : C;
@@ -247,8 +247,8 @@ __global__ __launch_bounds__(256) void groupnorm_apply_kernel(const float* __res
       v[e] = c + e < C ? moge_act(t, act) : 0.f;
     }
     u32x2 o;
-    o[0] = pack_bf16x2(v[0], v[1]);
-    o[1] = pack_bf16x2(v[2], v[3]);
+    o[0] = pack16x2(v[0], v[1], f16);
+    o[1] = pack16x2(v[2], v[3], f16);
     *(u32x2*)(ob + (long)pix * ldo + c) = o;
   }
   (void)dq;
@@ -278,8 +278,8 @@ extern "C" int pi3_add_rows(float* x, long ldx, const float* y, long ldy, long r
 
 extern "C" int pi3_groupnorm_apply(const float* x, long ldx, int B, int HW, int C, int Cpad, int G,
                                    const double* stats, const float* gamma, const float* beta, float eps, int act,
-                                   void* out, long ldo, void* stream) {
-  if (!x || (G > 0 && !stats) || ((gamma != nullptr) != (beta != nullptr)) || !out || C <= 0 || Cpad < C ||
+                                   void* out, long ldo, int out_dtype, void* stream) {
+  if ((out_dtype != 0 && out_dtype != 2) || !x || (G > 0 && !stats) || ((gamma != nullptr) != (beta != nullptr)) || !out || C <= 0 || Cpad < C ||
       (Cpad % 4) || (ldo % 4) || ((uintptr_t)out & 7) || G < 0 || (G > 0 && (C % G)) || G > 64 * GN_MAXJ || act < 0 ||
       act > 5 || act == 1 || B <= 0 || HW <= 0) {
     pi3_set_error("pi3_groupnorm_apply: bad arguments C=%d Cpad=%d G=%d act=%d (Cpad, ldo multiples of 4)", C, Cpad, G, act);
@@ -294,7 +294,7 @@ extern "C" int pi3_groupnorm_apply(const float* x, long ldx, int B, int HW, int 
   if (blocks > 2048) blocks = 2048;
   blocks = (blocks + unit - 1) / unit * unit;
   hipLaunchKernelGGL(groupnorm_apply_kernel, dim3((unsigned)blocks, (unsigned)B), dim3(256), 0, (hipStream_t)stream, x,
-                     ldx, HW, C, Cpad, G, stats, gamma, beta, eps, act, (bf16_t*)out, ldo);
+                     ldx, HW, C, Cpad, G, stats, gamma, beta, eps, act, (bf16_t*)out, ldo, out_dtype == 2);
   return pi3_check_launch("groupnorm_apply");
 }
 
@@ -304,7 +304,7 @@ extern "C" int pi3_groupnorm_apply(const float* x, long ldx, int B, int HW, int 
 // version: one element pair per thread behind five 64-bit divisions).
 __global__ __launch_bounds__(256) void convt_scatter_kernel(const float* __restrict__ g, long ldg, int H, int W,
                                                             int Cout, int Cs, int Cpad, bf16_t* __restrict__ out,
-                                                            long ldo) {
+                                                            long ldo, int f16) {
   const int orow = blockIdx.x;                 // over [B][2H]
   const int oy = orow % (2 * H), b = orow / (2 * H);
   const int q = Cpad >> 2, n = 2 * W * q;
@@ -323,21 +323,21 @@ __global__ __launch_bounds__(256) void convt_scatter_kernel(const float* __restr
       for (int e = 0; e < 4; ++e) v[e] = c + e < Cout ? src[e] : 0.f;
     }
     u32x2 o;
-    o[0] = pack_bf16x2(v[0], v[1]);
-    o[1] = pack_bf16x2(v[2], v[3]);
+    o[0] = pack16x2(v[0], v[1], f16);
+    o[1] = pack16x2(v[2], v[3], f16);
     *(u32x2*)(orowp + (long)ox * ldo + c) = o;
   }
 }
 
 extern "C" int pi3_convt_scatter(const float* g, long ldg, int B, int H, int W, int Cout, int Cs, int Cpad, void* out,
-                                 long ldo, void* stream) {
-  if (!g || !out || B <= 0 || H <= 0 || W <= 0 || Cout <= 0 || Cs < Cout || Cpad < Cout || (Cpad % 4) || (ldo % 4) ||
+                                 long ldo, int out_dtype, void* stream) {
+  if ((out_dtype != 0 && out_dtype != 2) || !g || !out || B <= 0 || H <= 0 || W <= 0 || Cout <= 0 || Cs < Cout || Cpad < Cout || (Cpad % 4) || (ldo % 4) ||
       ((uintptr_t)out & 7) || (long)B * 2 * H > 0x7fffffffL || (long)2 * W * (Cpad / 4) > 0x7fffffffL) {
     pi3_set_error("pi3_convt_scatter: bad arguments (Cpad, ldo multiples of 4)");
     return PI3_ERR_ARG;
   }
   hipLaunchKernelGGL(convt_scatter_kernel, dim3((unsigned)(B * 2 * H)), dim3(256), 0, (hipStream_t)stream, g, ldg, H, W,
-                     Cout, Cs, Cpad, (bf16_t*)out, ldo);
+                     Cout, Cs, Cpad, (bf16_t*)out, ldo, out_dtype == 2);
   return pi3_check_launch("convt_scatter");
 }
 

@@ -22,14 +22,14 @@ _vp, _i, _l, _f, _u64, _d = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_ulongl
 SIGNATURES = {
     "pi3_gemm": [_vp, _l, _vp, _l, _i, _i, _i, _i, _vp, _vp, _vp, _l, _vp, _l, _i, _i, _i, _i, _i, _vp, _l, _f, _i, _vp],
     "pi3_gemm_qkv": [_vp, _l, _vp, _l, _i, _i, _i, _vp, _vp, _l, _i, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _i, _i, _vp],
-    "pi3_attention": [_vp, _vp, _vp, _l, _l, _vp, _l, _l, _i, _i, _i, _i, _vp, _i, _vp],
+    "pi3_attention": [_vp, _vp, _vp, _l, _l, _vp, _l, _l, _i, _i, _i, _i, _i, _vp, _i, _vp],
     "pi3_attention_path_counters": [_vp],
     "pi3_layernorm": [_vp, _l, _i, _i, _vp, _vp, _f, _vp, _l, _i, _i, _i, _vp, _vp],
     "pi3_qknorm_rope": [_vp, _l, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _i, _vp],
     "pi3_rope_2d": [_vp, _vp, _i, _i, _i, _i, _l, _l, _f, _f, _i, _vp],
     "pi3_cast_rows": [_vp, _l, _vp, _l, _l, _i, _i, _vp],
     "pi3_cast_rows_pad": [_vp, _l, _i, _vp, _l, _l, _i, _i, _vp],
-    "pi3_patch_gather": [_vp, _i, _i, _i, _vp, _i, C.POINTER(_f), C.POINTER(_f), _vp],
+    "pi3_patch_gather": [_vp, _i, _i, _i, _vp, _i, _i, C.POINTER(_f), C.POINTER(_f), _vp],
     "pi3_resample_grid": [_vp, _i, _i, _i, _vp, _vp, _i, _i, _vp, _vp],
     "pi3_fill_tokens": [_vp, _i, _i, _i, _i, _i, _vp, _vp],
     "pi3_recipe_fill": [_vp, _l, _u64, _f, _f, _i, _vp],
@@ -40,11 +40,11 @@ SIGNATURES = {
     "pi3_apply_scale": [_vp, _vp, _vp, _l, _vp, _i, _vp],
     "pi3_gather_keypoints": [_vp] * 6 + [_i] * 4 + [_vp] * 7,
     "pi3_focal_shift": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp],
-    "pi3_conv3x3": [_vp, _l, _i, _i, _i, _i, _vp, _i, _vp, _vp, _l, _vp, _l, _i, _i, _vp],
+    "pi3_conv3x3": [_vp, _l, _i, _i, _i, _i, _vp, _i, _vp, _vp, _l, _vp, _l, _i, _i, _i, _vp],
     "pi3_groupnorm_stats": [_vp, _l, _i, _i, _i, _i, _vp, _vp, _l, _vp],
-    "pi3_groupnorm_apply": [_vp, _l, _i, _i, _i, _i, _i, _vp, _vp, _vp, _f, _i, _vp, _l, _vp],
+    "pi3_groupnorm_apply": [_vp, _l, _i, _i, _i, _i, _i, _vp, _vp, _vp, _f, _i, _vp, _l, _i, _vp],
     "pi3_add_rows": [_vp, _l, _vp, _l, _l, _i, _vp],
-    "pi3_convt_scatter": [_vp, _l, _i, _i, _i, _i, _i, _i, _vp, _l, _vp],
+    "pi3_convt_scatter": [_vp, _l, _i, _i, _i, _i, _i, _i, _vp, _l, _i, _vp],
     "pi3_uv_affine": [_vp, _l, _i, _i, _i, _i, _vp, _l, _i, _vp, _vp, _vp, _i, _vp],
     "pi3_resize_taps": [_vp, _l, _l, _l, _i, _vp, _vp, _vp, _vp, _i, _i, _vp, _l, _l, _l, _vp],
     "pi3_dense_vec": [_vp, _vp, _vp, _i, _i, _i, _vp, _vp],

@@ -5,7 +5,7 @@ Mirror of MoGeModel.from_pretrained / infer (moge/model/v2.py:66-97, 181-290) dr
 `model_config` dict, with every arithmetic step in C-ABI kernels: the DINOv2 encoder reuses the pi3 transformer kernels
 (vit.py), 3x3 replicate-padded convolutions run as implicit GEMMs on MFMA (pi3_conv3x3), 1x1 convolutions as pi3_gemm,
 GroupNorm / transposed-conv scatter / UV planes / resizes / remap in csrc/moge.hip, focal-shift recovery in the same LM
-kernel as the pi3 intrinsics.  Activations: NHWC fp32 [H*W, ld] + bf16 NHWC staging images (channel stride % 64 == 0).
+kernel as the pi3 intrinsics.  Activations: NHWC fp32 [H*W, ld] + 16-bit NHWC staging images (channel stride % 64 == 0).
 
 Supported config space (moge/model/modules.py:18-254, every option an UP-sampling ConvStack can carry): resamplers
 conv_transpose / pixel_shuffle / nearest / bilinear; activations relu / leaky_relu / silu / elu; res-block norms
@@ -14,8 +14,9 @@ down-sampling resamplers (pixel_unshuffle / avg_pool / max_pool) cannot occur in
 MoGeModel.forward (v2.py:141-150) and raise NotImplementedError at construction.  The released
 "Ruicheng/moge-2-vits-normal" checkpoint (weights and config) is not available offline; `from_pretrained("recipe")`
 builds SYNTHETIC_CONFIG with recipe weights, and a local model.pt ({'model_config', 'model'}) is loaded as the reference
-does (v2.py:80-95).  The reference runs this forward under fp16 autocast; here matmuls are bf16 MFMA with fp32
-accumulation and fp32 residual maps.
+does (v2.py:80-95).  The reference runs this forward under fp16 autocast (v2.py:228); so does this engine since round 5:
+IEEE-half operands on the f16 matrix-core forms with fp32 accumulation and fp32 maps between the layers (`dtype=torch.bfloat16`
+selects the bf16 forms of rounds 1-4).
 """
 from __future__ import annotations
 
@@ -271,7 +272,14 @@ class _Act:
 
 
 class MoGeEngine:
-    def __init__(self, cfg: Dict, device: str = "cuda:0", state_dict: Optional[Dict[str, torch.Tensor]] = None):
+    def __init__(self, cfg: Dict, device: str = "cuda:0", state_dict: Optional[Dict[str, torch.Tensor]] = None,
+                 dtype: torch.dtype = torch.float16):
+        """dtype: the 16-bit format of the matrix-core operands (weights, staging images, q / k / v).  torch.float16 is
+        what the reference computes in - MoGeModel.infer runs its forward under fp16 autocast (moge/model/v2.py:228) -
+        and the default: v_mfma_*_f16 at the bf16 rate, fp32 accumulation, fp32 maps between the layers (where the
+        reference's own are fp16).  torch.bfloat16 (rounds 1-4) stays selectable: 3 mantissa bits fewer, 8x the deviation."""
+        assert dtype in (torch.float16, torch.bfloat16)
+        self.dt16 = dtype
         self.cfg = cfg
         self.device = torch.device(device)
         torch.cuda.set_device(self.device)
@@ -299,17 +307,17 @@ class MoGeEngine:
         self._consts = {}
 
     @classmethod
-    def from_pretrained(cls, path: str, device: str = "cuda:0") -> "MoGeEngine":
+    def from_pretrained(cls, path: str, device: str = "cuda:0", dtype: torch.dtype = torch.float16) -> "MoGeEngine":
         """path == "recipe": synthetic config + recipe weights; otherwise a local model.pt like the reference's
         MoGeModel.from_pretrained (v2.py:80-95): {'model_config': dict, 'model': state_dict}."""
         if path == "recipe":
-            return cls(SYNTHETIC_CONFIG, device)
+            return cls(SYNTHETIC_CONFIG, device, dtype=dtype)
         ckpt = torch.load(path, map_location="cpu", weights_only=True)
-        return cls(ckpt["model_config"], device, ckpt["model"])
+        return cls(ckpt["model_config"], device, ckpt["model"], dtype=dtype)
 
     # ------------------------------------------------------------------ weight layouts
     def _install(self, name: str, t: torch.Tensor) -> None:
-        dev, bf = self.device, torch.bfloat16
+        dev, bf = self.device, self.dt16
         if name.endswith("patch_embed.proj.weight"):
             D = t.shape[0]
             w = torch.zeros(D, 640, device=dev, dtype=bf)
@@ -366,7 +374,7 @@ class MoGeEngine:
         conv=True, for a 3x3 one (_cpad).  The fp32 maps keep exact zeros in their padded columns (zero-padded weights and
         biases); columns beyond the map's row are written as zeros."""
         Cp = _cpad(a.C) if conv else _up(a.C, 64)
-        out = self._new(a.H * a.W, Cp, torch.bfloat16)
+        out = self._new(a.H * a.W, Cp, self.dt16)
         ops.cast_rows(a.t, out, rows=a.H * a.W, cols=Cp, in_cols=min(Cp, a.t.shape[1]))
         return out
 
@@ -392,7 +400,7 @@ class MoGeEngine:
         """norm + activation of a map -> bf16 NHWC staging image for the following 3x3 convolution."""
         HW, C = src.H * src.W, src.C
         Cp = _cpad(C)
-        a = self._new(HW, Cp, torch.bfloat16)
+        a = self._new(HW, Cp, self.dt16)
         if norm == "none":
             ops.groupnorm_apply(src.t, HW, C, Cp, 0, None, None, None, 1e-5, act, a)
             return a
@@ -419,7 +427,7 @@ class MoGeEngine:
         if kind == "conv_transpose":          # ConvTranspose2d(k = s = 2) as a GEMM + scatter, then Conv2d 3x3
             g = self._new(H * W, 4 * Cn)
             ops.gemm(self._to_bf16(x), self.w[p + ".0.weight"], g, M=H * W, bias=self.w[p + ".0.bias"])
-            up = self._new(4 * H * W, _cpad(Cn), torch.bfloat16)
+            up = self._new(4 * H * W, _cpad(Cn), self.dt16)
             ops.convt_scatter(g, H, W, Cn, Cn, _cpad(Cn), up)
             out = _Act(self._new(4 * H * W, _npad(Cn)), Cn, 2 * H, 2 * W)
             ops.conv3x3(up, 2 * H, 2 * W, _cpad(Cn), self.w[p + ".1.weight"], self.w[p + ".1.bias"], out.t)
@@ -427,7 +435,7 @@ class MoGeEngine:
         if kind == "pixel_shuffle":           # Conv2d(C, 4 Cn, 3) with (dy, dx, co)-major rows + the same scatter
             g = self._new(H * W, _npad(4 * Cn))
             ops.conv3x3(self._to_bf16(x, conv=True), H, W, _cpad(C), self.w[p + ".0.weight"], self.w[p + ".0.bias"], g)
-            up = self._new(4 * H * W, _cpad(Cn), torch.bfloat16)
+            up = self._new(4 * H * W, _cpad(Cn), self.dt16)
             ops.convt_scatter(g, H, W, Cn, Cn, _cpad(Cn), up)
             out = _Act(self._new(4 * H * W, _npad(Cn)), Cn, 2 * H, 2 * W)
             ops.conv3x3(up, 2 * H, 2 * W, _cpad(Cn), self.w[p + ".2.weight"], self.w[p + ".2.bias"], out.t)
@@ -448,7 +456,7 @@ class MoGeEngine:
         ld = x.t.shape[1]
         big = self._new(4 * H * W, ld)
         ops.resize_taps(x.t, (1, W * ld, ld), C, ys, yw, xs, xw, 2 * H, 2 * W, big, (1, 2 * W * ld, ld))
-        a = self._new(4 * H * W, _cpad(C), torch.bfloat16)
+        a = self._new(4 * H * W, _cpad(C), self.dt16)
         ops.cast_rows(big, a, rows=4 * H * W, cols=_cpad(C), in_cols=C if C % 4 == 0 else _up(C, 4))
         out = _Act(self._new(4 * H * W, _npad(Cn)), Cn, 2 * H, 2 * W)
         ops.conv3x3(a, 2 * H, 2 * W, _cpad(C), self.w[p + ".1.weight"], self.w[p + ".1.bias"], out.t)
@@ -524,7 +532,7 @@ class MoGeEngine:
         img14 = torch.empty(1, 3, 14 * bh, 14 * bw, device=dev)
         ops.resize_taps(image.contiguous(), (H * W, W, 1), 3, ys, yw, xs, xw, 14 * bh, 14 * bw, img14,
                         (14 * bh * 14 * bw, 14 * bw, 1))
-        patches = self._new(P, 640, torch.bfloat16)
+        patches = self._new(P, 640, self.dt16)
         ops.patch_gather(img14, patches, IMAGE_MEAN, IMAGE_STD)
         key = ("pos", bh, bw)
         if key not in self._consts:
@@ -549,8 +557,8 @@ class MoGeEngine:
         ops.gemm(patches, w["encoder.backbone.patch_embed.proj.weight"], x, M=P,
                  bias=w["encoder.backbone.patch_embed.proj.bias"], rpg=P, gstride=T, goff=1 + nreg, addtab=pos_patch)
         ops.fill_tokens(x, 1, T, 0, special)
-        bufs = (self._new(T, D, torch.bfloat16), self._new(T, 3 * D, torch.bfloat16), self._new(T, D, torch.bfloat16),
-                self._new(T, 4 * D, torch.bfloat16), self._new(1, heads, torch.float32).view(-1))
+        bufs = (self._new(T, D, self.dt16), self._new(T, 3 * D, self.dt16), self._new(T, D, self.dt16),
+                self._new(T, 4 * D, self.dt16), self._new(1, heads, torch.float32).view(-1))
         n_int = cfg["encoder"]["intermediate_layers"]
         take = list(range(bb["depth"] - n_int, bb["depth"])) if isinstance(n_int, int) else list(n_int)
         Cenc = cfg["encoder"]["dim_out"]

@@ -13,7 +13,8 @@ import torch
 
 from . import lib as _L
 
-BF16, F32 = 0, 1
+BF16, F32, F16 = 0, 1, 2
+_16BIT = (torch.bfloat16, torch.float16)
 ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2
 QSCALE = 0.125 * math.log2(math.e)  # head_dim^-0.5 * log2(e), folded into q (attn.hip works in the exp2 domain)
 
@@ -23,6 +24,8 @@ def _dt(t: torch.Tensor) -> int:
         return BF16
     if t.dtype == torch.float32:
         return F32
+    if t.dtype == torch.float16:       # IEEE half: the MoGe path (the reference runs it under fp16 autocast)
+        return F16
     raise _L.Pi3HipError(f"unsupported dtype {t.dtype}")
 
 
@@ -75,18 +78,19 @@ def attention(qkv: torch.Tensor, out: torch.Tensor, B: int, S: int, H: int,
     k2max: f32 [B*H] already holding max_s |k|^2 per (batch, head) (written by the fused qkv epilogue); None -> a
     workspace is taken from torch's allocator and the call fills it with its own pre-pass."""
     lib = _L.load()
-    assert qkv.dtype == torch.bfloat16 and out.dtype == torch.bfloat16 and qkv.dim() == 2 and out.dim() == 2
+    assert qkv.dtype in _16BIT and out.dtype == qkv.dtype and qkv.dim() == 2 and out.dim() == 2
     assert qkv.shape[0] >= B * S and qkv.shape[1] == 3 * H * 64 and qkv.stride(1) == 1 and out.stride(1) == 1
     ts = qkv.stride(0)
     base = qkv.data_ptr()
     ready = 1
     if k2max is None:
         ready = 0
-        k2max = torch.empty(B * H, device=qkv.device, dtype=torch.float32) if S >= 4096 else None
+        k2max = torch.empty(B * H, device=qkv.device, dtype=torch.float32) \
+            if S >= 4096 and qkv.dtype == torch.bfloat16 else None
     else:
         assert k2max.dtype == torch.float32 and k2max.numel() >= B * H and k2max.is_contiguous()
     rc = lib.pi3_attention(base, base + 2 * H * 64, base + 4 * H * 64, ts, S * ts, out.data_ptr(), out.stride(0),
-                           S * out.stride(0), B, S, H, 64, _L.ptr(k2max), ready, _L.stream_ptr())
+                           S * out.stride(0), B, S, H, 64, _dt(qkv), _L.ptr(k2max), ready, _L.stream_ptr())
     _L.check(rc, "pi3_attention")
     return out
 
@@ -197,11 +201,11 @@ def cast_rows(x: torch.Tensor, out: torch.Tensor, rows: Optional[int] = None, co
 def patch_gather(imgs: torch.Tensor, out: torch.Tensor, mean, std) -> torch.Tensor:
     """imgs: [F, 3, H, W] f32 -> out: [F*P, KP] bf16 normalised patch rows."""
     lib = _L.load()
-    assert imgs.dtype == torch.float32 and imgs.is_contiguous() and out.dtype == torch.bfloat16 and out.is_contiguous()
+    assert imgs.dtype == torch.float32 and imgs.is_contiguous() and out.dtype in _16BIT and out.is_contiguous()
     F, _, H, W = imgs.shape
     m3 = (C.c_float * 3)(*[float(v) for v in mean])
     s3 = (C.c_float * 3)(*[float(v) for v in std])
-    rc = lib.pi3_patch_gather(imgs.data_ptr(), F, H, W, out.data_ptr(), out.shape[1], m3, s3, _L.stream_ptr())
+    rc = lib.pi3_patch_gather(imgs.data_ptr(), F, H, W, out.data_ptr(), out.shape[1], _dt(out), m3, s3, _L.stream_ptr())
     _L.check(rc, "pi3_patch_gather")
     return out
 
@@ -227,7 +231,7 @@ def fill_tokens(x: torch.Tensor, F: int, T: int, t0: int, vals: torch.Tensor) ->
 
 def recipe_fill(out: torch.Tensor, seed: int, offset: float, scale: float) -> torch.Tensor:
     lib = _L.load()
-    assert out.is_contiguous()
+    assert out.is_contiguous() and out.dtype != torch.float16      # bf16 / f32 only (half weights: fill f32, then .half())
     rc = lib.pi3_recipe_fill(out.data_ptr(), out.numel(), C.c_ulonglong(seed), float(offset), float(scale), _dt(out),
                              _L.stream_ptr())
     _L.check(rc, "pi3_recipe_fill")
@@ -409,10 +413,10 @@ def conv3x3(img: torch.Tensor, H: int, W: int, C: int, wgt: torch.Tensor, bias: 
     """img bf16 NHWC [H*W, ldc] (one image), wgt bf16 [N, 9*C] (C % 64 == 0) or [N, 10*32] (C == 32: ten tap slots, the
     tenth zero); out [H*W, >=N] f32/bf16."""
     lib = _L.load()
-    assert img.dtype == torch.bfloat16 and wgt.dtype == torch.bfloat16 and wgt.shape[1] == (320 if C == 32 else 9 * C)
+    assert img.dtype in _16BIT and wgt.dtype == img.dtype and wgt.shape[1] == (320 if C == 32 else 9 * C)
     rc = lib.pi3_conv3x3(img.data_ptr(), img.stride(0), 1, H, W, C, wgt.data_ptr(), wgt.shape[0], _L.ptr(bias),
                          _L.ptr(resid), resid.stride(0) if resid is not None else 0, out.data_ptr(), out.stride(0),
-                         _dt(out), act, _L.stream_ptr())
+                         _dt(img), _dt(out), act, _L.stream_ptr())
     _L.check(rc, "pi3_conv3x3")
     return out
 
@@ -433,9 +437,9 @@ ACT_LEAKY, ACT_SILU, ACT_ELU = 3, 4, 5
 def groupnorm_apply(x, HW, C, Cpad, G, stats, gamma, beta, eps, act, out) -> None:
     """G = 0: no normalisation; gamma / beta None: no affine (InstanceNorm2d)."""
     lib = _L.load()
-    assert out.dtype == torch.bfloat16 and out.shape[1] >= Cpad
+    assert out.dtype in _16BIT and out.shape[1] >= Cpad
     rc = lib.pi3_groupnorm_apply(x.data_ptr(), x.stride(0), 1, HW, C, Cpad, G, _L.ptr(stats), _L.ptr(gamma),
-                                 _L.ptr(beta), float(eps), act, out.data_ptr(), out.stride(0), _L.stream_ptr())
+                                 _L.ptr(beta), float(eps), act, out.data_ptr(), out.stride(0), _dt(out), _L.stream_ptr())
     _L.check(rc, "pi3_groupnorm_apply")
 
 
@@ -448,9 +452,9 @@ def add_rows(x: torch.Tensor, y: torch.Tensor, rows: int, C: int) -> None:
 
 def convt_scatter(g: torch.Tensor, H: int, W: int, Cout: int, Cs: int, Cpad: int, out: torch.Tensor) -> None:
     lib = _L.load()
-    assert g.dtype == torch.float32 and out.dtype == torch.bfloat16
+    assert g.dtype == torch.float32 and out.dtype in _16BIT
     rc = lib.pi3_convt_scatter(g.data_ptr(), g.stride(0), 1, H, W, Cout, Cs, Cpad, out.data_ptr(), out.stride(0),
-                               _L.stream_ptr())
+                               _dt(out), _L.stream_ptr())
     _L.check(rc, "pi3_convt_scatter")
 
 

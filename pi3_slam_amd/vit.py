@@ -22,10 +22,14 @@ def run_block(w: Dict[str, torch.Tensor], prefix: str, x: torch.Tensor, S: int, 
     k2buf = bufs[4] if len(bufs) > 4 else None
     ops.layernorm(x, w[f"{prefix}.norm1.weight"], w[f"{prefix}.norm1.bias"], xn, eps, rows=S)
     fused = rope or qk_norm
+    assert xn.dtype == torch.bfloat16 or not fused, "the fused q/k epilogue (pi3 decoder) is bf16 only"
     # encoder blocks (no q/k norm, no RoPE; pi3/models/dinov2/layers/block.py:88-113) take the fused epilogue as well where
     # the 256x256 kernel applies, for its max |k|^2 alone: the frame-wise attention then runs its bounded-score loop
     # (0.22 ms instead of 0.27-0.34 ms per launch at 100 x 643 tokens) and falls back per wave where the bound fails
-    k2_only = (not fused) and attn_S >= 256 and S >= 1024 and (3 * D) % 256 == 0 and D % 64 == 0
+    # (bf16 only: an IEEE-half block - MoGe under the reference's fp16 autocast - runs the plain projection and the
+    # online-max attention loop, ops.attention / pi3_attention dtype 2)
+    k2_only = (not fused) and attn_S >= 256 and S >= 1024 and (3 * D) % 256 == 0 and D % 64 == 0 \
+        and xn.dtype == torch.bfloat16
     k2max = None
     if fused or k2_only:
         # q/k LayerNorm(64) + RoPE-2D + softmax scale (+ max |k|^2 per (batch, head) for the attention's bounded-score loop) ride in the qkv

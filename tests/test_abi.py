@@ -38,7 +38,7 @@ def test_ctypes_table_matches_header(built_lib):
 def test_loads_without_gpu_and_reports_version(built_lib):
     from pi3_slam_amd import lib
     dll = lib.load(require_gpu=False)
-    assert dll.pi3_abi_version() == 5
+    assert dll.pi3_abi_version() == 6
     assert dll.pi3_device_count() >= 0
     assert isinstance(dll.pi3_last_error(), bytes)
 

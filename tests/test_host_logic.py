@@ -45,6 +45,37 @@ def test_grid_keypoints_bit_exact(name, max_kp, seed, tag):
     assert kp.dtype == torch.float32 and np.array_equal(kp.numpy(), g[f"kp_{tag}"])
 
 
+def test_headline_chunk_keypoints_colours_and_layout_of_the_full_size_reference_run():
+    """tests/golden/pi3_full.npz is the reference's own `_process_single_chunk` at the headline size (100 frames, 308 x
+    406, K = 200; oracle/gen_golden_full.py).  What does not need the network, on the CPU: the extractor with the
+    reference's RNG behaviour (seed=None: the global generator) reproduces all 100 per-frame random subsets of the
+    234-point grid bit for bit; the oracle's colour sampler returns the stored colours; the chunk's schema is the one
+    SURVEY.md §8(b) records."""
+    from oracle.gen_golden import golden_images
+    g = np.load(os.path.join(GOLDEN, "pi3_full.npz"))
+    N, H, W, K = (int(v) for v in g["shape"])
+    assert (N, H, W, K) == (100, 308, 406, 200)
+    ext = create_keypoint_extractor("grid", K, device="cpu", seed=None)
+    torch.manual_seed(int(g["seed"][0]))
+    kp = ext.extract(torch.zeros(N, 3, H, W))["keypoints"]
+    ref = torch.from_numpy(g["c_keypoints"]).view(torch.float16)
+    assert torch.equal(kp.half().view(torch.int16), ref.view(torch.int16))
+    assert len({tuple(map(tuple, kp[i].tolist())) for i in range(3)}) == 3          # the subsets differ per frame
+    col = post_ref.keypoint_colors(golden_images("pi3_full", 1, N, H, W)[0], kp)
+    assert torch.equal(torch.as_tensor(col).to(torch.float16).view(torch.int16),
+                       torch.from_numpy(g["c_colors"]).view(torch.float16).view(torch.int16))
+    schema = set(g["schema"].tolist())
+    for want in ("points:float16:100x200x3", "local_points:float16:100x200x3", "conf:float16:100x200x1",
+                 "masks:bool:100x200x1", "camera_poses:float32:100x4x4", "keypoints:float16:100x200x2",
+                 "descriptors:float16:100x200x128", "scores:float16:100x200", "colors:float16:100x200x3",
+                 "intrinsics:float32:100x3x3", "camera_params.focal:float32:1x100", "original_width:int",
+                 "original_height:int", "image_paths:list", "_metrics:dict"):
+        assert want in schema, (want, sorted(schema))
+    # poses the reference returned are rigid
+    P = torch.from_numpy(g["camera_poses"])[0].double()
+    assert (P[:, :3, :3] @ P[:, :3, :3].transpose(-1, -2) - torch.eye(3, dtype=torch.float64)).abs().max() < 1e-5
+
+
 def test_keypoint_factory_and_north_star_grid():
     ext = create_keypoint_extractor("aliked", 200)      # falls back to grid like the reference when lightglue is absent
     assert isinstance(ext, GridKeypointExtractor)

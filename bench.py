@@ -493,6 +493,13 @@ def main(args) -> None:
                          "softmax_paths": softmax_paths(path_counters, online_max, attn_flops)},
             "stages_ms": {"stage_in_h2d_resize": mean("stage_in_s"), "pi3_forward": mean("infer_s"),
                           "post_masks_scale_intrinsics_gather": mean("post_s"), "align_host_wait": mean("align_host_s"),
+                          # the consumer-side wall-clock gate (moved here from the correctness suite):
+                          # the alignment of chunk k-1 runs beside the forward of chunk k and must not wait for it
+                          "align_host_wait_median": 1e3 * sorted(s.get("align_host_s", 0.0) for s in stats)[len(stats) // 2],
+                          "align_host_wait_max": 1e3 * max(s.get("align_host_s", 0.0) for s in stats),
+                          "align_host_wait_over_10ms": sum(1 for s in stats if s.get("align_host_s", 0.0) > 0.010),
+                          "align_host_wait_bound": "median < 5 ms and no sample > 10 ms (0 of 198 in gpurun_out/r5c/stall3.log; "
+                                                   "a violated rule shows as ~0.6 x pi3_forward on every chunk)",
                           "note": "GPU-event times per chunk (copy stream / compute stream); stages of consecutive chunks "
                                   "overlap, so they do not add up to ms_per_step"},
         }

@@ -101,8 +101,10 @@ int pi3_qknorm_rope(void* qkv, long rows, int H, int T, const int* pos, const fl
 
 /* The reference's one native FFI entry under its own contract: `curope.rope_2d(tokens, positions, base, fwd)`
  * (pi3/models/curope/curope.cpp:49-68, kernels.cu:17-108), what `cuRoPE2D.forward` (curope2d.py:33-40) calls.
- * In place on tokens (B, N, H, D): element (b, n, h, d) at tokens[b*stride_b + n*stride_n + h*D + d] (the last two
- * dims contiguous as kernels.cu:91 demands; stride_n = 0 -> H*D, stride_b = 0 -> N*stride_n: a contiguous tensor);
+ * In place on tokens (B, N, H, D): element (b, n, h, d) at tokens[b*stride_b + n*stride_n + h*stride_h + d] (the last
+ * dim contiguous; 0 for a stride = the contiguous default D, H*stride_h, N*stride_n.  kernels.cu:91 also demands
+ * stride_h == D, which excludes the transposed view of a contiguous (B, heads, N, D) tensor that `cuRoPE2D.forward`
+ * produces behind pi3's q_norm: accepted here);
  * positions int64 (B, N, 2) = (y, x), contiguous; D % 4 == 0.  With Q = D/4 a token vector is [u_Y | v_Y | u_X | v_X]:
  *   freq = pos * fwd / base^(d/Q);   u' = u cos(freq) - v sin(freq);   v' = v cos(freq) + u sin(freq)     (fp32)
  * fwd = F0 (1.0) rotates forward, -F0 is the reference's backward pass = the inverse rotation.
@@ -110,7 +112,7 @@ int pi3_qknorm_rope(void* qkv, long rows, int H, int T, const int* pos, const fl
  * The hot path does not call it (the rotation rides in pi3_gemm_qkv's epilogue); it exists so that a `cuRoPE2D`
  * caller binds to this library unchanged. */
 int pi3_rope_2d(void* tokens, const long* positions, int B, int N, int H, int D, long stride_b, long stride_n,
-                float base, float fwd, int dtype, void* stream);
+                long stride_h, float base, float fwd, int dtype, void* stream);
 
 /* f32 -> bf16/f32 strided row copy (concat of the last two decoder outputs, pi3.py:168-171). */
 int pi3_cast_rows(const float* in, long ldi, void* out, long ldo, long rows, int cols, int out_dtype, void* stream);

@@ -10,6 +10,7 @@ from typing import Dict, List, Optional, Tuple
 import torch
 
 from . import ops
+from .hostmem import pinned_copy
 
 
 def create_view_graph_matches(chunk_size: int, overlap_size: int) -> List[Tuple[int, int]]:
@@ -32,22 +33,30 @@ def upload(t: torch.Tensor, device, dtype: Optional[torch.dtype] = None) -> torc
     alive until the copy has run."""
     if t.device.type != "cpu" or torch.device(device).type == "cpu":
         return t.to(device) if dtype is None else t.to(device, dtype)
-    if dtype is not None and t.dtype != dtype:
-        t = t.to(dtype)
+    # No ATen CPU operator on this path (round 5).  A dtype conversion or copy_ of >= 32 768 elements and every advanced
+    # index open an OpenMP parallel region; on a box whose CPU share is a cgroup quota (16 of the host's cores) the
+    # region's threads - torch sizes its pool by the HOST's core count - were seen to stall the caller for 85-110 ms,
+    # one alignment in 25 (tools/dev_host_stall.py: 6 of 148 alignments, every one inside `t.to(float32)` of a
+    # (60, 200, 3) tensor or `t[idx]`; gpurun_out/r5c/stall2.log).  So: a plain memcpy into the pinned staging block,
+    # the asynchronous copy, and the conversion on the device (exact for the widening conversions used here).
     if not t.is_pinned():
-        p = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
-        p.copy_(t)
-        t = p
-    return t.to(device, non_blocking=True)
+        t = pinned_copy(t)
+    out = t.to(device, non_blocking=True)
+    return out if dtype is None or out.dtype == dtype else out.to(dtype)
 
 
 def _overlap_block(chunk: Dict[str, torch.Tensor], frames: List[int], device) -> Dict[str, torch.Tensor]:
-    idx = torch.tensor(frames, dtype=torch.long)
     src = _chunk_frame(chunk)
     out = {}
+    consecutive = all(b == a + 1 for a, b in zip(frames, frames[1:]))      # the overlap views of a chunk pair always are
     for k in ("points", "keypoints", "masks"):
         t = src[k] if k == "points" else chunk[k]
-        out[k] = upload(t[idx.to(t.device)], device).contiguous()
+        if consecutive:          # a slice of the leading axis: contiguous memory, no index operator on the host
+            out[k] = upload(t[frames[0]: frames[0] + len(frames)], device).contiguous()
+        elif t.device.type == "cpu":       # a ragged view graph: gather on the device
+            out[k] = upload(t, device)[torch.tensor(frames, dtype=torch.long, device=device)].contiguous()
+        else:
+            out[k] = t[torch.tensor(frames, dtype=torch.long, device=t.device)].contiguous()
     return out
 
 

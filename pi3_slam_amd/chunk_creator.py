@@ -33,6 +33,7 @@ from torch.utils.data import DataLoader
 from . import ops
 from .engine import Pi3Engine
 from .image_io import ChunkImageDataset, ThreadedChunkLoader, calculate_target_size, ingest_frames_device
+from .hostmem import clone_host, full_host, zeros_host
 from .keypoints import create_keypoint_extractor
 from .undistortion import create_undistortion_maps
 from .weights import Pi3Config
@@ -376,13 +377,10 @@ class OfflineChunkCreator:
                 for k in ("points", "local_points", "conf", "keypoints", "colors"):
                     out[k] = g[k]
                 out["masks"] = g["masks"].view(torch.uint8)
-                if kp.get("constant"):     # zeros / ones: fp16 copies of cached constants (a memcpy, no conversion)
-                    key = ("kp_const", tuple(kp["descriptors"].shape))
-                    if key not in self.__dict__.setdefault("_host_consts", {}):
-                        self._host_consts[key] = (torch.zeros(kp["descriptors"].shape, dtype=torch.float16),
-                                                  torch.ones(kp["scores"].shape, dtype=torch.float16))
-                    d16, s16 = self._host_consts[key]
-                    host["descriptors"], host["scores"] = d16.clone(), s16.clone()
+                if kp.get("constant"):     # all-zero descriptors, all-one scores (keypoint_extraction.py:150-151)
+                    # fresh calloc'ed zeros / a small filled array per chunk (callers own and may mutate their chunk)
+                    host["descriptors"] = zeros_host(kp["descriptors"].shape, torch.float16)
+                    host["scores"] = full_host(kp["scores"].shape, 1.0, torch.float16)
                 else:
                     host["descriptors"] = kp["descriptors"].to(torch.float16)
                     host["scores"] = kp["scores"].to(torch.float16)
@@ -428,7 +426,7 @@ class OfflineChunkCreator:
         fl.packed = None
         got: Dict[str, torch.Tensor] = {}
         for k, dt, shape, off, nbytes in fl.layout:
-            got[k] = pinned[off:off + nbytes].clone().view(dt).reshape(shape)
+            got[k] = clone_host(pinned[off:off + nbytes]).view(dt).reshape(shape)      # memcpy, no ATen operator (hostmem.py)
         self._pinned_pool.setdefault(pinned.numel(), []).append(pinned)
         N = fl.meta["num_frames"]
         infer_s = max(1e-6, fl.timing["f0"].elapsed_time(fl.timing["f1"]) / 1e3)

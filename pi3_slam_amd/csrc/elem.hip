@@ -192,9 +192,12 @@ extern "C" int pi3_qknorm_rope(void* qkv, long rows, int H, int T, const int* po
 // ---------------------------------------------------------------------------------------------------------------
 // pi3_rope_2d: the reference's ONE native FFI entry, `curope.rope_2d(tokens, positions, base, fwd)`
 // (pi3/models/curope/curope.cpp:49-68; device kernel kernels.cu:17-82; launch checks :85-108), with its contract:
-// in place on tokens (B, N, H, D), element (b, n, h, d) at tok[b*stride_b + n*stride_n + h*D + d] (the reference's
-// checks: stride(3) == 1, stride(2) == D, kernels.cu:91; `cuRoPE2D.forward` hands it the transposed view of a
-// (B, H, N, D) tensor or a slice of the packed qkv, so the two outer strides are free), positions int64 (B, N, 2) =
+// in place on tokens (B, N, H, D), element (b, n, h, d) at tok[b*stride_b + n*stride_n + h*stride_h + d].  The reference's
+// kernel walks a PackedTensorAccessor (all four strides free) but its launch check demands stride(3) == 1 and
+// stride(2) == D (kernels.cu:91) - true for q / k slices of a packed qkv, NOT for the transposed view of a contiguous
+// (B, heads, N, D) tensor, which is what `cuRoPE2D.forward` passes after pi3's q_norm / k_norm (attention.py:330-334):
+// there the CUDA original raises.  This entry takes the three outer strides as they are (stride(3) == 1 only), so it
+// is a superset of what the reference accepts.  positions int64 (B, N, 2) =
 // (y, x) contiguous, D % 4 == 0.  One token vector = [u_Y (Q) | v_Y (Q) | u_X (Q) | v_X (Q)], Q = D/4:
 //   freq = pos * (fwd / base^(d/Q));  u' = u cos - v sin;  v' = v cos + u sin        (fp32 arithmetic, any storage)
 // fwd = F0 forward, -F0 for the backward pass (curope2d.py:24-29), i.e. the inverse rotation.
@@ -203,7 +206,8 @@ extern "C" int pi3_qknorm_rope(void* qkv, long rows, int H, int T, const int* po
 // ---------------------------------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void rope2d_kernel(T* __restrict__ tok, const long* __restrict__ pos, long ntok, int N,
-                                                     int H, int D, long stride_b, long stride_n, float base, float fwd) {
+                                                     int H, int D, long stride_b, long stride_n, long stride_h, float base,
+                                                     float fwd) {
   const int half = D >> 1, Q = D >> 2;
   const long g = (long)blockIdx.x * 256 + threadIdx.x;
   const long token = g / half;
@@ -215,7 +219,7 @@ __global__ __launch_bounds__(256) void rope2d_kernel(T* __restrict__ tok, const 
   float sn, cs;
   sincosf(freq, &sn, &cs);
   T* p = tok + b * stride_b + n * stride_n + X * 2 * Q + d;
-  for (int h = 0; h < H; ++h, p += D) {
+  for (int h = 0; h < H; ++h, p += stride_h) {
     const float u = (float)p[0], v = (float)p[Q];
     p[0] = (T)(u * cs - v * sn);
     p[Q] = (T)(v * cs + u * sn);
@@ -223,14 +227,15 @@ __global__ __launch_bounds__(256) void rope2d_kernel(T* __restrict__ tok, const 
 }
 
 extern "C" int pi3_rope_2d(void* tokens, const long* positions, int B, int N, int H, int D, long stride_b, long stride_n,
-                           float base, float fwd, int dtype, void* stream) {
-  if (stride_n == 0) stride_n = (long)H * D;
+                           long stride_h, float base, float fwd, int dtype, void* stream) {
+  if (stride_h == 0) stride_h = D;
+  if (stride_n == 0) stride_n = (long)H * stride_h;
   if (stride_b == 0) stride_b = (long)N * stride_n;
   // the reference's TORCH_CHECKs (curope.cpp:54-59, kernels.cu:91-94) as argument errors
-  if (!tokens || !positions || B <= 0 || N <= 0 || H <= 0 || D <= 0 || (D & 3) || stride_n < (long)H * D ||
-      !(base > 0.0f) || dtype < 0 || dtype > 2) {
+  if (!tokens || !positions || B <= 0 || N <= 0 || H <= 0 || D <= 0 || (D & 3) || stride_h < D || stride_n <= 0 ||
+      stride_b <= 0 || !(base > 0.0f) || dtype < 0 || dtype > 2) {
     pi3_set_error("pi3_rope_2d: bad arguments B=%d N=%d H=%d D=%d (token dim must be multiple of 4) stride_b=%ld "
-                  "stride_n=%ld base=%g dtype=%d", B, N, H, D, stride_b, stride_n, (double)base, dtype);
+                  "stride_n=%ld stride_h=%ld base=%g dtype=%d", B, N, H, D, stride_b, stride_n, stride_h, (double)base, dtype);
     return PI3_ERR_ARG;
   }
   const long ntok = (long)B * N, work = ntok * (D >> 1);
@@ -238,13 +243,13 @@ extern "C" int pi3_rope_2d(void* tokens, const long* positions, int B, int N, in
   hipStream_t s = (hipStream_t)stream;
   if (dtype == 0)
     hipLaunchKernelGGL(rope2d_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, (bf16_t*)tokens, positions, ntok, N, H, D,
-                       stride_b, stride_n, base, fwd);
+                       stride_b, stride_n, stride_h, base, fwd);
   else if (dtype == 1)
     hipLaunchKernelGGL(rope2d_kernel<float>, dim3(blocks), dim3(256), 0, s, (float*)tokens, positions, ntok, N, H, D,
-                       stride_b, stride_n, base, fwd);
+                       stride_b, stride_n, stride_h, base, fwd);
   else
     hipLaunchKernelGGL(rope2d_kernel<_Float16>, dim3(blocks), dim3(256), 0, s, (_Float16*)tokens, positions, ntok, N, H,
-                       D, stride_b, stride_n, base, fwd);
+                       D, stride_b, stride_n, stride_h, base, fwd);
   return pi3_check_launch("rope_2d");
 }
 

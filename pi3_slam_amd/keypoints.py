@@ -12,6 +12,8 @@ from typing import Dict, Optional
 import numpy as np
 import torch
 
+from .hostmem import full_host, zeros_host
+
 
 class GridKeypointExtractor:
     def __init__(self, max_num_keypoints: int = 512, grid_spacing: Optional[int] = None, device: str = "cuda",
@@ -66,7 +68,9 @@ class GridKeypointExtractor:
         K = keypoints.shape[1]
         # "constant": descriptors are all zero and scores all one (keypoint_extraction.py:150-151); the chunk creator
         # then writes its fp16 copies from cached constants instead of converting 2.5 M floats per chunk on the host
-        return dict(keypoints=keypoints, descriptors=torch.zeros(N, K, 128), scores=torch.ones(N, K), constant=True)
+        # (calloc'ed / numpy-filled: a torch.zeros of 2.5 M floats per chunk is an OpenMP region on the launch path, hostmem.py)
+        return dict(keypoints=keypoints, descriptors=zeros_host((N, K, 128), torch.float32),
+                    scores=full_host((N, K), 1.0, torch.float32), constant=True)
 
 
 def create_keypoint_extractor(keypoint_type: str = "grid", max_num_keypoints: int = 512,

@@ -26,7 +26,7 @@ SIGNATURES = {
     "pi3_attention_path_counters": [_vp],
     "pi3_layernorm": [_vp, _l, _i, _i, _vp, _vp, _f, _vp, _l, _i, _i, _i, _vp, _vp],
     "pi3_qknorm_rope": [_vp, _l, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _i, _vp],
-    "pi3_rope_2d": [_vp, _vp, _i, _i, _i, _i, _l, _l, _f, _f, _i, _vp],
+    "pi3_rope_2d": [_vp, _vp, _i, _i, _i, _i, _l, _l, _l, _f, _f, _i, _vp],
     "pi3_cast_rows": [_vp, _l, _vp, _l, _l, _i, _i, _vp],
     "pi3_cast_rows_pad": [_vp, _l, _i, _vp, _l, _l, _i, _i, _vp],
     "pi3_patch_gather": [_vp, _i, _i, _i, _vp, _i, _i, C.POINTER(_f), C.POINTER(_f), _vp],

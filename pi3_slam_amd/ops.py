@@ -135,9 +135,10 @@ _ROPE_DT = {torch.bfloat16: 0, torch.float32: 1, torch.float16: 2}
 
 def rope_2d(tokens: torch.Tensor, positions: torch.Tensor, base: float, fwd: float) -> None:
     """`curope.rope_2d(tokens, positions, base, fwd)` (pi3/models/curope/curope.cpp:49-68): IN PLACE on tokens
-    (B, N, H, D) - any outer strides, last two dims contiguous - with positions (B, N, 2) int64 = (y, x).  The argument
+    (B, N, H, D) - any strides with the last dim contiguous - with positions (B, N, 2) int64 = (y, x).  The argument
     checks and their messages are the reference's TORCH_CHECKs (curope.cpp:54-59, kernels.cu:11-14, 91-94), raised as
-    RuntimeError like a failing TORCH_CHECK is."""
+    RuntimeError like a failing TORCH_CHECK is; one is relaxed: kernels.cu:91 also wants stride(2) == D, which the
+    transposed view `cuRoPE2D.forward` makes of a contiguous (B, heads, N, D) tensor does not have."""
     lib = _L.load()
     if tokens.dim() != 4:
         raise RuntimeError("tokens must have 4 dimensions")
@@ -154,7 +155,7 @@ def rope_2d(tokens: torch.Tensor, positions: torch.Tensor, base: float, fwd: flo
     if not tokens.is_cuda:
         raise _L.Pi3HipError("pi3_rope_2d runs on the GPU only (the reference's rope_2d_cpu is restated in oracle/)")
     B, N, H, D = tokens.shape
-    if tokens.stride(3) != 1 or tokens.stride(2) != D:
+    if tokens.stride(3) != 1:
         raise RuntimeError("tokens are not contiguous")
     if not positions.is_contiguous():
         raise RuntimeError("positions are not contiguous")
@@ -163,7 +164,7 @@ def rope_2d(tokens: torch.Tensor, positions: torch.Tensor, base: float, fwd: flo
     if tokens.dtype not in _ROPE_DT or positions.dtype != torch.int64:
         raise RuntimeError(f"rope_2d: unsupported dtypes {tokens.dtype} / {positions.dtype}")
     rc = lib.pi3_rope_2d(tokens.data_ptr(), positions.data_ptr(), B, N, H, D, tokens.stride(0), tokens.stride(1),
-                         float(base), float(fwd), _ROPE_DT[tokens.dtype], _L.stream_ptr())
+                         tokens.stride(2), float(base), float(fwd), _ROPE_DT[tokens.dtype], _L.stream_ptr())
     _L.check(rc, "pi3_rope_2d")
 
 

@@ -270,11 +270,11 @@ def test_rope_2d_ffi_entry_against_the_reference_vectors(dev, tag):
     for bad, msg in ((lambda: ops.rope_2d(t[0], posd, 100.0, 1.0), "tokens must have 4 dimensions"),
                      (lambda: ops.rope_2d(t.transpose(1, 2), posd[:, :-1], 100.0, 1.0), "seq_length differs"),
                      (lambda: ops.rope_2d(t.transpose(1, 2), posd[..., :1], 100.0, 1.0), "positions.shape[2]"),
-                     (lambda: ops.rope_2d(t, posd[:, :Hh], 100.0, 1.0), "tokens are not contiguous"),
+                     (lambda: ops.rope_2d(t.transpose(1, 2).transpose(2, 3), posd, 100.0, 1.0), "tokens are not contiguous"),
                      (lambda: ops.rope_2d(t.transpose(1, 2)[..., :D - 2].contiguous(), posd, 100.0, 1.0), "multiple of 4")):
         with pytest.raises(RuntimeError, match=msg.replace("[", r"\[").replace("]", r"\]")):
             bad()
-    assert lib.load().pi3_rope_2d(None, None, 1, 1, 1, 6, 0, 0, 100.0, 1.0, 1, None) == -1      # C-ABI level: PI3_ERR_ARG
+    assert lib.load().pi3_rope_2d(None, None, 1, 1, 1, 6, 0, 0, 0, 100.0, 1.0, 1, None) == -1      # C-ABI level: PI3_ERR_ARG
     torch.cuda.synchronize()
 
 

@@ -287,8 +287,14 @@ def main(args) -> None:
         return launch_check(args)
     ndev = torch.cuda.device_count()
     backend = os.environ.get("PI3_DIST_BACKEND", "nccl")   # "gloo" only to rehearse the N > 1 logic on a 1-GPU box
-    dev = torch.device(f"cuda:{local_rank % max(1, ndev) if backend == 'gloo' else local_rank}")
-    torch.cuda.set_device(dev)
+    # PI3_BENCH_STUB=1 (tests only, gloo only): every GPU object replaced by tests/bench_stub.py so that THIS function's
+    # N > 1 control flow runs on a box without a GPU; the line then says "stub": true and is not a measurement
+    stub = os.environ.get("PI3_BENCH_STUB") == "1"
+    if stub and backend != "gloo":
+        raise SystemExit("PI3_BENCH_STUB=1 is a CPU rehearsal of the control flow: it needs PI3_DIST_BACKEND=gloo")
+    dev = None if stub else torch.device(f"cuda:{local_rank % max(1, ndev) if backend == 'gloo' else local_rank}")
+    if not stub:
+        torch.cuda.set_device(dev)
     # PI3_DIST_FORCE=1: build the process group and take the wave-alignment path even with ONE rank - a 1-rank RCCL group
     # is the only way to run the nccl branch of this file (device-resident boundary blocks, all-gathers, comm record) on
     # a one-GPU box; the line then carries `comm` like an N > 1 line (tests/test_pipeline_gpu.py)
@@ -323,15 +329,20 @@ def main(args) -> None:
     from pi3_slam_amd.weights import Pi3Config
 
     cfg = Pi3Config()
-    engine = Pi3Engine(cfg, str(dev))
     moge = None
-    try:
-        from pi3_slam_amd.moge import MoGeEngine
-        if not args.no_moge:
-            moge = MoGeEngine.from_pretrained("recipe", str(dev))
-    except Exception as e:  # noqa: BLE001
-        if rank == 0:
-            print(f"[bench] MoGe engine unavailable ({e}); metric scaling is NOT in the timed region", file=sys.stderr)
+    if stub:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import bench_stub
+        engine = bench_stub.StubEngine()
+    else:
+        engine = Pi3Engine(cfg, str(dev))
+        try:
+            from pi3_slam_amd.moge import MoGeEngine
+            if not args.no_moge:
+                moge = MoGeEngine.from_pretrained("recipe", str(dev))
+        except Exception as e:  # noqa: BLE001
+            if rank == 0:
+                print(f"[bench] MoGe engine unavailable ({e}); metric scaling is NOT in the timed region", file=sys.stderr)
 
     def make_creator(kp: int, out_dir: str = "/tmp/pi3_bench_out", workers: int = 0):
         cc = OfflineCreatorConfig(model_path="recipe", output_dir=out_dir, chunk_length=CL, overlap=OV,
@@ -339,14 +350,27 @@ def main(args) -> None:
                                   max_num_keypoints=kp, num_loader_workers=workers, device_resize=True)
         return OfflineChunkCreator(cc, model=engine, moge_model=moge)
 
-    creator = make_creator(KP)
+    import contextlib
+    if stub:
+        creator = bench_stub.StubCreator(CL, OV, KP, rank, world)
+        frames_u8 = None
+        solve = bench_stub.stub_solver(OV, CL)
+        on_align_stream = contextlib.nullcontext
+        compose = None                                       # align_wave's own f64 prefix product
+        apply_global = bench_stub.transform_chunk_cpu
+    else:
+        creator = make_creator(KP)
+        frames_u8 = synthetic_frames_u8(CL, SRC_H, SRC_W, 1234 + rank)        # decoded frames, pinned host memory
+        align_stream = torch.cuda.Stream(dev, priority=-1)   # the tiny alignment kernels slot in beside the next chunk's forward
+        solve = default_solver(OV, dev, CL)
+        on_align_stream = lambda: torch.cuda.stream(align_stream)   # noqa: E731
+        compose = lambda T: ops.sim3_compose_prefix(T.to(dev))      # noqa: E731
+        apply_global = lambda ch, G: transform_chunk(ch, G, device=str(dev), absolute=True)   # noqa: E731
     creator.target_size = (H, W)
-    frames_u8 = synthetic_frames_u8(CL, SRC_H, SRC_W, 1234 + rank)        # decoded frames, pinned host memory
     paths = [[f"frame_{i:06d}.png"] for i in range(CL)]
     matches = create_view_graph_matches(CL, OV)
     attn_events = []
-    align_stream = torch.cuda.Stream(dev, priority=-1)   # the tiny alignment kernels slot in beside the next chunk's forward
-    solve = default_solver(OV, dev, CL)
+    last_wave = {"Gs": []}      # the global transforms of the most recent wave (the stub run prints them to be checked)
 
     class _EventedModel:   # HIP events on the launch stream around the dominant kernel (global attention)
         def __init__(self, eng, events):
@@ -361,12 +385,13 @@ def main(args) -> None:
         # the warm-up goes through the same (plain-launch, evented) forward as the timed steps: warmed up through the
         # hipGraph replay instead, the first timed step paid for the plain path's first-use allocations (20-85 ms, i.e. up
         # to 4 % of a 5-step measurement)
-        cr.model = _EventedModel(engine, attn_events if timed else [])
+        if not stub:
+            cr.model = _EventedModel(engine, attn_events if timed else [])
         items = ({"frames": src, "kind": kind, "paths": paths, "meta": {"chunk_index": i}} for i in range(n_steps))
         stats = []
         for meta, chunk in cr.process_chunks(items):
             t0 = time.perf_counter()
-            with torch.cuda.stream(align_stream):
+            with on_align_stream():
                 if not grouped:
                     if state["prev"] is not None:
                         ok, _ = align_and_refine_reconstructions(state["prev"], chunk, matches, device=str(dev))
@@ -378,24 +403,27 @@ def main(args) -> None:
                               for b in allgather_boundaries(pack_boundary(chunk, OV, kk, device=comm_dev), comm_dev)]
                     w0 = state["wave"] * world
                     Gs, _ = align_wave(rank, world, w0, w0 + world, blocks, state["prev_tail"], state["G_last"], solve,
-                                       comm_dev, lambda T: ops.sim3_compose_prefix(T.to(dev)))
-                    transform_chunk(chunk, Gs[rank], device=str(dev), absolute=True)
+                                       comm_dev, compose)
+                    apply_global(chunk, Gs[rank])
+                    last_wave["Gs"] = Gs
                     state["G_last"], state["prev_tail"], state["wave"] = Gs[-1], blocks[-1], state["wave"] + 1
             m = dict(chunk["_metrics"])
             m["align_host_s"] = time.perf_counter() - t0
             stats.append(m)
-        cr.model = engine
+        if not stub:
+            cr.model = engine
         return stats
 
-    import contextlib
     quiet = contextlib.redirect_stdout(open(os.devnull, "w")) if rank != 0 else contextlib.nullcontext()
 
     def sync_all():
-        torch.cuda.synchronize(dev)
+        if not stub:
+            torch.cuda.synchronize(dev)
         if grouped:
             import torch.distributed as dist
             dist.barrier()
-            torch.cuda.synchronize(dev)
+            if not stub:
+                torch.cuda.synchronize(dev)
 
     # which softmax loop the attention waves take in the timed steps (the bounded-score loop is what
     # the headline runs on because recipe weights keep |q| max|k| <= 90; real encoder activations may not): a device
@@ -405,16 +433,20 @@ def main(args) -> None:
         if args.warmup > 0:
             run(creator, frames_u8, args.warmup, False)
         sync_all()
-        ops.attention_path_counters(path_counters)
+        if not stub:
+            ops.attention_path_counters(path_counters)
         t0 = time.perf_counter()
         stats = run(creator, frames_u8, args.steps, True)
         sync_all()
         dt = time.perf_counter() - t0
-        ops.attention_path_counters(None)
+        if not stub:
+            ops.attention_path_counters(None)
     n_headline_events = len(attn_events)
     online_max = None
-    if world == 1 and not grouped:
-        # the same step with every wave on the online-max loop (knob attn_nomax = 0): the worst case for real weights
+    if world == 1 and not grouped and not args.no_extras:
+        # the same step with every wave on the online-max loop (knob attn_nomax = 0): the worst case for real weights.
+        # (--no-extras skips it: the rocprofv3 kernel-trace of the bench command must average the headline launches only,
+        # the two loops being one kernel instance)
         from pi3_slam_amd import lib as _lib
         k_steps = max(3, min(5, args.steps))
         with quiet:
@@ -458,7 +490,7 @@ def main(args) -> None:
         S = CL * T
         attn_flops = 4.0 * cfg.heads * float(S) * float(S) * 64.0          # one global-attention launch
         attn_ms = sum(a.elapsed_time(b) for a, b in attn_events) / max(1, len(attn_events))
-        achieved = attn_flops / (attn_ms * 1e-3) / 1e12
+        achieved = attn_flops / (attn_ms * 1e-3) / 1e12 if attn_ms > 0 else 0.0
         fl = engine.flops(1, CL, H, W)
         mean = lambda k: 1e3 * sum(s.get(k, 0.0) for s in stats) / max(1, len(stats))   # noqa: E731
         line = {
@@ -503,6 +535,11 @@ def main(args) -> None:
                           "note": "GPU-event times per chunk (copy stream / compute stream); stages of consecutive chunks "
                                   "overlap, so they do not add up to ms_per_step"},
         }
+        if stub:     # a control-flow rehearsal: say so, and carry nothing that reads like a measurement of the GPU path
+            line.update(stub=True, data="STUB: no GPU work (tests/bench_stub.py on gloo); control-flow rehearsal only",
+                        vs_baseline=None)
+            line.pop("roofline")
+            line["stub_check"] = {"global_transforms_last_wave": [g.reshape(-1).tolist() for g in last_wave["Gs"]]}
         if comm is not None:
             line["comm"] = comm
             # what ONE GPU takes for the same step, to cross-check this N-rank line against the N = 1 line: the committed

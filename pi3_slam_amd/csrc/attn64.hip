@@ -192,9 +192,9 @@ __device__ __forceinline__ void a64_softmax(f32x16 (&sc)[2], float& m, f32x16 (&
 
 // NW = waves per workgroup (4 or 8): NW * 64 query rows share one staged K/V tile.
 // GLDS: stage K/V with LDS-DMA (global_load_lds, swizzle on the source address) instead of registers + ds_write.
+// (the kernel body as a function of the LDS block: attn_fwd64_kernel wraps it; attn_fwd64a_kernel, below, falls back to it)
 template <int NW, bool GLDS = false, bool MSUM = false, bool F16 = false>
-__global__ __launch_bounds__(NW * 64, (NW == 2 ? 4 : 2)) void attn_fwd64_kernel(Attn64Params p) {
-  __shared__ __attribute__((aligned(16))) char lds[32768];  // K ring [2][64][128 B] then V ring [2][64][128 B]
+__device__ __forceinline__ void a64_body(const Attn64Params& p, char* lds) {   // lds: K ring [2][64][128 B] then V ring [2][64][128 B]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
   const int nwg = p.nqb * p.H * p.B;
@@ -497,6 +497,204 @@ __global__ __launch_bounds__(NW * 64, (NW == 2 ? 4 : 2)) void attn_fwd64_kernel(
     atomicAdd(p.stats + (NW == 8 ? 0 : 64) + (fast ? 0 : 32) + (blockIdx.x & 31), 1u);
 }
 
+template <int NW, bool GLDS = false, bool MSUM = false, bool F16 = false>
+__global__ __launch_bounds__(NW * 64, (NW == 2 ? 4 : 2)) void attn_fwd64_kernel(Attn64Params p) {
+  __shared__ __attribute__((aligned(16))) char lds[32768];
+  a64_body<NW, GLDS, MSUM, F16>(p, lds);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// attn_fwd64a_kernel (round 5): the eight-wave kernel with a HAND-PLACED main loop for workgroups whose eight waves all
+// pass the bounded-score test (recipe weights: every workgroup of the global attention, bench.py `softmax_paths`).
+// The loop body is one inline-asm block generated by tools/gen_attn_asm.py (attn64a_loop.inc; its header explains the
+// quarter-tile software pipeline and the register map).  C++ around it: prologue, tile 0, the last three tiles (the
+// partial one with its clamped DMA and key mask among them), finalisation and stores - the code of a64_body with the
+// K ring three slots deep (slot t % 3 at LDS offsets 0 / 8 192 / 32 768; V ring two slots at 16 384 + 8 192 (t & 1)):
+// the pipelined loop computes Q.K^T of tile t + 1 during tile t, so K is staged two tiles ahead, V one.
+// A workgroup with a wave outside the bound, or a sequence of fewer than eight tiles, runs a64_body unchanged
+// (workgroup-uniform choice before anything is staged, so the two LDS protocols never meet).
+// ---------------------------------------------------------------------------------------------------------------------
+#include "attn64a_loop.inc"
+#define A64A_KSLOT(T) (((T) % 3) == 0 ? 0 : (((T) % 3) == 1 ? 8192 : 32768))
+#define A64A_VSLOT(T) (16384 + ((T) & 1) * 8192)
+#define A64A_LDSADDR(P) ((unsigned)(__UINTPTR_TYPE__)((__attribute__((address_space(3))) void*)(P)))
+
+__global__ __launch_bounds__(512, 2) void attn_fwd64a_kernel(Attn64Params p) {
+  __shared__ __attribute__((aligned(16))) char lds[40960];
+  constexpr bool F16 = false;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int nwg = p.nqb * p.H * p.B;
+  const int id = xcd_remap(blockIdx.x, nwg);
+  const int qb = id % p.nqb;
+  const int head = (id / p.nqb) % p.H;
+  const int b = id / (p.nqb * p.H);
+  const int S = p.S;
+  const int nt = (S + A64_KT - 1) / A64_KT;
+  const int q0 = qb * 512 + wave * 64;
+  bf16x8 qfA[4], qfB[4];
+  {
+    const int ra = min(q0 + r, S - 1), rb = min(q0 + 32 + r, S - 1);
+    const bf16_t* pa = p.q + (long)b * p.batch_stride + (long)ra * p.tok_stride + head * 64;
+    const bf16_t* pb = p.q + (long)b * p.batch_stride + (long)rb * p.tok_stride + head * 64;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      qfA[s] = *(const bf16x8*)(pa + 16 * s + 8 * h);
+      qfB[s] = *(const bf16x8*)(pb + 16 * s + 8 * h);
+    }
+  }
+  bool fast = false;
+  if (p.k2max) {
+    const float k2 = p.k2max[b * p.H + head];
+    float qa = 0.f, qbn = 0.f;
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float fa = (float)qfA[s][e], fb = (float)qfB[s][e];
+        qa += fa * fa;
+        qbn += fb * fb;
+      }
+    qa += __shfl_xor(qa, 32, 64);
+    qbn += __shfl_xor(qbn, 32, 64);
+    fast = __all(fmaxf(qa, qbn) * k2 <= A64_BOUND2);
+  }
+  if (!(nt >= 8 && __syncthreads_and(fast))) {      // workgroup-uniform
+    a64_body<8, true, true, false>(p, lds);
+    return;
+  }
+
+  f32x16 oA[2], oB[2];
+  oA[0] = oA[1] = oB[0] = oB[1] = (f32x16)(0.f);
+  float mA = 0.f, mB = 0.f, lA = 0.f, lB = 0.f;
+  f32x4 laccA = (f32x4)(0.f), laccB = (f32x4)(0.f);
+  const bf16_t* kbase = p.k + (long)b * p.batch_stride + head * 64;
+  const bf16_t* vbase = p.v + (long)b * p.batch_stride + head * 64;
+  const long tile_bytes = (long)A64_KT * p.tok_stride * 2;
+  const bool tail = (S & (A64_KT - 1)) != 0;
+  // this wave's LDS-DMA piece of a tile: rows 8 wave .. 8 wave + 7, lane -> (row, 16-byte slot), swizzle on the source
+  const int drow = wave * 8 + (lane >> 3), dpos = lane & 7;
+  const unsigned ksrc = (unsigned)(drow * p.tok_stride * 2) + ((dpos ^ ((drow >> 1) & 7)) << 4);
+  const unsigned vsrc = (unsigned)(drow * p.tok_stride * 2) + ((dpos ^ (((drow >> 1) & 1) << 2)) << 4);
+  auto dma_k = [&](int T) {
+    int grow = T * A64_KT + drow;
+    grow = grow < S ? grow : S - 1;                  // only the last, partial tile clamps
+    a64_glds16((const char*)(kbase + (long)grow * p.tok_stride) + ((dpos ^ ((drow >> 1) & 7)) << 4),
+               lds + A64A_KSLOT(T) + wave * 1024);
+  };
+  auto dma_v = [&](int T) {
+    int grow = T * A64_KT + drow;
+    grow = grow < S ? grow : S - 1;
+    a64_glds16((const char*)(vbase + (long)grow * p.tok_stride) + ((dpos ^ (((drow >> 1) & 1) << 2)) << 4),
+               lds + A64A_VSLOT(T) + wave * 1024);
+  };
+  dma_k(0);
+  dma_v(0);
+  dma_k(1);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  const int kswz = (r >> 1) & 7;
+  const int krow_off = r * 128;
+  const int gi = lane & 15, gg = (lane >> 4) & 1;
+  const int vrow_l = 4 * h + (gi >> 2);
+  const int vcol_l = 16 * gg + 4 * (gi & 3);
+  const int vch_l = vcol_l >> 3;
+  const int vin_l = (vcol_l & 7) * 2;
+  const int vswz = ((vrow_l >> 1) & 1) << 2;
+
+  // one 64-key tile, bounded-score path, both query blocks (the C++ form of a64_body's tile on the three-slot K ring)
+#define A64A_TILE(T, FIRST, LAST)                                                                                  \
+  {                                                                                                               \
+    if ((T) + 1 < nt) dma_v((T) + 1);                                                                             \
+    if ((T) + 2 < nt) dma_k((T) + 2);                                                                             \
+    f32x16 scA[2], scB[2];                                                                                        \
+    bf16x8 pfA[2][2], pfB[2][2];                                                                                  \
+    const char* kl = lds + A64A_KSLOT(T) + krow_off;                                                              \
+    const char* vl = lds + A64A_VSLOT(T);                                                                         \
+    _Pragma("unroll") for (int s = 0; s < 4; ++s) {                                                               \
+      const int off = ((2 * s + h) ^ kswz) << 4;                                                                  \
+      const bf16x8 a0 = *(const bf16x8*)(kl + off);                                                               \
+      const bf16x8 a1 = *(const bf16x8*)(kl + 32 * 128 + off);                                                    \
+      scA[0] = a64_mfma<F16>(a0, qfA[s], s == 0 ? (f32x16)(0.f) : scA[0]);                                        \
+      scB[0] = a64_mfma<F16>(a0, qfB[s], s == 0 ? (f32x16)(0.f) : scB[0]);                                        \
+      scA[1] = a64_mfma<F16>(a1, qfA[s], s == 0 ? (f32x16)(0.f) : scA[1]);                                        \
+      scB[1] = a64_mfma<F16>(a1, qfB[s], s == 0 ? (f32x16)(0.f) : scB[1]);                                        \
+    }                                                                                                             \
+    if ((LAST) && tail) { A64_MASK(T, scA, 2) A64_MASK(T, scB, 2) }                                               \
+    a64_softmax<FIRST, true, true, 2, F16>(scA, mA, oA, lA, laccA, pfA);                                          \
+    a64_softmax<FIRST, true, true, 2, F16>(scB, mB, oB, lB, laccB, pfB);                                          \
+    _Pragma("unroll") for (int kt = 0; kt < 2; ++kt)                                                              \
+    _Pragma("unroll") for (int s2 = 0; s2 < 2; ++s2) {                                                            \
+      const int row0 = 32 * kt + 16 * s2 + vrow_l;                                                                \
+      _Pragma("unroll") for (int dt = 0; dt < 2; ++dt) {                                                          \
+        const int ch = (4 * dt + vch_l) ^ vswz;                                                                   \
+        const char* a = vl + row0 * 128 + (ch << 4) + vin_l;                                                      \
+        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)LDS_PTR(a)); \
+        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(                                               \
+            (__attribute__((address_space(3))) bf16x4*)LDS_PTR(a + 8 * 128));                                     \
+        const bf16x8 vf = a64_cat4(lo, hi);                                                                       \
+        oA[dt] = a64_mfma<F16>(vf, pfA[kt][s2], oA[dt]);                                                          \
+        oB[dt] = a64_mfma<F16>(vf, pfB[kt][s2], oB[dt]);                                                          \
+      }                                                                                                           \
+    }                                                                                                             \
+    if (!(LAST)) {                                                                                                \
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                            \
+      __syncthreads();                                                                                            \
+    }                                                                                                             \
+  }
+
+  A64A_TILE(0, true, false)
+  {
+    // ---- tiles 1 .. nt - 4: the hand-placed loop.  Entry state of its registers (tools/gen_attn_asm.py): K fragment
+    // addresses in the slot of tile 1, V fragment addresses in the slot of tile 0 (the loop head steps them to tile 1)
+    const unsigned lds0 = A64A_LDSADDR(lds);
+    const unsigned ka0 = lds0 + 8192 + krow_off + (((0 + h) ^ kswz) << 4), ka1 = lds0 + 8192 + krow_off + (((2 + h) ^ kswz) << 4);
+    const unsigned ka2 = lds0 + 8192 + krow_off + (((4 + h) ^ kswz) << 4), ka3 = lds0 + 8192 + krow_off + (((6 + h) ^ kswz) << 4);
+    const unsigned va0 = lds0 + 16384 + vrow_l * 128 + (((0 + vch_l) ^ vswz) << 4) + vin_l;
+    const unsigned va1 = lds0 + 16384 + vrow_l * 128 + (((4 + vch_l) ^ vswz) << 4) + vin_l;
+    const unsigned cnt = (unsigned)(nt - 4);
+    const unsigned long long kg = (unsigned long long)(__UINTPTR_TYPE__)kbase + 3ull * (unsigned long long)tile_bytes;
+    const unsigned long long vg = (unsigned long long)(__UINTPTR_TYPE__)vbase + 2ull * (unsigned long long)tile_bytes;
+    const unsigned kg_lo = __builtin_amdgcn_readfirstlane((unsigned)kg), kg_hi = __builtin_amdgcn_readfirstlane((unsigned)(kg >> 32));
+    const unsigned vg_lo = __builtin_amdgcn_readfirstlane((unsigned)vg), vg_hi = __builtin_amdgcn_readfirstlane((unsigned)(vg >> 32));
+    const unsigned long long kgs = ((unsigned long long)kg_hi << 32) | kg_lo, vgs = ((unsigned long long)vg_hi << 32) | vg_lo;
+    const unsigned tb = __builtin_amdgcn_readfirstlane((unsigned)tile_bytes);
+    const unsigned kd0 = __builtin_amdgcn_readfirstlane(lds0 + wave * 1024);
+    asm volatile(A64A_LOOP_ASM
+                 : [oa0] "+v"(oA[0]), [oa1] "+v"(oA[1]), [ob0] "+v"(oB[0]), [ob1] "+v"(oB[1]), [lA] "+v"(laccA), [lB] "+v"(laccB)
+                 : [qa0] "v"(qfA[0]), [qa1] "v"(qfA[1]), [qa2] "v"(qfA[2]), [qa3] "v"(qfA[3]), [qb0] "v"(qfB[0]),
+                   [qb1] "v"(qfB[1]), [qb2] "v"(qfB[2]), [qb3] "v"(qfB[3]), [ka0] "v"(ka0), [ka1] "v"(ka1), [ka2] "v"(ka2),
+                   [ka3] "v"(ka3), [va0] "v"(va0), [va1] "v"(va1), [ksrc] "v"(ksrc), [vsrc] "v"(vsrc), [cnt] "s"(cnt),
+                   [kg] "s"(kgs), [vg] "s"(vgs), [tb] "s"(tb), [kd0] "s"(kd0)
+                 : "memory", "scc", "vcc", "m0", A64A_CLOBBER_V, A64A_CLOBBER_S);
+  }
+  A64A_TILE(nt - 3, false, false)
+  A64A_TILE(nt - 2, false, false)
+  A64A_TILE(nt - 1, false, true)
+
+  if (p.stats && lane == 0) atomicAdd(p.stats + 0 + (blockIdx.x & 31), 1u);      // eight-wave kernel, bounded-score loop
+#pragma unroll
+  for (int blk = 0; blk < 2; ++blk) {
+    const float lsum = blk ? lB + laccB[0] : lA + laccA[0];
+    const float inv = 1.0f / (lsum + __shfl_xor(lsum, 32, 64));
+    const int row = q0 + 32 * blk + r;
+    if (row < S) {
+      bf16_t* optr = p.o + (long)b * p.o_batch_stride + (long)row * p.o_tok_stride + head * 64;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f32x16& ov = blk ? oB[dt] : oA[dt];
+          u32x2 w;
+          w[0] = pack_bf16x2(ov[4 * g + 0] * inv, ov[4 * g + 1] * inv);
+          w[1] = pack_bf16x2(ov[4 * g + 2] * inv, ov[4 * g + 3] * inv);
+          *(u32x2*)(optr + 32 * dt + 8 * g + 4 * h) = w;
+        }
+    }
+  }
+}
+
 // max over keys of |k|^2 per (batch, head) for the bounded-score test; out must be zeroed (non-negative floats order
 // like their bit patterns, so the reduction is an integer atomicMax)
 #define A64_KNORM_BLOCKS 24   // blocks per (batch, head): 24 * 16 heads = 384 blocks, one atomic each
@@ -647,7 +845,11 @@ int pi3_attention64_launch(const void* q, const void* k, const void* v, long tok
     const char* e = getenv("PI3_ATTN_MSUM");
     msum = e ? atoi(e) : 1;
   }
-  if (nw == 8 && glds && msum)
+  // knob attn_asm (PI3_ATTN_ASM): 1 = the kernel with the hand-placed main loop (attn_fwd64a_kernel; workgroups it does
+  // not cover run the compiler-scheduled body inside it), 0 = the compiler-scheduled kernel
+  if (nw == 8 && glds && msum && p.k2max && PI3_KNOB("attn_asm", 0) != 0)
+    hipLaunchKernelGGL(attn_fwd64a_kernel, dim3((unsigned)nwg), dim3(512), 0, stream, p);
+  else if (nw == 8 && glds && msum)
     hipLaunchKernelGGL((attn_fwd64_kernel<8, true, true>), dim3((unsigned)nwg), dim3(512), 0, stream, p);
   else if (nw == 8 && glds)
     hipLaunchKernelGGL((attn_fwd64_kernel<8, true>), dim3((unsigned)nwg), dim3(512), 0, stream, p);

@@ -514,7 +514,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 2 ? 4 : 2)) void attn_fwd64_kernel(
 // A workgroup with a wave outside the bound, or a sequence of fewer than eight tiles, runs a64_body unchanged
 // (workgroup-uniform choice before anything is staged, so the two LDS protocols never meet).
 // ---------------------------------------------------------------------------------------------------------------------
-#include "attn64a_loop.inc"
+#include <attn64a_loop.inc>   // -I. (the Makefile); tools/build_attn_variants.sh puts a variant directory in front
 #define A64A_KSLOT(T) (((T) % 3) == 0 ? 0 : (((T) % 3) == 1 ? 8192 : 32768))
 #define A64A_VSLOT(T) (16384 + ((T) & 1) * 8192)
 #define A64A_LDSADDR(P) ((unsigned)(__UINTPTR_TYPE__)((__attribute__((address_space(3))) void*)(P)))
@@ -845,9 +845,9 @@ int pi3_attention64_launch(const void* q, const void* k, const void* v, long tok
     const char* e = getenv("PI3_ATTN_MSUM");
     msum = e ? atoi(e) : 1;
   }
-  // knob attn_asm (PI3_ATTN_ASM): 1 = the kernel with the hand-placed main loop (attn_fwd64a_kernel; workgroups it does
-  // not cover run the compiler-scheduled body inside it), 0 = the compiler-scheduled kernel
-  if (nw == 8 && glds && msum && p.k2max && PI3_KNOB("attn_asm", 0) != 0)
+  // knob attn_asm (PI3_ATTN_ASM): 1 (default) = the kernel with the hand-placed main loop (attn_fwd64a_kernel; workgroups
+  // it does not cover run the compiler-scheduled body inside it), 0 = the compiler-scheduled kernel.  Bit-identical results.
+  if (nw == 8 && glds && msum && p.k2max && PI3_KNOB("attn_asm", 1) != 0)
     hipLaunchKernelGGL(attn_fwd64a_kernel, dim3((unsigned)nwg), dim3(512), 0, stream, p);
   else if (nw == 8 && glds && msum)
     hipLaunchKernelGGL((attn_fwd64_kernel<8, true, true>), dim3((unsigned)nwg), dim3(512), 0, stream, p);

@@ -47,6 +47,9 @@ S_KCUR = "s78"                                      # current K slot offset of t
 SCALARS = list(range(60, 79))
 
 lines = []
+ABL = set(os.environ.get("A64A_ABL", "").split(","))       # timing-only ablations (WRONG results): noexp, norowsum, nopv, noqk, nobarrier
+OPT = dict(kv.split("=") for kv in os.environ.get("A64A_OPT", "").split(",") if "=" in kv)      # schedule options (correct results)
+OUT = os.environ.get("A64A_OUT", OUT)
 
 
 def emit(s):
@@ -72,7 +75,7 @@ def slot(kt, s2, *, pv=True, qk=True, ex=True, rowsum=True, kaddr_update=False, 
     for g in range(8):
         for (blk, i) in exps[2 * g: 2 * g + 2]:
             r = S[blk] + 8 * s2 + i
-            fill[g].append(f"v_exp_f32_e32 v{r}, v{r}")
+            fill[g].append(f"v_mov_b32_e32 v{r}, v{r}" if "noexp" in ABL else f"v_exp_f32_e32 v{r}, v{r}")
     if ex:
         for j in range(8):                          # cvt j packs exps 2j, 2j+1 (issued in gap j); placed in gap j+1 (last: gap 7 tail)
             blk, i = exps[2 * j]
@@ -80,7 +83,7 @@ def slot(kt, s2, *, pv=True, qk=True, ex=True, rowsum=True, kaddr_update=False, 
             dst = cur[blk] + (i // 2)
             g = min(j + 1, 7)
             fill[g].append(f"v_cvt_pk_bf16_f32 v{dst}, v{r}, v{r + 1}")
-    if rowsum and pv:                               # 4 row-sum MFMAs on P(q-1): gaps 1, 3, 5, 7
+    if rowsum and pv and "norowsum" not in ABL:     # 4 row-sum MFMAs on P(q-1): gaps 1, 3, 5, 7
         for n, (blk, half) in enumerate(((0, 0), (0, 1), (1, 0), (1, 1))):
             acc = "%[lA]" if blk == 0 else "%[lB]"
             fill[2 * n + 1].append(f"v_mfma_f32_4x4x4_16b_bf16 {acc}, {vr(ONES, 2)}, {vr(prev[blk] + 2 * half, 2)}, {acc}")
@@ -111,7 +114,16 @@ def slot(kt, s2, *, pv=True, qk=True, ex=True, rowsum=True, kaddr_update=False, 
             acc = vr(tgt[blk], 16)
             c = "0" if s == 0 else acc
             mf.append(f"v_mfma_f32_32x32x16_bf16 {acc}, {vr(KF[n], 4)}, {Q[blk][s]}, {c}" if qk else None)
+    if "nopv" in ABL:
+        mf[:4] = [None] * 4
+    if "noqk" in ABL and ex:
+        mf[4:] = [None] * 4
     emit(f"; ---- slot kt={kt} s2={s2} pv={int(pv)} qk={int(qk)} ex={int(ex)}")
+    # dependent row-sum MFMAs must not follow each other directly (the second would read its accumulator before the first
+    # has written it): where a slot carries no big MFMA between them (the drain), pad
+    if not qk:
+        for g in range(len(fill)):
+            fill[g] = [y for x in fill[g] for y in ((["s_nop 7"] if x.startswith("v_mfma_f32_4x4x4") else []) + [x])]
     for g in range(8):
         if g == 0 and pv:
             emit("s_waitcnt lgkmcnt(0)")             # V fragments of quarter q-1 (read half a slot ago)
@@ -156,9 +168,10 @@ def tile_head():
 
 def tile_tail():
     emit("; ---- tile tail: every DMA piece landed, every fragment read returned, then the workgroup barrier")
-    emit("s_waitcnt vmcnt(0)")
-    emit("s_waitcnt lgkmcnt(0)")
-    emit("s_barrier")
+    if "nobarrier" not in ABL:
+        emit("s_waitcnt vmcnt(0)")
+        emit("s_waitcnt lgkmcnt(0)")
+        emit("s_barrier")
 
 
 def entry():

@@ -1,0 +1,137 @@
+// Timing harness for the generated hand-placed attention loops (tools/gen_attn_asm2.py): the loop alone, on real K / V
+// streams (LDS-DMA from a packed qkv buffer, XCD-aware block order as in the product kernel), NO correctness claim.
+//   NBLK = 2: eight waves per workgroup (two per SIMD), 64 rows per wave      NBLK = 4: four waves (one per SIMD), 128 rows
+// Build:  python tools/gen_attn_asm2.py 2 tools/micro/a64b2.inc && python tools/gen_attn_asm2.py 4 tools/micro/a64b4.inc
+//         hipcc --offload-arch=gfx950 -O3 -I pi3_slam_amd/csrc -I tools/micro -o tools/micro/attn_loop_bench tools/micro/attn_loop_bench.hip
+#include "common.h"
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+#include <a64b2.inc>      // -I: tools/micro, or a variant directory in front (build_loop_bench.sh)
+#include <a64b4.inc>
+
+#define LDSADDR(P) ((unsigned)(__UINTPTR_TYPE__)((__attribute__((address_space(3))) void*)(P)))
+__device__ __forceinline__ void glds16(const void* gsrc, const void* lds_dst) {
+  const unsigned m0v = __builtin_amdgcn_readfirstlane(LDSADDR(lds_dst));
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(m0v) : "memory", "m0");
+}
+
+struct P { const bf16_t* q; const bf16_t* k; const bf16_t* v; long tok_stride; int S, H, nqb; float* out; unsigned long long* cyc; };
+
+template <int N>
+__global__ __launch_bounds__((N == 2 ? 512 : 256), (N == 2 ? 2 : 1)) void loop_kernel(P p) {
+  constexpr int NW = N == 2 ? 8 : 4, PIECES = 16 / NW;
+  __shared__ __attribute__((aligned(16))) char lds[40960];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int nwg = p.nqb * p.H;
+  const int id = xcd_remap(blockIdx.x, nwg);
+  const int qb = id % p.nqb, head = id / p.nqb;
+  const int S = p.S, nt = (S + 63) / 64;
+  const int q0 = qb * 512 + wave * (32 * N);
+  const bf16_t* kbase = p.k + head * 64;
+  const bf16_t* vbase = p.v + head * 64;
+  const long tile_bytes = 64L * p.tok_stride * 2;
+  unsigned ksrc[2], vsrc[2];
+  for (int i = 0; i < PIECES / 2; ++i) {
+    const int seg = wave * (PIECES / 2) + i, drow = seg * 8 + (lane >> 3), dpos = lane & 7;
+    ksrc[i] = (unsigned)(drow * p.tok_stride * 2) + ((dpos ^ ((drow >> 1) & 7)) << 4);
+    vsrc[i] = (unsigned)(drow * p.tok_stride * 2) + ((dpos ^ (((drow >> 1) & 1) << 2)) << 4);
+    // prologue: K0 -> slot 0, V0 -> V slot 0, K1 -> slot 1
+    glds16((const char*)kbase + ksrc[i], lds + 0 + seg * 1024);
+    glds16((const char*)vbase + vsrc[i], lds + 16384 + seg * 1024);
+    glds16((const char*)kbase + tile_bytes + ksrc[i], lds + 8192 + seg * 1024);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  const int kswz = (r >> 1) & 7, krow_off = r * 128;
+  const int gi = lane & 15, gg = (lane >> 4) & 1;
+  const int vrow_l = 4 * h + (gi >> 2), vcol_l = 16 * gg + 4 * (gi & 3), vch_l = vcol_l >> 3, vin_l = (vcol_l & 7) * 2;
+  const int vswz = ((vrow_l >> 1) & 1) << 2;
+  const unsigned lds0 = LDSADDR(lds);
+  const unsigned ka0 = lds0 + 8192 + krow_off + (((0 + h) ^ kswz) << 4), ka1 = lds0 + 8192 + krow_off + (((2 + h) ^ kswz) << 4);
+  const unsigned ka2 = lds0 + 8192 + krow_off + (((4 + h) ^ kswz) << 4), ka3 = lds0 + 8192 + krow_off + (((6 + h) ^ kswz) << 4);
+  const unsigned va0 = lds0 + 16384 + vrow_l * 128 + (((0 + vch_l) ^ vswz) << 4) + vin_l;
+  const unsigned va1 = lds0 + 16384 + vrow_l * 128 + (((4 + vch_l) ^ vswz) << 4) + vin_l;
+  const bf16_t* qp[4];
+  for (int blk = 0; blk < N; ++blk) qp[blk] = p.q + (long)min(q0 + 32 * blk + r, S - 1) * p.tok_stride + head * 64 + 8 * h;
+  const unsigned cnt = (unsigned)(nt - 2);
+  const unsigned long long kg = (unsigned long long)(__UINTPTR_TYPE__)kbase + 3ull * tile_bytes;
+  const unsigned long long vg = (unsigned long long)(__UINTPTR_TYPE__)vbase + 2ull * tile_bytes;
+  // (readfirstlane returns int: through unsigned variables, or the low word is SIGN-extended into the high one - a wild
+  // address whenever bit 31 of the buffer address is set)
+  const unsigned kg_lo = __builtin_amdgcn_readfirstlane((unsigned)kg), kg_hi = __builtin_amdgcn_readfirstlane((unsigned)(kg >> 32));
+  const unsigned vg_lo = __builtin_amdgcn_readfirstlane((unsigned)vg), vg_hi = __builtin_amdgcn_readfirstlane((unsigned)(vg >> 32));
+  const unsigned long long kgs = ((unsigned long long)kg_hi << 32) | kg_lo, vgs = ((unsigned long long)vg_hi << 32) | vg_lo;
+  const unsigned tb = __builtin_amdgcn_readfirstlane((unsigned)tile_bytes);
+  const unsigned kd0 = __builtin_amdgcn_readfirstlane(lds0 + wave * (PIECES / 2) * 1024);
+  float out;
+  unsigned long long c0, c1, r0, r1;
+  asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(c0), "=s"(r0)::"memory");
+  if constexpr (N == 2) {
+    asm volatile(A64B2_LOOP_ASM
+                 : [out] "=&v"(out)
+                 : [ka0] "v"(ka0), [ka1] "v"(ka1), [ka2] "v"(ka2), [ka3] "v"(ka3), [va0] "v"(va0), [va1] "v"(va1),
+                   [ksrc0] "v"(ksrc[0]), [vsrc0] "v"(vsrc[0]), [qp0] "v"(qp[0]), [qp1] "v"(qp[1]), [cnt] "s"(cnt), [kg] "s"(kgs),
+                   [vg] "s"(vgs), [tb] "s"(tb), [kd0] "s"(kd0)
+                 : "memory", "scc", "vcc", "m0", A64B2_CLOBBER_V, A64B2_CLOBBER_A, A64B2_CLOBBER_S);
+  } else {
+    asm volatile(A64B4_LOOP_ASM
+                 : [out] "=&v"(out)
+                 : [ka0] "v"(ka0), [ka1] "v"(ka1), [ka2] "v"(ka2), [ka3] "v"(ka3), [va0] "v"(va0), [va1] "v"(va1),
+                   [ksrc0] "v"(ksrc[0]), [vsrc0] "v"(vsrc[0]), [ksrc1] "v"(ksrc[1]), [vsrc1] "v"(vsrc[1]), [qp0] "v"(qp[0]),
+                   [qp1] "v"(qp[1]), [qp2] "v"(qp[2]), [qp3] "v"(qp[3]), [cnt] "s"(cnt), [kg] "s"(kgs), [vg] "s"(vgs), [tb] "s"(tb),
+                   [kd0] "s"(kd0)
+                 : "memory", "scc", "vcc", "m0", A64B4_CLOBBER_V, A64B4_CLOBBER_A, A64B4_CLOBBER_S);
+  }
+  asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(c1), "=s"(r1)::"memory");
+  p.out[(long)blockIdx.x * blockDim.x + tid] = out;
+  if (tid == 0 && (blockIdx.x % 64) == 7) {      // shader cycles and 100 MHz ticks of the loop of a sample of workgroups
+    p.cyc[2 * (blockIdx.x / 64)] = c1 - c0;
+    p.cyc[2 * (blockIdx.x / 64) + 1] = r1 - r0;
+  }
+}
+
+template <int N>
+void run(const P& p, const char* name) {
+  const int threads = N == 2 ? 512 : 256;
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  float best = 1e9f, ms = 0.f;
+  for (int rep = 0; rep < 6; ++rep) {
+    hipEventRecord(e0);
+    hipLaunchKernelGGL(loop_kernel<N>, dim3(p.nqb * p.H), dim3(threads), 0, 0, p);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    hipEventElapsedTime(&ms, e0, e1);
+    if (rep >= 2 && ms < best) best = ms;
+  }
+  hipError_t e = hipGetLastError();
+  unsigned long long hc[64];
+  hipMemcpy(hc, p.cyc, sizeof(hc), hipMemcpyDeviceToHost);
+  double cyc = 0, rt = 0;
+  int n = 0;
+  for (int i = 0; i < 31; ++i) { cyc += (double)hc[2 * i]; rt += (double)hc[2 * i + 1]; ++n; }
+  const double tiles = (p.S + 63) / 64 - 2;
+  printf("%-34s %8.3f ms  %7.1f TF/s-eq  | loop: %7.0f cycles per tile and workgroup, clock %.0f MHz  (%s)\n", name, best,
+         4.0 * p.H * (double)p.S * p.S * 64 / best / 1e9, cyc / n / tiles, 100.0 * cyc / rt, hipGetErrorString(e));
+}
+
+int main() {
+  const int S = 64300, H = 16;
+  const long stride = 3L * H * 64, rows = S + 512;
+  std::vector<unsigned short> h(rows * stride);
+  unsigned x = 12345u;
+  for (auto& e : h) { x = x * 1664525u + 1013904223u; const float f = ((int)(x >> 9) % 2001 - 1000) * 2.5e-4f;   // [-0.25, 0.25]
+    unsigned u; memcpy(&u, &f, 4); e = (unsigned short)(u >> 16); }
+  bf16_t* d; float* out; unsigned long long* cyc;
+  hipMalloc(&d, h.size() * 2); hipMalloc(&out, 2016L * 512 * 4); hipMalloc(&cyc, 64 * 8); hipMemset(cyc, 0, 64 * 8);
+  hipMemcpy(d, h.data(), h.size() * 2, hipMemcpyHostToDevice);
+  P p{d, d + H * 64, d + 2 * H * 64, stride, S, H, (S + 511) / 512, out, cyc};
+  for (int round = 0; round < 2; ++round) {
+    run<2>(p, "two waves / SIMD, 64 rows per wave");
+    run<4>(p, "one wave / SIMD, 128 rows per wave");
+  }
+  return 0;
+}

@@ -573,9 +573,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd64a_kernel(Attn64Params p) {
   const long tile_bytes = (long)A64_KT * p.tok_stride * 2;
   const bool tail = (S & (A64_KT - 1)) != 0;
   // this wave's LDS-DMA piece of a tile: rows 8 wave .. 8 wave + 7, lane -> (row, 16-byte slot), swizzle on the source
-  const int drow = wave * 8 + (lane >> 3), dpos = lane & 7;
-  const unsigned ksrc = (unsigned)(drow * p.tok_stride * 2) + ((dpos ^ ((drow >> 1) & 7)) << 4);
-  const unsigned vsrc = (unsigned)(drow * p.tok_stride * 2) + ((dpos ^ (((drow >> 1) & 1) << 2)) << 4);
+  int drow, dpos;                                    // (set by A64A_LANE_CONSTS)
   auto dma_k = [&](int T) {
     int grow = T * A64_KT + drow;
     grow = grow < S ? grow : S - 1;                  // only the last, partial tile clamps
@@ -588,42 +586,48 @@ __global__ __launch_bounds__(512, 2) void attn_fwd64a_kernel(Attn64Params p) {
     a64_glds16((const char*)(vbase + (long)grow * p.tok_stride) + ((dpos ^ (((drow >> 1) & 1) << 2)) << 4),
                lds + A64A_VSLOT(T) + wave * 1024);
   };
+
+  // lane-derived fragment offsets.  They are recomputed from a laundered lane id behind the asm loop (A64A_LANE_CONSTS
+  // again, below): kept live across it they would have to sit below the loop's fixed registers beside O, Q and the row
+  // sums, and hipcc sent a dozen of them through scratch (53 MB of spill traffic per launch in the WRITE_SIZE counter)
+  int kswz, krow_off, vrow_l, vch_l, vin_l, vswz, r_, h_;
+#define A64A_LANE_CONSTS(LANE)                                                                                     \
+  {                                                                                                               \
+    r_ = (LANE) & 31; h_ = (LANE) >> 5;                                                                           \
+    drow = wave * 8 + ((LANE) >> 3); dpos = (LANE) & 7;                                                           \
+    kswz = (r_ >> 1) & 7;                                                                                         \
+    krow_off = r_ * 128;                                                                                          \
+    const int gi = (LANE) & 15, gg = ((LANE) >> 4) & 1;                                                           \
+    vrow_l = 4 * h_ + (gi >> 2);                                                                                  \
+    const int vcol_l = 16 * gg + 4 * (gi & 3);                                                                    \
+    vch_l = vcol_l >> 3;                                                                                          \
+    vin_l = (vcol_l & 7) * 2;                                                                                     \
+    vswz = ((vrow_l >> 1) & 1) << 2;                                                                              \
+  }
+  A64A_LANE_CONSTS(lane)
   dma_k(0);
   dma_v(0);
   dma_k(1);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
-  const int kswz = (r >> 1) & 7;
-  const int krow_off = r * 128;
-  const int gi = lane & 15, gg = (lane >> 4) & 1;
-  const int vrow_l = 4 * h + (gi >> 2);
-  const int vcol_l = 16 * gg + 4 * (gi & 3);
-  const int vch_l = vcol_l >> 3;
-  const int vin_l = (vcol_l & 7) * 2;
-  const int vswz = ((vrow_l >> 1) & 1) << 2;
-
-  // one 64-key tile, bounded-score path, both query blocks (the C++ form of a64_body's tile on the three-slot K ring)
-#define A64A_TILE(T, FIRST, LAST)                                                                                  \
+  // one 64-key tile, bounded-score path (the C++ form of a64_body's tile on the three-slot K ring).  Four of ~1 000 tiles
+  // run here, so the two query blocks go one after the other: half the live score / probability registers, which keeps
+  // the values that live across the asm statement (O, Q, row sums: 104 registers below the loop's fixed v150..v255)
+  // out of scratch.
+#define A64A_BLOCK(T, FIRST, LAST, QF, OACC, LSUM, LACC, MREF)                                                      \
   {                                                                                                               \
-    if ((T) + 1 < nt) dma_v((T) + 1);                                                                             \
-    if ((T) + 2 < nt) dma_k((T) + 2);                                                                             \
-    f32x16 scA[2], scB[2];                                                                                        \
-    bf16x8 pfA[2][2], pfB[2][2];                                                                                  \
-    const char* kl = lds + A64A_KSLOT(T) + krow_off;                                                              \
-    const char* vl = lds + A64A_VSLOT(T);                                                                         \
+    f32x16 sc[2];                                                                                                 \
+    bf16x8 pf[2][2];                                                                                              \
     _Pragma("unroll") for (int s = 0; s < 4; ++s) {                                                               \
-      const int off = ((2 * s + h) ^ kswz) << 4;                                                                  \
+      const int off = ((2 * s + h_) ^ kswz) << 4;                                                                 \
       const bf16x8 a0 = *(const bf16x8*)(kl + off);                                                               \
       const bf16x8 a1 = *(const bf16x8*)(kl + 32 * 128 + off);                                                    \
-      scA[0] = a64_mfma<F16>(a0, qfA[s], s == 0 ? (f32x16)(0.f) : scA[0]);                                        \
-      scB[0] = a64_mfma<F16>(a0, qfB[s], s == 0 ? (f32x16)(0.f) : scB[0]);                                        \
-      scA[1] = a64_mfma<F16>(a1, qfA[s], s == 0 ? (f32x16)(0.f) : scA[1]);                                        \
-      scB[1] = a64_mfma<F16>(a1, qfB[s], s == 0 ? (f32x16)(0.f) : scB[1]);                                        \
+      sc[0] = a64_mfma<F16>(a0, QF[s], s == 0 ? (f32x16)(0.f) : sc[0]);                                           \
+      sc[1] = a64_mfma<F16>(a1, QF[s], s == 0 ? (f32x16)(0.f) : sc[1]);                                           \
     }                                                                                                             \
-    if ((LAST) && tail) { A64_MASK(T, scA, 2) A64_MASK(T, scB, 2) }                                               \
-    a64_softmax<FIRST, true, true, 2, F16>(scA, mA, oA, lA, laccA, pfA);                                          \
-    a64_softmax<FIRST, true, true, 2, F16>(scB, mB, oB, lB, laccB, pfB);                                          \
+    if ((LAST) && tail) { A64_MASK(T, sc, 2) }                                                                    \
+    a64_softmax<FIRST, true, true, 2, F16>(sc, MREF, OACC, LSUM, LACC, pf);                                       \
     _Pragma("unroll") for (int kt = 0; kt < 2; ++kt)                                                              \
     _Pragma("unroll") for (int s2 = 0; s2 < 2; ++s2) {                                                            \
       const int row0 = 32 * kt + 16 * s2 + vrow_l;                                                                \
@@ -633,11 +637,19 @@ __global__ __launch_bounds__(512, 2) void attn_fwd64a_kernel(Attn64Params p) {
         const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)LDS_PTR(a)); \
         const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(                                               \
             (__attribute__((address_space(3))) bf16x4*)LDS_PTR(a + 8 * 128));                                     \
-        const bf16x8 vf = a64_cat4(lo, hi);                                                                       \
-        oA[dt] = a64_mfma<F16>(vf, pfA[kt][s2], oA[dt]);                                                          \
-        oB[dt] = a64_mfma<F16>(vf, pfB[kt][s2], oB[dt]);                                                          \
+        OACC[dt] = a64_mfma<F16>(a64_cat4(lo, hi), pf[kt][s2], OACC[dt]);                                         \
       }                                                                                                           \
     }                                                                                                             \
+  }
+#define A64A_TILE(T, FIRST, LAST)                                                                                  \
+  {                                                                                                               \
+    if ((T) + 1 < nt) dma_v((T) + 1);                                                                             \
+    if ((T) + 2 < nt) dma_k((T) + 2);                                                                             \
+    const char* kl = lds + A64A_KSLOT(T) + krow_off;                                                              \
+    const char* vl = lds + A64A_VSLOT(T);                                                                         \
+    A64A_BLOCK(T, FIRST, LAST, qfA, oA, lA, laccA, mA)                                                            \
+    __builtin_amdgcn_sched_barrier(0);                                                                            \
+    A64A_BLOCK(T, FIRST, LAST, qfB, oB, lB, laccB, mB)                                                            \
     if (!(LAST)) {                                                                                                \
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                            \
       __syncthreads();                                                                                            \
@@ -649,10 +661,12 @@ __global__ __launch_bounds__(512, 2) void attn_fwd64a_kernel(Attn64Params p) {
     // ---- tiles 1 .. nt - 4: the hand-placed loop.  Entry state of its registers (tools/gen_attn_asm.py): K fragment
     // addresses in the slot of tile 1, V fragment addresses in the slot of tile 0 (the loop head steps them to tile 1)
     const unsigned lds0 = A64A_LDSADDR(lds);
-    const unsigned ka0 = lds0 + 8192 + krow_off + (((0 + h) ^ kswz) << 4), ka1 = lds0 + 8192 + krow_off + (((2 + h) ^ kswz) << 4);
-    const unsigned ka2 = lds0 + 8192 + krow_off + (((4 + h) ^ kswz) << 4), ka3 = lds0 + 8192 + krow_off + (((6 + h) ^ kswz) << 4);
+    const unsigned ka0 = lds0 + 8192 + krow_off + (((0 + h_) ^ kswz) << 4), ka1 = lds0 + 8192 + krow_off + (((2 + h_) ^ kswz) << 4);
+    const unsigned ka2 = lds0 + 8192 + krow_off + (((4 + h_) ^ kswz) << 4), ka3 = lds0 + 8192 + krow_off + (((6 + h_) ^ kswz) << 4);
     const unsigned va0 = lds0 + 16384 + vrow_l * 128 + (((0 + vch_l) ^ vswz) << 4) + vin_l;
     const unsigned va1 = lds0 + 16384 + vrow_l * 128 + (((4 + vch_l) ^ vswz) << 4) + vin_l;
+    const unsigned ksrc = (unsigned)(drow * p.tok_stride * 2) + ((dpos ^ ((drow >> 1) & 7)) << 4);
+    const unsigned vsrc = (unsigned)(drow * p.tok_stride * 2) + ((dpos ^ (((drow >> 1) & 1) << 2)) << 4);
     const unsigned cnt = (unsigned)(nt - 4);
     const unsigned long long kg = (unsigned long long)(__UINTPTR_TYPE__)kbase + 3ull * (unsigned long long)tile_bytes;
     const unsigned long long vg = (unsigned long long)(__UINTPTR_TYPE__)vbase + 2ull * (unsigned long long)tile_bytes;
@@ -669,16 +683,23 @@ __global__ __launch_bounds__(512, 2) void attn_fwd64a_kernel(Attn64Params p) {
                    [kg] "s"(kgs), [vg] "s"(vgs), [tb] "s"(tb), [kd0] "s"(kd0)
                  : "memory", "scc", "vcc", "m0", A64A_CLOBBER_V, A64A_CLOBBER_S);
   }
+  {
+    int lane2 = (int)(threadIdx.x & 63);
+    asm volatile("" : "+v"(lane2));                    // opaque: nothing derived from the lane id before the loop stays live
+    A64A_LANE_CONSTS(lane2)
+  }
+#define h h_      /* A64_MASK reads `h`: the recomputed one from here on */
   A64A_TILE(nt - 3, false, false)
   A64A_TILE(nt - 2, false, false)
   A64A_TILE(nt - 1, false, true)
+#undef h
 
-  if (p.stats && lane == 0) atomicAdd(p.stats + 0 + (blockIdx.x & 31), 1u);      // eight-wave kernel, bounded-score loop
+  if (p.stats && (threadIdx.x & 63) == 0) atomicAdd(p.stats + 0 + (blockIdx.x & 31), 1u);      // eight-wave kernel, bounded-score loop
 #pragma unroll
   for (int blk = 0; blk < 2; ++blk) {
     const float lsum = blk ? lB + laccB[0] : lA + laccA[0];
     const float inv = 1.0f / (lsum + __shfl_xor(lsum, 32, 64));
-    const int row = q0 + 32 * blk + r;
+    const int row = q0 + 32 * blk + r_;
     if (row < S) {
       bf16_t* optr = p.o + (long)b * p.o_batch_stride + (long)row * p.o_tok_stride + head * 64;
 #pragma unroll
@@ -689,7 +710,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd64a_kernel(Attn64Params p) {
           u32x2 w;
           w[0] = pack_bf16x2(ov[4 * g + 0] * inv, ov[4 * g + 1] * inv);
           w[1] = pack_bf16x2(ov[4 * g + 2] * inv, ov[4 * g + 3] * inv);
-          *(u32x2*)(optr + 32 * dt + 8 * g + 4 * h) = w;
+          *(u32x2*)(optr + 32 * dt + 8 * g + 4 * h_) = w;
         }
     }
   }

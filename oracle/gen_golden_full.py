@@ -1,7 +1,7 @@
 """ORACLE tooling — generates tests/golden/pi3_full.npz: the REAL reference at the HEADLINE size (BASELINE configs[1]:
 100 frames at 308x406, chunk_length 100, grid K = 200), run in the build container only (imports /root/reference).
 
-    python oracle/gen_golden_full.py [--no-bf16]        (~17 min per forward on 8 cores, ~12 GB RAM)
+    python oracle/gen_golden_full.py [pi3_full | pi3_euroc] [--no-bf16]        (pi3_full: ~17 min fp32 + 6 min bf16 on 8 cores, ~12 GB)
 
 What runs, unmodified: `Pi3.forward` (pi3/models/pi3.py:173-216) INSIDE `OfflineChunkCreator._process_single_chunk`
 (slam/offline_chunk_creator.py:161-256) - masks, intrinsics LM, grid keypoints (234-point grid -> per-frame
@@ -36,13 +36,18 @@ from oracle.gen_golden import golden_images  # noqa: E402
 from oracle.gen_golden_post import _Placeholder  # noqa: E402
 from pi3_slam_amd.weights import Pi3Config, recipe_state_dict_cpu  # noqa: E402
 
-CASE = ("pi3_full", 100, 308, 406, 200)      # name, frames, H, W, max_num_keypoints
-SUB, ROWS = 7, 512                            # pixel stride of the dense maps, token-row stride of the intermediates
+CASES = {
+    "pi3_full": (100, 308, 406, 200, 7, 512),     # frames, H, W, max_num_keypoints, pixel stride, token-row stride
+    # BASELINE configs[3]'s frame shape (EuRoC 752 x 480 -> 280 x 448: 640 patches, T = 645), --estimate-intrinsics, grid
+    # K = 200; 32 frames: S = 20 640 tokens, i.e. the long-sequence attention kernel and the 256 x 256 GEMMs, in ~4 minutes
+    "pi3_euroc": (32, 280, 448, 200, 7, 256),
+}
 SEED = 20261005                               # torch.manual_seed before _process_single_chunk (the keypoint subsets)
 
 
 def main() -> None:
-    name, N, H, W, max_kp = CASE
+    name = next((a for a in sys.argv[1:] if not a.startswith("--")), "pi3_full")
+    N, H, W, max_kp, SUB, ROWS = CASES[name]
     want_bf16 = "--no-bf16" not in sys.argv
     torch.set_num_threads(os.cpu_count() or 8)
     for mod in ("cv2", "natsort", "plyfile", "torchvision", "torchvision.transforms", "torchcodec",

@@ -165,12 +165,17 @@ def _full_anchors(g):
     when the generator's second forward was run (`bf16err_*` inside pi3_full.npz), else those of pi3_mid (the same model
     and frame size on 8 frames) - the test says which."""
     if "bf16err_points" in g.files:
-        return g, "pi3_full (N = 100)"
+        return g, f"the fixture's own anchors (N = {int(g['shape'][0])})"
     return np.load(os.path.join(GOLDEN, "pi3_mid.npz")), "pi3_mid (N = 8; the N = 100 bf16 pass was not run)"
 
 
-def test_headline_chunk_forward_against_the_reference_at_full_size(full_engine):
-    """BASELINE configs[1] at its real size against the reference ITSELF: tests/golden/pi3_full.npz holds what the real
+FULL_SIZE_CASES = ["pi3_full", "pi3_euroc"]      # configs[1]: 100 x 308 x 406;  configs[3]'s frame shape: 32 x 280 x 448 (EuRoC)
+
+
+@pytest.mark.parametrize("case", FULL_SIZE_CASES)
+def test_headline_chunk_forward_against_the_reference_at_full_size(full_engine, case):
+    """BASELINE configs[1] at its real size against the reference ITSELF (and, `pi3_euroc`, configs[3]'s 280 x 448 frames:
+    640 patches, 645 tokens per frame, 32 frames = 20 640 tokens through the same long-sequence kernels): tests/golden/pi3_full.npz holds what the real
     `Pi3.forward` (pi3/models/pi3.py:173-216, run inside the reference's `_process_single_chunk` by
     oracle/gen_golden_full.py: 100 frames at 308 x 406, S = 64 300 tokens, recipe weights, fp32, the sdpa_kernel context
     not entered) returned - the four outputs every 7th pixel and eight intermediates every 512th token row.  The HIP path
@@ -179,12 +184,12 @@ def test_headline_chunk_forward_against_the_reference_at_full_size(full_engine):
     error, rotation in degrees) and < 1.5 % relative mean error on every intermediate.  A consistent indexing error at
     this size (frame / token / head strides beyond the 8-frame fixture's range) cannot pass."""
     from oracle.gen_golden import golden_images
-    g = np.load(os.path.join(GOLDEN, "pi3_full.npz"))
+    g = np.load(os.path.join(GOLDEN, case + ".npz"))
     N, H, W, _ = (int(v) for v in g["shape"])
     sub, rows = (int(v) for v in g["strides"])
-    assert (N, H, W) == (100, 308, 406)
+    assert (N, H, W) == {"pi3_full": (100, 308, 406), "pi3_euroc": (32, 280, 448)}[case]
     anchors, which = _full_anchors(g)
-    out = full_engine.forward(golden_images("pi3_full", 1, N, H, W), return_intermediates=True)
+    out = full_engine.forward(golden_images(case, 1, N, H, W), return_intermediates=True)
     torch.cuda.synchronize()
     report = {}
     for k in ("points", "local_points", "conf", "camera_poses"):
@@ -207,21 +212,23 @@ def test_headline_chunk_forward_against_the_reference_at_full_size(full_engine):
             r = ((got - ref).abs().mean() / ref.abs().mean()).item()
             report[k] = r
             assert r < 1.5e-2, (k, r)
-    print(f"pi3_full vs the reference, in units of its own bf16 deviation [{which}] (mean, max): {report}; rotation {rot:.3f} deg")
+    print(f"{case} vs the reference, in units of its own bf16 deviation [{which}] (mean, max): {report}; rotation {rot:.3f} deg")
     # per-frame check: no frame may be an outlier (an error confined to late frames would hide in the chunk mean)
     d = (out["local_points"].float().cpu()[0, :, ::sub, ::sub] - torch.from_numpy(g["local_points"])[0]).abs().mean(dim=(1, 2, 3))
     assert d.max().item() <= 4.0 * anchors["bf16err_local_points"][0], (int(d.argmax()), d.max().item())
 
 
-def test_headline_chunk_dictionary_against_the_reference_at_full_size(full_engine):
-    """`OfflineChunkCreator._process_single_chunk` at cl = 100, K = 200 (the benchmarked configuration) against the
+@pytest.mark.parametrize("case", FULL_SIZE_CASES)
+def test_headline_chunk_dictionary_against_the_reference_at_full_size(full_engine, case):
+    """`OfflineChunkCreator._process_single_chunk` at cl = 100, K = 200 (the benchmarked configuration; `pi3_euroc`: 32
+    frames at configs[3]'s 280 x 448 with intrinsics estimation) against the
     dictionary the reference's own method returned for the same frames (tests/golden/pi3_full.npz, `c_*` entries): same
     keys, dtypes and shapes; keypoints (the 234-point grid, per-frame `torch.randperm` subsets of 200 drawn from the global
     CPU generator seeded as in the generator), colours, descriptors, scores bit for bit; network values at the keypoints
     within 2x the reference's bf16 deviation; keypoint masks within the stated flip bound; intrinsics' layout."""
     from oracle.gen_golden import golden_images
     from pi3_slam_amd.chunk_creator import OfflineChunkCreator, OfflineCreatorConfig
-    g = np.load(os.path.join(GOLDEN, "pi3_full.npz"))
+    g = np.load(os.path.join(GOLDEN, case + ".npz"))
     anchors, which = _full_anchors(g)
     N, H, W, max_kp = (int(v) for v in g["shape"])
     cfg = OfflineCreatorConfig(model_path="recipe", output_dir="/tmp/pi3_t_chunk_full", chunk_length=N, overlap=20,
@@ -229,7 +236,7 @@ def test_headline_chunk_dictionary_against_the_reference_at_full_size(full_engin
                                estimate_camera_params=True, num_loader_workers=0, keypoint_seed=None)   # global RNG, as the reference
     cr = OfflineChunkCreator(cfg, model=full_engine, moge_model=None)
     cr.target_size = (H, W)
-    imgs = golden_images("pi3_full", 1, N, H, W)
+    imgs = golden_images(case, 1, N, H, W)
     torch.manual_seed(int(g["seed"][0]))
     res = cr._process_single_chunk(imgs, [[f"frame_{i:03d}.png"] for i in range(N)])
     schema = []
@@ -257,7 +264,7 @@ def test_headline_chunk_dictionary_against_the_reference_at_full_size(full_engin
     # bound: 2x the flips of the reference's OWN bf16 run against its fp32 run on the dense maps when the generator
     # measured them (bf16err_mask_flips), with the floor of the 8-frame test (0.1 %)
     bound = max(2.0 * float(g["bf16err_mask_flips"][0]) if "bf16err_mask_flips" in g.files else 0.0, MASK_FLIPS_FLOOR)
-    print(f"pi3_full keypoint-mask flips vs the reference's fp32 run: {mism:.5f} of {res['masks'].numel()} (bound {bound:.5f}; "
+    print(f"{case} keypoint-mask flips vs the reference's fp32 run: {mism:.5f} of {res['masks'].numel()} (bound {bound:.5f}; "
           f"reference masks true on {ref_masks.float().mean().item():.4f})")
     assert mism <= bound, (mism, bound)
     K_ref, K_got = torch.from_numpy(g["c_intrinsics"]), res["intrinsics"]
@@ -271,7 +278,7 @@ def test_headline_chunk_dictionary_against_the_reference_at_full_size(full_engin
     out = full_engine(imgs)
     dense = cr._compute_masks(out)[0].bool().cpu()[:, ::sub, ::sub]
     dm = (dense != torch.from_numpy(g["masks_dense"])).float().mean().item()
-    print(f"pi3_full dense-mask flips: {dm:.5f}")
+    print(f"{case} dense-mask flips: {dm:.5f}")
     assert dm <= bound, (dm, bound)
 
 

@@ -346,3 +346,29 @@ def test_ba_summary_and_keypoint_weights():
     assert w.shape == (2, 7) and w.dtype == torch.float32
     want = torch.sigmoid(conf[[4, 1]].float().reshape(2, 7)) * masks[[4, 1]].reshape(2, 7).float()
     assert torch.equal(w, want) and (w[~masks[[4, 1]].reshape(2, 7)] == 0).all() and (w <= 1).all()
+
+
+def test_hostmem_byte_movers_equal_the_aten_operators():
+    """pi3_slam_amd/hostmem.py moves the consumer side's bytes with memcpy / calloc instead of ATen CPU operators (the
+    OpenMP regions behind the one-off 85-110 ms host stalls of round 4): same values, dtypes, shapes, and fresh storage."""
+    from pi3_slam_amd import hostmem
+    g = torch.Generator().manual_seed(3)
+    for t in (torch.randn(60, 200, 3, generator=g).half(), torch.randn(7, 5, generator=g), torch.rand(33, generator=g) > 0.5,
+              torch.randint(0, 255, (40, 3), generator=g, dtype=torch.uint8), torch.randn(6, 4, 4, generator=g).double(),
+              torch.zeros(0, 3)):
+        c = hostmem.clone_host(t)
+        assert c.dtype == t.dtype and c.shape == t.shape and torch.equal(c, t) and (t.numel() == 0 or c.data_ptr() != t.data_ptr())
+    nc = torch.randn(8, 6, generator=g).t()                      # non-contiguous source
+    assert torch.equal(hostmem.clone_host(nc), nc) and hostmem.clone_host(nc).is_contiguous()
+    z = hostmem.zeros_host((3, 4, 128), torch.float16)
+    assert z.dtype == torch.float16 and z.shape == (3, 4, 128) and float(z.abs().sum()) == 0
+    z[0, 0, 0] = 1                                                # writable, owned
+    o = hostmem.full_host((5, 7), 1.0, torch.float16)
+    assert o.dtype == torch.float16 and torch.equal(o, torch.ones(5, 7, dtype=torch.float16))
+    # byte copy between views of different dtype (how the packed D2H buffer is unpacked)
+    src = torch.arange(24, dtype=torch.uint8)
+    dst = torch.empty(6, dtype=torch.float32)
+    hostmem.memcpy_into(dst, src)
+    assert torch.equal(dst.view(torch.uint8), src)
+    with pytest.raises(AssertionError):
+        hostmem.memcpy_into(torch.empty(5, dtype=torch.float32), src)

@@ -532,6 +532,41 @@ def test_attention_bounded_score_and_online_max_paths(dev):
         ops.attention_path_counters(None)
 
 
+@pytest.mark.parametrize("B,S,H,spoil", [(1, 4096, 1, 0), (1, 4097, 2, 0), (2, 4160, 3, 0), (1, 4544, 2, 1), (1, 5000, 16, 0),
+                                         (3, 4608, 1, 2), (1, 8191, 4, 0), (1, 12345, 2, 1), (1, 4099, 1, 0)])
+def test_attention_hand_placed_loop_equals_the_compiler_kernel_bitwise(dev, B, S, H, spoil):
+    """attn_fwd64a_kernel (generated inline-asm main loop, the default for the eight-wave kernel) against the
+    compiler-scheduled attn_fwd64_kernel<8> (knob attn_asm = 0): the same arithmetic in the same order, so equal BIT FOR
+    BIT - at the shortest sequences the kernel takes (64 tiles), tile counts 0 / 1 / 2 mod 3 (the K ring has three slots)
+    and even / odd (the V ring two), full and partial last tiles (1 ... 63 keys), several batches and heads, and with
+    `spoil` waves pushed over the score bound (those workgroups fall back to the C++ body inside the kernel; spoil = 2:
+    every workgroup of a head).  Also against the fp32 softmax."""
+    from pi3_slam_amd import lib, ops
+    g = torch.Generator(device=dev).manual_seed(S * 7 + H)
+    qkv = torch.randn(B * S, 3 * H * 64, device=dev, generator=g)
+    qkv[:, :H * 64] *= ops.QSCALE * 2.0
+    if spoil == 1:
+        qkv[S // 3: S // 3 + 64, :64] *= 10.0                      # one wave of head 0
+    if spoil == 2:
+        qkv[:, :64] *= 10.0                                        # all of head 0, every batch
+    qkv = qkv.bfloat16()
+    outs = []
+    try:
+        for asm in (1, 0):
+            lib.set_knob("attn_asm", asm)
+            o = torch.full((B * S, H * 64), float("nan"), device=dev, dtype=torch.bfloat16)
+            ops.attention(qkv, o, B, S, H)
+            torch.cuda.synchronize()
+            outs.append(o)
+    finally:
+        lib.set_knob("attn_asm", 1)
+    assert torch.isfinite(outs[0].float()).all()
+    assert torch.equal(outs[0], outs[1]), int((outs[0] != outs[1]).sum())
+    if spoil != 2 and S <= 8191:
+        mx, mean = rel(outs[0], attn_ref(qkv, B, S, H))
+        assert mx < 8e-3 and mean < 5e-3, (mx, mean)
+
+
 @pytest.mark.parametrize("M,N,K,reps", [(5000, 256, 4096, 40), (2049, 1024, 1024, 40), (1024, 256, 64, 60), (33000, 512, 192, 20)])
 def test_gemm256_repeatable_bitwise(dev, M, N, K, reps):
     """Race screen for the staggered-wave 256x256 kernel (waves 4-7 one barrier behind waves 0-3, counted vmcnt, raw

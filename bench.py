@@ -346,6 +346,18 @@ def main(args) -> None:
             if rank == 0:
                 print(f"[bench] MoGe engine unavailable ({e}); metric scaling is NOT in the timed region", file=sys.stderr)
 
+    if not stub and os.environ.get("PI3_BENCH_PLAIN_RECIPE") != "1":
+        # Plain recipe weights make EVERY pixel a depth edge (z = exp(random) differs by ~50 % between neighbours): masks
+        # empty, the MoGe ratio median NaN, the rescale a no-op - the post-processing kernels would run on degenerate
+        # data.  The same edit as oracle/gen_golden_full.mask_overrides (fixture pi3_full_masks): z constant inside a
+        # patch and a few per cent apart between patches, confidence logits straddling the sigmoid > 0.1 threshold.
+        # Shapes, kernels and launch counts are unchanged (the edit touches 197 rows of two fp32 head matrices).
+        with torch.no_grad():
+            w_, b_ = engine.w["point_head.proj.weight"], engine.w["point_head.proj.bias"]
+            w_[392:588] = 0.05 * w_[392:393].clone()
+            b_[392:588] = b_[392].clone()
+            engine.w["conf_head.proj.bias"][:196] -= 2.2
+
     def make_creator(kp: int, out_dir: str = "/tmp/pi3_bench_out", workers: int = 0):
         cc = OfflineCreatorConfig(model_path="recipe", output_dir=out_dir, chunk_length=CL, overlap=OV,
                                   device=str(dev), do_metric_depth=moge is not None, keypoint_type="grid",
@@ -514,9 +526,11 @@ def main(args) -> None:
                        "timed_from": "pinned host uint8 frames (H2D + device resize inside the timed region)",
                        "moge_metric_scale_in_timed_region": moge is not None,
                        "metric_scale_usable_chunks": sum(1 for s in stats if s.get("metric_scale") is not None),
-                       "metric_scale_note": "MoGe forward, masked ratio median and the rescale kernels run in every chunk; "
-                                            "with recipe weights frame 0's mask is usually empty (random depth is all edges), "
-                                            "the median is then NaN and the rescale applies 1.0, as the warning on stderr says",
+                       "metric_scale_note": "MoGe forward, masked ratio median and the rescale kernels run in every chunk; the "
+                                            "recipe's point / confidence heads are edited as in fixture pi3_full_masks so that "
+                                            "masks are not empty (plain recipe weights make every pixel a depth edge: "
+                                            "PI3_BENCH_PLAIN_RECIPE=1 restores that, the median is then NaN and the rescale "
+                                            "applies 1.0)",
                        "algorithmic_tflop_per_chunk": fl["total"] / 1e12},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_DENSE_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_BF16_DENSE_TFLOPS, "traffic": ATTN_TRAFFIC_BYTES,

@@ -41,7 +41,25 @@ CASES = {
     # BASELINE configs[3]'s frame shape (EuRoC 752 x 480 -> 280 x 448: 640 patches, T = 645), --estimate-intrinsics, grid
     # K = 200; 32 frames: S = 20 640 tokens, i.e. the long-sequence attention kernel and the 256 x 256 GEMMs, in ~4 minutes
     "pi3_euroc": (32, 280, 448, 200, 7, 256),
+    # the headline chunk again with the point / confidence heads edited (mask_overrides) so that the reference's masks are
+    # NOT all false: with plain recipe weights every pixel is a depth edge (z = exp(random) differs by ~50 % between
+    # neighbours), so every other reference-generated fixture compares masks that are trivially empty
+    "pi3_full_masks": (100, 308, 406, 200, 7, 0),
 }
+
+
+def mask_overrides(sd):
+    """Edit a recipe state dict in place (fixture pi3_full_masks; tests apply the same edit to the engine):
+    * the 196 z rows of point_head.proj (rows 392..587, pi3/models/layers/transformer_head.py:70-80) all become 0.05 x row
+      392 with one bias: z = exp(z_raw) is then constant inside a 14 x 14 patch and differs by a few per cent between
+      patches - `depth_edge(rtol = 0.03)` (pi3/utils/geometry.py:347-375) fires on some patch borders and not on others;
+    * conf_head.proj.bias drops by 2.2, which puts the `sigmoid(conf) > 0.1` threshold (logit -2.197,
+      offline_chunk_creator.py:116) inside the distribution of the confidence logits."""
+    w, b = sd["point_head.proj.weight"], sd["point_head.proj.bias"]
+    w[392:588] = 0.05 * w[392:393].clone()
+    b[392:588] = b[392].clone()
+    sd["conf_head.proj.bias"] -= 2.2
+    return sd
 SEED = 20261005                               # torch.manual_seed before _process_single_chunk (the keypoint subsets)
 
 
@@ -75,7 +93,11 @@ def main() -> None:
     torch.nn.attention.sdpa_kernel = lambda *a, **k: contextlib.nullcontext()      # the one change (docstring)
 
     model = Pi3().eval()
-    missing, unexpected = model.load_state_dict(recipe_state_dict_cpu(Pi3Config()), strict=False)
+    sd = recipe_state_dict_cpu(Pi3Config())
+    if name == "pi3_full_masks":
+        mask_overrides(sd)
+    missing, unexpected = model.load_state_dict(sd, strict=False)
+    del sd
     assert not unexpected and set(missing) <= {"image_mean", "image_std"}
     cr = object.__new__(OfflineChunkCreator)
     cr.config = OfflineCreatorConfig(model_path="unused", output_dir="/tmp/pi3_full_golden", chunk_length=N, overlap=20,
@@ -93,7 +115,7 @@ def main() -> None:
         return lambda m, a, o=None: cap.__setitem__(
             key, (a[0] if o is None else o).detach().reshape(-1, (a[0] if o is None else o).shape[-1])[::ROWS].clone())
 
-    hooks = [
+    hooks = [] if ROWS == 0 else [
         model.encoder.blocks[0].register_forward_pre_hook(keep("tokens")),
         model.decoder[0].register_forward_pre_hook(keep("enc_out")),
         model.decoder[0].register_forward_hook(keep("dec0")),
@@ -102,8 +124,8 @@ def main() -> None:
         model.point_decoder.register_forward_hook(keep("point_decoder")),
         model.conf_decoder.register_forward_hook(keep("conf_decoder")),
         model.camera_decoder.register_forward_hook(keep("camera_decoder")),
-        model.register_forward_hook(lambda m, a, o: dense.update({k: v.detach().clone() for k, v in o.items()})),
     ]
+    hooks.append(model.register_forward_hook(lambda m, a, o: dense.update({k: v.detach().clone() for k, v in o.items()})))
     t0 = time.time()
     torch.manual_seed(SEED)
     res = cr._process_single_chunk(imgs, [[f"frame_{i:03d}.png"] for i in range(N)])

@@ -282,6 +282,62 @@ def test_headline_chunk_dictionary_against_the_reference_at_full_size(full_engin
     assert dm <= bound, (dm, bound)
 
 
+def test_headline_chunk_masks_against_the_reference_where_masks_are_not_trivial(full_engine):
+    """With plain recipe weights the reference's masks are all false (every pixel is a depth edge), so the fixtures above
+    compare empty masks.  tests/golden/pi3_full_masks.npz is the same headline-size run of the REAL `Pi3` +
+    `_process_single_chunk` with the point / confidence heads edited (oracle/gen_golden_full.mask_overrides: z constant
+    inside a patch and a few per cent apart between patches; confidence logits straddling the sigmoid > 0.1 threshold):
+    the reference's dense masks are true on a non-trivial share of the pixels, and `sigmoid(conf) > 0.1 & ~depth_edge(z,
+    0.03)` (offline_chunk_creator.py:114-119) thresholds values the network produced.  The same edit goes into the engine;
+    dense masks (every 7th pixel) and the nearest-sampled keypoint masks may differ from the reference's fp32 run on at
+    most 2x the share on which the reference's OWN bf16-autocast run differs from it (floor 0.1 %)."""
+    from oracle.gen_golden import golden_images
+    from oracle.gen_golden_full import mask_overrides
+    from pi3_slam_amd.chunk_creator import OfflineChunkCreator, OfflineCreatorConfig
+    from pi3_slam_amd.weights import Pi3Config, recipe_state_dict_cpu
+    g = np.load(os.path.join(GOLDEN, "pi3_full_masks.npz"))
+    N, H, W, max_kp = (int(v) for v in g["shape"])
+    sub = int(g["strides"][0])
+    ref_dense = torch.from_numpy(g["masks_dense"])
+    frac = ref_dense.float().mean().item()
+    assert 0.05 < frac < 0.95, frac                                    # the point of this fixture
+    names = ("point_head.proj.weight", "point_head.proj.bias", "conf_head.proj.bias")
+    sd = mask_overrides(recipe_state_dict_cpu(Pi3Config(), names=names))
+    saved = {n: full_engine.w[n] for n in names}
+    try:
+        for n in names:
+            full_engine._install(n, sd[n].to(full_engine.device))
+        cfg = OfflineCreatorConfig(model_path="recipe", output_dir="/tmp/pi3_t_chunk_masks", chunk_length=N, overlap=20,
+                                   do_metric_depth=False, keypoint_type="grid", max_num_keypoints=max_kp,
+                                   estimate_camera_params=True, num_loader_workers=0, keypoint_seed=None)
+        cr = OfflineChunkCreator(cfg, model=full_engine, moge_model=None)
+        cr.target_size = (H, W)
+        imgs = golden_images("pi3_full_masks", 1, N, H, W)
+        torch.manual_seed(int(g["seed"][0]))
+        res = cr._process_single_chunk(imgs, [[f"frame_{i:03d}.png"] for i in range(N)])
+        out = full_engine(imgs)
+        dense = cr._compute_masks(out)[0].bool().cpu()[:, ::sub, ::sub]
+        z = out["local_points"][0, :, ::sub, ::sub, 2].float().cpu()
+        conf = out["conf"][0, :, ::sub, ::sub, 0].float().cpu()
+    finally:
+        for n in names:
+            full_engine.w[n] = saved[n]
+    bound = max(2.0 * float(g["bf16err_mask_flips"][0]), MASK_FLIPS_FLOOR)
+    dm = (dense != ref_dense).float().mean().item()
+    km = (res["masks"] != torch.from_numpy(g["c_masks"])).float().mean().item()
+    print(f"pi3_full_masks: reference masks true on {frac:.3f} of the pixels; dense flips {dm:.5f}, keypoint flips {km:.5f} "
+          f"(bound {bound:.5f} = 2x the reference's own bf16-vs-fp32 flips {float(g['bf16err_mask_flips'][0]):.5f})")
+    assert dm <= bound and km <= 2.0 * bound + 1e-3, (dm, km, bound)
+    # the thresholded quantities themselves, against the reference's: z and the confidence logits within 2x its bf16 deviation
+    dz = (z - torch.from_numpy(g["local_points"])[0, ..., 2]).abs().mean().item()
+    dc = (conf - torch.from_numpy(g["conf"])[0, ..., 0]).abs().mean().item()
+    assert dz <= 2.0 * g["bf16err_local_points"][0] and dc <= 2.0 * g["bf16err_conf"][0], (dz, dc)
+    # keypoints and colours do not depend on the edit: still bit for bit
+    f16 = lambda k: torch.from_numpy(g["c_" + k]).view(torch.float16)      # noqa: E731
+    for k in ("keypoints", "colors"):
+        assert torch.equal(res[k].view(torch.int16), f16(k).view(torch.int16)), k
+
+
 @pytest.mark.parametrize("shape", [(1, 3, 28, 42), (2, 2, 70, 70), (1, 4, 56, 84), (1, 1, 14, 14), (1, 1, 42, 28),
                                    (3, 1, 28, 28), (1, 2, 28, 70)])
 def test_small_config_against_oracle(dev, shape):

@@ -62,3 +62,19 @@ def test_product_does_not_import_oracle():
             if f.endswith(".py"):
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
+
+
+def test_generated_attention_loop_is_in_sync_with_its_generator(tmp_path):
+    """pi3_slam_amd/csrc/attn64a_loop.inc (the hand-placed main loop of attn_fwd64a_kernel) is committed generator output:
+    tools/gen_attn_asm.py must reproduce it byte for byte, so nobody edits one without the other."""
+    import subprocess
+    import sys
+    out = tmp_path / "loop.inc"
+    env = dict(os.environ, A64A_OUT=str(out))
+    env.pop("A64A_ABL", None)
+    env.pop("A64A_OPT", None)
+    subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_attn_asm.py")], check=True, env=env, capture_output=True)
+    committed = open(os.path.join(ROOT, "pi3_slam_amd", "csrc", "attn64a_loop.inc")).read()
+    assert out.read_text() == committed
+    # the loop's fixed registers stay clear of the compiler's share (operands live below v150) and inside the file
+    assert '#define A64A_V0 150' in committed and '"v255"' in committed and '"v256"' not in committed

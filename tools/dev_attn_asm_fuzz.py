@@ -1,0 +1,40 @@
+"""Seeded fuzz of the hand-placed attention loop against the compiler-scheduled kernel (bit identity): random sequence
+lengths (every residue of the tile count mod 3 and mod 2, every partial-tile length), heads, batches, strides, and waves
+pushed over the score bound.      python tools/dev_attn_asm_fuzz.py [cases=60] [seed=0]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from pi3_slam_amd import lib, ops
+dev = torch.device("cuda:0")
+cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+g = torch.Generator().manual_seed(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+bad = 0
+for c in range(cases):
+    S = int(torch.randint(4096, 14000, (1,), generator=g))
+    H = int(torch.randint(1, 5, (1,), generator=g))
+    B = int(torch.randint(1, 3, (1,), generator=g))
+    spoil = int(torch.randint(0, 4, (1,), generator=g))
+    scale = float(torch.rand(1, generator=g)) * 3 + 0.5
+    qkv = torch.randn(B * S, 3 * H * 64, device=dev) * 0.6
+    qkv[:, :H * 64] *= ops.QSCALE * scale
+    if spoil == 1:
+        r0 = int(torch.randint(0, S - 64, (1,), generator=g))
+        qkv[r0:r0 + 64, :64] *= 40.0
+    if spoil == 2:
+        qkv[:, (H - 1) * 64:H * 64] *= 40.0
+    qkv = qkv.bfloat16()
+    outs = []
+    for asm in (1, 0):
+        lib.set_knob("attn_asm", asm)
+        o = torch.full((B * S, H * 64), float("nan"), device=dev, dtype=torch.bfloat16)
+        ops.attention(qkv, o, B, S, H)
+        torch.cuda.synchronize()
+        outs.append(o)
+    lib.set_knob("attn_asm", 1)
+    same = torch.equal(outs[0], outs[1]) and bool(torch.isfinite(outs[0].float()).all())
+    bad += not same
+    if not same or c % 10 == 0:
+        print(f"case {c}: B={B} S={S} (tiles {(S + 63) // 64}, last {S % 64 or 64}) H={H} spoil={spoil} scale={scale:.2f} -> "
+              f"{'identical' if same else 'DIFFERENT: ' + str(int((outs[0] != outs[1]).sum()))}", flush=True)
+print(f"{cases} cases, {bad} different")
+sys.exit(1 if bad else 0)

@@ -67,10 +67,15 @@ int pi3_gemm_qkv(const void* A, long lda, const void* W, long ldw, int M, int K,
 /* F.scaled_dot_product_attention, non-causal, head_dim 64 (pi3/models/layers/attention.py:102-107, 336-341).
  * q/k/v: bf16, element (b, s, h, d) at ptr[b*batch_stride + s*tok_stride + h*64 + d]; q PRE-SCALED by
  * 64^-0.5 * log2(e).  o: bf16 [B][S][H*64] with the given strides.
+ * o must not overlap q/k/v.
  * k2max_ws: caller-provided workspace of B*H floats (this library allocates nothing) for max_s |k[b,s,h,:]|^2, or
- * NULL.  With it the long-sequence kernel takes its bounded-score path (no running max) for every wave whose scores
- * are provably inside the fp32/bf16 exponent range, otherwise - and always when NULL - the online-max loop; both are
- * exact.  k2max_ready = 0: the call zeroes the workspace and fills it with a pre-pass over k; 1: the workspace already
+ * NULL.  With it the 64-row kernel keeps its bounded-score loop (no running max) without further ado for every wave
+ * whose scores are provably inside the fp32/bf16 exponent range (|q| max|k| <= 90 in the exp2 domain).  Other waves -
+ * all of them when NULL - run the same loop optimistically (knob attn_nomax = 2, the default): their workgroup keeps
+ * the result iff every row sum lies in [2^-60, 2^120] and the outputs are finite, else a second launch inside this call
+ * recomputes that workgroup on the online-max loop (attn64.hip, a64_reject).  Knob 1: waves outside the bound go to
+ * the online-max loop directly (rounds 3-4); 0: online-max loop everywhere.  Every form is the exact softmax.
+ * k2max_ready = 0: the call zeroes the workspace and fills it with a pre-pass over k; 1: the workspace already
  * holds the maxima (written by pi3_gemm's fused q/k epilogue, see pi3_gemm_qkv).
  * dtype: 0 = q/k/v/o bf16 (pi3), 2 = IEEE half (MoGe: the reference runs it under fp16 autocast, moge/model/v2.py:228):
  * the same kernel on v_mfma_f32_32x32x16_f16, online-max loop only (half has 5 exponent bits), k2max_ws unused. */
@@ -80,8 +85,9 @@ int pi3_attention(const void* q, const void* k, const void* v, long tok_stride, 
 
 /* Diagnostic of pi3_attention's long-sequence kernel: which softmax loop its waves took.  counters: caller-owned DEVICE
  * memory of 128 uint32, zeroed by the caller, laid out [kind][path][32 slots] (sum the slots): kind 0 = eight-wave
- * workgroups (global attention), 1 = four-/two-wave workgroups (frame-wise attention); path 0 = bounded-score loop,
- * 1 = online-max loop.  One no-return atomic per wave while registered; NULL (the default) switches it off.
+ * workgroups (global attention), 1 = four-/two-wave workgroups (frame-wise attention); path 0 = the wave's result comes
+ * from the bounded-score loop, 1 = from the online-max loop (under knob attn_nomax = 2 these are the waves of workgroups
+ * that rejected the optimistic pass and ran again).  One no-return atomic per wave while registered; NULL (the default) switches it off.
  * Process-wide; change it only while no attention launch is in flight.  bench.py reports the fractions with it. */
 int pi3_attention_path_counters(unsigned int* counters);
 

@@ -53,6 +53,8 @@ struct Attn64Params {
   int tailopt;          // 1: short-sequence waves skip query blocks / key halves that do not exist (A/B knob, default 1)
   unsigned long long* dbg;   // -DPI3_ATTN_STAMPS builds only: s_memtime stamps of workgroup 0
   unsigned* stats;      // optional caller-owned path counters (pi3_attention_path_counters), else null
+  int optim;            // 1: optimistic bounded-score loop + acceptance test (a64_reject); 0: a-priori test on k2max
+  int redo;             // 1: the follow-up launch of the optimistic form: only workgroups that left the mark run, on the online-max loop
 };
 #ifndef A64_ABL   // development builds only (-DA64_ABL=n, a separate .so): timing ablations with WRONG results.
 #define A64_ABL 0   // 1 no exp, 3 no P.V MFMAs, 4 no Q.K^T MFMAs, 5 no barrier / DMA wait, 6 no row-sum MFMAs, 7 one LDS fragment reused
@@ -110,6 +112,46 @@ template <bool F16>
 __device__ __forceinline__ uint32_t a64_pack(float lo, float hi) {
   if constexpr (F16) return pack_f16x2(lo, hi);
   else return pack_bf16x2(lo, hi);
+}
+
+// Optimistic bounded-score loop (round 5, knob attn_nomax = 2, the default).  The a-priori bound |q| max|k| <= 90 is a
+// Cauchy-Schwarz bound: it fails as soon as ONE key of a head has a large norm although the scores themselves stay
+// moderate (the learned q/k LayerNorm gains of real weights decide, and nobody has them offline).  The loop without a
+// running maximum is exact whenever no p = exp2(s) overflows and the terms that matter are normal numbers, and both can
+// be read off the result: a workgroup whose waves are not all inside the a-priori bound (those need no test: |s| <= 90)
+// runs the loop anyway and ACCEPTS it iff for each row of the waves outside the bound
+//   2^-60 <= l <= 2^120  and every accumulator of O is finite.
+// l finite: no p overflowed (p <= l).  l >= 2^-60: the largest p of the row is >= 2^-60 / S >= 2^-77, so every term within
+// 2^-49 of it is a normal bf16 / fp32 number and what was flushed is below fp32 resolution of the sum.  l <= 2^120 keeps
+// the sums themselves away from the top of the range; O = sum p v is tested directly (|v| > 2^7 can overflow it first).
+// In score terms: a row is kept when its largest score lies in about [-76, 120 - log2(#keys near the maximum)].
+// A rejected workgroup (workgroup-uniform: one __syncthreads_or) stores NOTHING but a mark - the bf16 pattern A64_MARK (a
+// NaN with a payload) in the first output element it owns - and a second launch of the compiler-scheduled kernel (redo = 1,
+// same grid) runs the online-max loop for exactly the marked workgroups; every other workgroup of that launch reads one
+// element and leaves.  A genuine result that happens to carry the pattern only costs a re-run that stores the same softmax
+// again.  The result is therefore the same softmax for every input.  Price (profiles/r05c_attention_optimistic_ab.log, one
+// process): the almost empty second launch is not measurable (14.655 against 14.648 ms for the a-priori form); with one
+// 8 x-norm key per head - the a-priori bound broken for 2 015 of 2 016 workgroups, scores moderate - the a-priori form takes
+// 17.74 ms, the online-max loop 17.76 ms and this form 14.69 ms with no workgroup rejected.  A rejected workgroup pays its
+// time again on the slower loop: in the frame-wise launches 24 us spread over the card, in the global launch the 2.1 ms ONE
+// workgroup takes to sweep 1 005 key tiles however few are rejected; every workgroup rejected would cost both loops.
+// In-kernel re-runs (a second inlined body, or a loop around one) were built first: hipcc then spills 70-80 registers per
+// lane in the main loops (ScratchSize 32 -> 320 bytes in the hand-placed kernel).  o must not alias q/k/v.
+#define A64_MARK 0x7FC1
+#define A64_LSUM_LO 8.673617379884035e-19f    // 2^-60
+#define A64_LSUM_HI 1.329227995784916e+36f    // 2^120
+__device__ __forceinline__ bool a64_reject(float lpart, const f32x16 (&o)[2]) {
+  const float l = lpart + __shfl_xor(lpart, 32, 64);
+  float chk = 0.f;       // inf / NaN in any accumulator ends up here (a finite sum that overflows only costs a re-run)
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) chk += fabsf(o[dt][i]);
+  return !(l >= A64_LSUM_LO && l <= A64_LSUM_HI && chk <= 3.0e38f);
+}
+// the first output element a workgroup owns (row qb * rows-per-workgroup < S always exists)
+__device__ __forceinline__ unsigned short* a64_mark_ptr(const Attn64Params& p, int b, int qb, int head, int rows) {
+  return (unsigned short*)(p.o + (long)b * p.o_batch_stride + (long)qb * rows * p.o_tok_stride + head * 64);
 }
 
 // online-softmax step of one 32-row block on its two raw score tiles; m is the per-lane running max (exp2 domain).
@@ -203,6 +245,10 @@ __device__ __forceinline__ void a64_body(const Attn64Params& p, char* lds) {   /
   const int head = (id / p.nqb) % p.H;
   const int b = id / (p.nqb * p.H);
   const int S = p.S;
+  if (!F16 && p.redo) {      // follow-up launch of the optimistic form: only marked workgroups run (workgroup-uniform)
+    if (__builtin_nontemporal_load(a64_mark_ptr(p, b, qb, head, NW * 64)) != A64_MARK) return;
+    __syncthreads();         // every wave has read the mark before wave 0's stores can replace it
+  }
 
   const int q0 = qb * (NW * 64) + wave * 64;
   bf16x8 qfA[4], qfB[4];
@@ -433,8 +479,8 @@ __device__ __forceinline__ void a64_body(const Attn64Params& p, char* lds) {   /
   // query blocks this wave owns (see A64_TILE); long sequences (NW == 8) keep the single two-block path
   const int nb = (NW <= 4 && p.tailopt) ? (q0 >= S ? 0 : (q0 + 32 >= S ? 1 : 2)) : 2;
   // bounded-score test (see header): wave-uniform
-  bool fast = false;
-  if (!F16 && p.k2max && nb > 0) {
+  bool fast = false;       // the a-priori test (wave-uniform); the optimistic form then runs the bounded-score loop anyway
+  if (!F16 && p.k2max && nb > 0 && !p.redo) {
     const float k2 = p.k2max[b * p.H + head];
     float qa = 0.f, qb = 0.f;
 #pragma unroll
@@ -449,6 +495,8 @@ __device__ __forceinline__ void a64_body(const Attn64Params& p, char* lds) {   /
     qb += __shfl_xor(qb, 32, 64);
     fast = __all(fmaxf(qa, qb) * k2 <= A64_BOUND2);
   }
+  const bool sure = fast;  // inside the a-priori bound: nothing to test afterwards
+  if (!F16 && p.optim) fast = !p.redo;
   // static priority for the second-dispatched half (MI355X_MICROARCH.md, two waves per SIMD, item 4): the younger
   // wave of a SIMD loses every VALU arbitration at equal priority
   if (p.prio && wave >= NW / 2) __builtin_amdgcn_s_setprio(1);
@@ -468,6 +516,15 @@ __device__ __forceinline__ void a64_body(const Attn64Params& p, char* lds) {   /
 #ifdef PI3_ATTN_STAMPS
   if (st_on) st[2] = a64_realtime();
 #endif
+  if (!F16 && p.optim && !p.redo) {     // acceptance test of the optimistic bounded-score loop (workgroup-uniform branch)
+    bool bad = false;
+    if (nb > 0 && !sure) bad = a64_reject(lA + laccA[0], oA);
+    if (nb > 1 && !sure) bad = bad || a64_reject(lB + laccB[0], oB);
+    if (__syncthreads_or(bad)) {
+      if (tid == 0) *a64_mark_ptr(p, b, qb, head, NW * 64) = A64_MARK;
+      return;
+    }
+  }
   // finalize both blocks
 #pragma unroll
   for (int blk = 0; blk < 2; ++blk) {
@@ -559,7 +616,8 @@ __global__ __launch_bounds__(512, 2) void attn_fwd64a_kernel(Attn64Params p) {
     qbn += __shfl_xor(qbn, 32, 64);
     fast = __all(fmaxf(qa, qbn) * k2 <= A64_BOUND2);
   }
-  if (!(nt >= 8 && __syncthreads_and(fast))) {      // workgroup-uniform
+  const bool sure = __syncthreads_and(fast) != 0;               // every wave inside the a-priori bound (workgroup-uniform)
+  if (!(nt >= 8 && (p.optim || sure))) {
     a64_body<8, true, true, false>(p, lds);
     return;
   }
@@ -694,6 +752,13 @@ __global__ __launch_bounds__(512, 2) void attn_fwd64a_kernel(Attn64Params p) {
   A64A_TILE(nt - 1, false, true)
 #undef h
 
+  if (p.optim && !sure) {       // acceptance test of the optimistic loop (a64_reject); workgroup-uniform
+    const bool bad = a64_reject(lA + laccA[0], oA) || a64_reject(lB + laccB[0], oB);
+    if (__syncthreads_or(bad)) {
+      if (tid == 0) *a64_mark_ptr(p, b, qb, head, 512) = A64_MARK;
+      return;
+    }
+  }
   if (p.stats && (threadIdx.x & 63) == 0) atomicAdd(p.stats + 0 + (blockIdx.x & 31), 1u);      // eight-wave kernel, bounded-score loop
 #pragma unroll
   for (int blk = 0; blk < 2; ++blk) {
@@ -812,8 +877,10 @@ int pi3_attention64_launch(const void* q, const void* k, const void* v, long tok
   }
   // knob attn_nomax (PI3_ATTN_NOMAX): 0 = always the online-max loop (A/B knob, how the tests reach that loop, and the
   // worst case bench.py reports beside the headline: real weights may not keep |q| max|k| inside the bound)
-  const int nomax = (int)PI3_KNOB("attn_nomax", 1);
+  const int nomax = (int)PI3_KNOB("attn_nomax", 2);
   p.k2max = nullptr;
+  p.optim = nomax == 2;
+  p.redo = 0;
   p.dbg = nullptr;
   p.stats = g_attn_stats;
   static int prio = -1;   // PI3_ATTN_PRIO: 1 = static s_setprio 1 for the second half of a workgroup's waves (A/B knob)
@@ -868,20 +935,28 @@ int pi3_attention64_launch(const void* q, const void* k, const void* v, long tok
   }
   // knob attn_asm (PI3_ATTN_ASM): 1 (default) = the kernel with the hand-placed main loop (attn_fwd64a_kernel; workgroups
   // it does not cover run the compiler-scheduled body inside it), 0 = the compiler-scheduled kernel.  Bit-identical results.
-  if (nw == 8 && glds && msum && p.k2max && PI3_KNOB("attn_asm", 1) != 0)
-    hipLaunchKernelGGL(attn_fwd64a_kernel, dim3((unsigned)nwg), dim3(512), 0, stream, p);
-  else if (nw == 8 && glds && msum)
-    hipLaunchKernelGGL((attn_fwd64_kernel<8, true, true>), dim3((unsigned)nwg), dim3(512), 0, stream, p);
-  else if (nw == 8 && glds)
-    hipLaunchKernelGGL((attn_fwd64_kernel<8, true>), dim3((unsigned)nwg), dim3(512), 0, stream, p);
-  else if (nw == 8)
-    hipLaunchKernelGGL(attn_fwd64_kernel<8>, dim3((unsigned)nwg), dim3(512), 0, stream, p);
-  else if (nw == 2)
-    hipLaunchKernelGGL((attn_fwd64_kernel<2, true, true>), dim3((unsigned)nwg), dim3(128), 0, stream, p);
-  else if (glds && msum)   // 4 waves: two independent workgroups per CU, the two waves of a SIMD drift out of phase
-    hipLaunchKernelGGL((attn_fwd64_kernel<4, true, true>), dim3((unsigned)nwg), dim3(256), 0, stream, p);
-  else
-    hipLaunchKernelGGL(attn_fwd64_kernel<4>, dim3((unsigned)nwg), dim3(256), 0, stream, p);
+  const bool use_asm = PI3_KNOB("attn_asm", 1) != 0;
+  auto launch = [&](bool allow_asm) {
+    if (nw == 8 && glds && msum && (p.k2max || p.optim) && allow_asm)
+      hipLaunchKernelGGL(attn_fwd64a_kernel, dim3((unsigned)nwg), dim3(512), 0, stream, p);
+    else if (nw == 8 && glds && msum)
+      hipLaunchKernelGGL((attn_fwd64_kernel<8, true, true>), dim3((unsigned)nwg), dim3(512), 0, stream, p);
+    else if (nw == 8 && glds)
+      hipLaunchKernelGGL((attn_fwd64_kernel<8, true>), dim3((unsigned)nwg), dim3(512), 0, stream, p);
+    else if (nw == 8)
+      hipLaunchKernelGGL(attn_fwd64_kernel<8>, dim3((unsigned)nwg), dim3(512), 0, stream, p);
+    else if (nw == 2)
+      hipLaunchKernelGGL((attn_fwd64_kernel<2, true, true>), dim3((unsigned)nwg), dim3(128), 0, stream, p);
+    else if (glds && msum)   // 4 waves: two independent workgroups per CU, the two waves of a SIMD drift out of phase
+      hipLaunchKernelGGL((attn_fwd64_kernel<4, true, true>), dim3((unsigned)nwg), dim3(256), 0, stream, p);
+    else
+      hipLaunchKernelGGL(attn_fwd64_kernel<4>, dim3((unsigned)nwg), dim3(256), 0, stream, p);
+  };
+  launch(use_asm);
+  if (p.optim) {        // the follow-up launch: workgroups that rejected the bounded-score loop run the online-max loop (a64_reject)
+    p.redo = 1;
+    launch(false);
+  }
 #ifdef PI3_ATTN_STAMPS
   {
     static int printed = 0;

@@ -39,6 +39,8 @@ struct Attn64Params {
   const float* k2max;
   int prio, tailopt;    // (attn64.hip's knobs; unused by this kernel - the struct must match attn64.hip's field for field)
   unsigned long long* dbg;
+  unsigned* stats;
+  int optim, redo;      // ignored here: this kernel keeps the a-priori test on k2max (null under attn_nomax = 2: online-max loop)
 };
 #ifndef P64_ABL   // development builds only (-DP64_ABL=1: no exp; timing ablation with WRONG results, never in the product .so)
 #define P64_ABL 0

@@ -96,6 +96,9 @@ def test_gemm_rejects_bad_shapes(dev):
         ops.gemm(a, w, torch.zeros(4, 128, device=dev, dtype=torch.bfloat16))      # K % 64 != 0
 
 
+ATTN_NOMAX_DEFAULT = 2      # knob attn_nomax: 0 online-max loop everywhere, 1 a-priori bound on |q| max|k|, 2 optimistic (attn64.hip)
+
+
 def attn_ref(qkv, B, S, H):
     q, k, v = qkv.float().view(B, S, 3, H, 64).permute(2, 0, 3, 1, 4)
     p = torch.softmax((q @ k.transpose(-1, -2)) * math.log(2.0), dim=-1)          # q is pre-scaled, exp2 domain
@@ -155,9 +158,16 @@ def test_attention_frame_sequences_bounded_score_path(dev):
     k = qkv.float().view(B, S, 3, H, 64)[:, :, 1]
     k2max = (k * k).sum(-1).amax(dim=1).reshape(-1).contiguous()          # [B][H]
     out = torch.empty(B * S, H * 64, device=dev, dtype=torch.bfloat16)
-    ops.attention(qkv, out, B, S, H, k2max=k2max)
-    mx, mean = rel(out, attn_ref(qkv, B, S, H))
-    assert mx < 8e-3 and mean < 5e-3 and torch.isfinite(out.float()).all()
+    from pi3_slam_amd import lib
+    try:
+        for knob in (1, ATTN_NOMAX_DEFAULT):      # a-priori test on max |k|^2 / the optimistic form (default)
+            lib.set_knob("attn_nomax", knob)
+            out.fill_(float("nan"))
+            ops.attention(qkv, out, B, S, H, k2max=k2max)
+            mx, mean = rel(out, attn_ref(qkv, B, S, H))
+            assert mx < 8e-3 and mean < 5e-3 and torch.isfinite(out.float()).all()
+    finally:
+        lib.set_knob("attn_nomax", ATTN_NOMAX_DEFAULT)
 
 
 def test_attention_linearity_in_v_full_size(dev):
@@ -504,7 +514,9 @@ def test_attention_bounded_score_and_online_max_paths(dev):
     out = torch.empty(B * S, H * 64, device=dev, dtype=torch.bfloat16)
     counters = torch.zeros(2, 2, 32, device=dev, dtype=torch.int32)      # pi3_attention_path_counters (what bench.py reports)
     ops.attention_path_counters(counters)
+    from pi3_slam_amd import lib
     try:
+        lib.set_knob("attn_nomax", 1)                          # the a-priori form: per-wave choice
         ops.attention(qkv, out, B, S, H)
         torch.cuda.synchronize()
         waves = counters.sum(-1).cpu()
@@ -526,9 +538,115 @@ def test_attention_bounded_score_and_online_max_paths(dev):
         assert counters.sum(-1)[0].tolist() == [0, 9 * 8 * H]
         assert rel(out2, ref)[0] < 8e-3 and rel(out2, out)[0] < 8e-3
     finally:
-        from pi3_slam_amd import lib
-        lib.set_knob("attn_nomax", 1)
+        lib.set_knob("attn_nomax", ATTN_NOMAX_DEFAULT)
         torch.cuda.synchronize()
+        ops.attention_path_counters(None)
+
+
+def _attn_with_knob(qkv, B, S, H, knob, counters=None):
+    from pi3_slam_amd import lib, ops
+    out = torch.full((B * S, H * 64), float("nan"), device=qkv.device, dtype=torch.bfloat16)
+    lib.set_knob("attn_nomax", knob)
+    try:
+        if counters is not None:
+            counters.zero_()
+        k = qkv.float().view(B, S, 3, H, 64)[:, :, 1]
+        k2max = (k * k).sum(-1).amax(dim=1).reshape(-1).contiguous()      # what the fused qkv epilogue hands over (knob 1 reads it)
+        ops.attention(qkv, out, B, S, H, k2max=k2max)
+        torch.cuda.synchronize()
+    finally:
+        lib.set_knob("attn_nomax", ATTN_NOMAX_DEFAULT)
+    return out
+
+
+@pytest.mark.parametrize("B,S,H,rows", [(1, 4608, 2, 512), (2, 643, 2, 256), (1, 8200, 1, 512), (3, 300, 2, 256)])
+def test_attention_optimistic_loop_accepts_rejects_and_reruns(dev, B, S, H, rows):
+    """Knob attn_nomax = 2 (the default): every workgroup runs the loop without a running maximum; waves inside the
+    a-priori bound keep the result as it is, the others iff 2^-60 <= l <= 2^120 and O is finite for all of their rows; a
+    rejected workgroup leaves a mark and the follow-up launch runs the online-max loop for it (attn64.hip, a64_reject).  On the eight-wave (hand-placed loop; 512 rows per
+    workgroup) and the four-wave (frame-wise; 256 rows) kernels:
+      (a) a key of 5 x the usual norm breaks the a-priori bound for every wave of its head, yet scores stay moderate:
+          all accepted, and bit-identical to the a-priori form on inputs where that one accepts too;
+      (b) rows whose scores reach 2^200 (overflow), whose scores all lie below -200 (underflow of every term), or whose
+          V holds an inf: those workgroups - and only those - are rejected, and the launch equals the all-online-max launch
+          (knob 0) bit for bit on them and the accepted launch on the rest."""
+    from pi3_slam_amd import ops
+    kind = 0 if rows == 512 else 1
+    nwg_head = (S + rows - 1) // rows
+    counters = torch.zeros(2, 2, 32, device=dev, dtype=torch.int32)
+    ops.attention_path_counters(counters)
+    try:
+        g = torch.Generator(device=dev).manual_seed(S + 13 * H)
+        base = torch.randn(B * S, 3 * H * 64, device=dev, generator=g)
+        base[:, :H * 64] *= ops.QSCALE * 2.0
+        # (a0) plain inputs: optimistic == a-priori, bit for bit, nothing rejected
+        qkv = base.bfloat16()
+        o_opt = _attn_with_knob(qkv, B, S, H, 2, counters)
+        w = counters.sum(-1).cpu()
+        assert w[kind, 1].item() == 0 and w[kind, 0].item() > 0 and w[1 - kind].sum().item() == 0
+        assert torch.equal(o_opt, _attn_with_knob(qkv, B, S, H, 1))
+        # (a1) inside the a-priori bound nothing is tested: a row of the last head at 2^85 against the head's longest key
+        # (|q| max|k| = 85 <= 90) is kept, on every form
+        x = base.clone()
+        kh = x[:S, H * 64 + 64 * (H - 1): H * 64 + 64 * H]
+        j = int((kh * kh).sum(-1).argmax())
+        x[2, 64 * (H - 1): 64 * H] = kh[j] * (85.0 / (kh[j] @ kh[j]))
+        qkv = x.bfloat16()
+        o_opt = _attn_with_knob(qkv, B, S, H, 2, counters)
+        assert counters.sum(-1)[kind, 1].item() == 0
+        assert torch.equal(o_opt, _attn_with_knob(qkv, B, S, H, 1))
+        assert (o_opt.float()[2, 64 * (H - 1):] - qkv.float()[j, 2 * H * 64 + 64 * (H - 1): 2 * H * 64 + 64 * H]).abs().max() < 2e-2
+        # (a) one key of head 0 with 5 x the norm: |q| max|k| ~ 23 * 5 > 90 for every wave of the head, scores against it ~ N(0, 14^2)
+        x = base.clone()
+        x[5, H * 64: H * 64 + 64] *= 5.0
+        qkv = x.bfloat16()
+        o_opt = _attn_with_knob(qkv, B, S, H, 2, counters)
+        w = counters.sum(-1).cpu()
+        assert w[kind, 1].item() == 0, w                       # nothing rejected although the a-priori bound fails ...
+        o_ap = _attn_with_knob(qkv, B, S, H, 1, counters)
+        assert counters.sum(-1)[kind, 1].item() > 0            # ... for (at least) a wave of head 0 in the a-priori form
+        ref = attn_ref(qkv, B, S, H)
+        assert rel(o_opt, ref)[0] < 8e-3 and rel(o_ap, ref)[0] < 8e-3
+        # (b) three bad rows in three different workgroups of batch 0 / head 0 (where the sequence has that many)
+        x = base.clone()
+        r_over = 3                                             # a query aligned with key 7 at 2^200
+        k7 = x[7, H * 64: H * 64 + 64]
+        x[r_over, :64] = k7 * (200.0 / (k7 @ k7))
+        bad_wgs = {r_over // rows}
+        if S > rows:                                           # a query whose every score is below -200: q = -c sum of key directions is
+            r_under = rows + 5                                 # not possible for random keys, so shift ALL keys of the head along u and
+            u = torch.zeros(64, device=dev); u[0] = 1.0        # point the query against u:  s_j = q.k_j = -(30 + k_j0) * 10 < -200
+            x[:S, H * 64: H * 64 + 64] += 30.0 * u
+            x[r_under, :64] = -10.0 * u
+            bad_wgs.add(r_under // rows)
+            k7 = x[7, H * 64: H * 64 + 64]
+            x[r_over, :64] = k7 * (200.0 / (k7 @ k7))
+        qkv = x.bfloat16()
+        if S > 2 * rows:
+            qkv[9, 2 * H * 64 + 3] = float("inf")              # V[9][3] of head 0, batch 0: every row of the head gets inf (or NaN)
+            bad_wgs = set(range(nwg_head))
+        o_opt = _attn_with_knob(qkv, B, S, H, 2, counters)
+        w = counters.sum(-1).cpu()
+        o_on = _attn_with_knob(qkv, B, S, H, 0)
+        wpw = rows // 64
+        # rejected workgroups: all of their waves are counted on the online-max loop by the follow-up launch (waves of the
+        # frame-wise kernel that own no rows are not counted)
+        n_bad_waves = sum(wpw if kind == 0 else min(wpw, (S - wg * rows + 63) // 64) for wg in bad_wgs)
+        assert w[kind, 1].item() == n_bad_waves, (w, bad_wgs)
+        for wg in range(nwg_head):
+            lo, hi = wg * rows, min(S, (wg + 1) * rows)
+            if wg in bad_wgs:                                  # batch 0, head 0
+                a, b_ = o_opt[lo:hi, :64], o_on[lo:hi, :64]
+                assert torch.equal(a.view(torch.int16), b_.view(torch.int16)), (wg, "rejected workgroup differs from the online-max launch")
+        if S <= 2 * rows:                                      # no inf planted: compare with the fp32 softmax
+            ref = attn_ref(qkv, B, S, H)
+            assert torch.isfinite(o_opt.float()).all()
+            assert rel(o_opt, ref)[0] < 8e-3
+            assert (o_opt.float()[r_over, :64] - ref[r_over, :64]).abs().max() < 2e-2
+        # heads / batches without a bad row: accepted, identical to the accepted launch of the same data without the bad rows' head
+        if H > 1:
+            assert torch.equal(o_opt[:, 64:].view(torch.int16), _attn_with_knob(qkv, B, S, H, 1)[:, 64:].view(torch.int16))
+    finally:
         ops.attention_path_counters(None)
 
 
@@ -550,18 +668,21 @@ def test_attention_hand_placed_loop_equals_the_compiler_kernel_bitwise(dev, B, S
     if spoil == 2:
         qkv[:, :64] *= 10.0                                        # all of head 0, every batch
     qkv = qkv.bfloat16()
-    outs = []
-    try:
-        for asm in (1, 0):
-            lib.set_knob("attn_asm", asm)
-            o = torch.full((B * S, H * 64), float("nan"), device=dev, dtype=torch.bfloat16)
-            ops.attention(qkv, o, B, S, H)
-            torch.cuda.synchronize()
-            outs.append(o)
-    finally:
-        lib.set_knob("attn_asm", 1)
-    assert torch.isfinite(outs[0].float()).all()
-    assert torch.equal(outs[0], outs[1]), int((outs[0] != outs[1]).sum())
+    for nomax in (1, ATTN_NOMAX_DEFAULT):       # a-priori form (spoiled waves -> C++ body inside the kernel) / optimistic form (follow-up launch)
+        outs = []
+        try:
+            lib.set_knob("attn_nomax", nomax)
+            for asm in (1, 0):
+                lib.set_knob("attn_asm", asm)
+                o = torch.full((B * S, H * 64), float("nan"), device=dev, dtype=torch.bfloat16)
+                ops.attention(qkv, o, B, S, H)
+                torch.cuda.synchronize()
+                outs.append(o)
+        finally:
+            lib.set_knob("attn_asm", 1)
+            lib.set_knob("attn_nomax", ATTN_NOMAX_DEFAULT)
+        assert torch.isfinite(outs[0].float()).all()
+        assert torch.equal(outs[0], outs[1]), (nomax, int((outs[0] != outs[1]).sum()))
     if spoil != 2 and S <= 8191:
         mx, mean = rel(outs[0], attn_ref(qkv, B, S, H))
         assert mx < 8e-3 and mean < 5e-3, (mx, mean)

@@ -1,7 +1,7 @@
 """Interleaved A/B timing of the global-attention launch (S = 64 300, 16 heads, bounded-score path) across several builds
 of the library loaded side by side in ONE process (cards of the pool differ by +-4 %, so only same-process rounds compare).
 
-    python tools/dev_attn_ab.py name=path.so [name=path.so ...] [--rounds 6] [--online-max]
+    python tools/dev_attn_ab.py name=path.so[:knob=v,...] [name=path.so ...] [--rounds 6] [--online-max] [--k2-ready] [--outlier-key]
 
 Timing-only ablation builds (-DA64_ABL=n) compute wrong results by construction: never the product library."""
 import ctypes
@@ -18,8 +18,14 @@ S, H = 64300, 16
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
 qkv = (torch.randn(S, 3 * H * 64, device=dev) * 0.5).bfloat16()
+if "--outlier-key" in sys.argv:       # one key of every head with 8 x the norm: |q| max|k| leaves the a-priori bound, the scores stay moderate
+    qkv.view(S, 3, H, 64)[1234, 1] *= 8.0
 out = torch.empty(S, H * 64, device=dev, dtype=torch.bfloat16)
 k2 = torch.zeros(H, device=dev)
+k2_ready = int("--k2-ready" in sys.argv)       # max |k|^2 per head handed over as the fused qkv epilogue does (no pre-pass in the timing)
+if k2_ready:
+    kk = qkv.float().view(S, 3, H, 64)[:, 1]
+    k2 = (kk * kk).sum(-1).amax(dim=0).contiguous()
 libs, knobs = {}, {}
 for a in args:
     name, path = a.split("=", 1)
@@ -42,7 +48,7 @@ def setk(name):
 def launch(lib):
     base, ts = qkv.data_ptr(), qkv.stride(0)
     rc = lib.pi3_attention(base, base + 2 * H * 64, base + 4 * H * 64, ts, S * ts, out.data_ptr(), out.stride(0),
-                           S * out.stride(0), 1, S, H, 64, 0, k2.data_ptr(), 0, torch.cuda.current_stream().cuda_stream)
+                           S * out.stride(0), 1, S, H, 64, 0, k2.data_ptr(), k2_ready, torch.cuda.current_stream().cuda_stream)
     assert rc == 0, rc
 
 
@@ -83,3 +89,16 @@ if "--check" in sys.argv:       # every variant against the fp32 softmax on a st
         torch.cuda.synchronize()
         err = (out[rows].float() - ref).abs()
         print(f"check {n:14s} max|d| {err.max().item():.3e} mean|d| {err.mean().item():.3e} (ref max {ref.abs().max().item():.3f})")
+
+if "--paths" in sys.argv:       # which softmax loop the waves' results came from (pi3_attention_path_counters), one launch per variant
+    cnt = torch.zeros(2, 2, 32, device=dev, dtype=torch.int32)
+    for n, lib in libs.items():
+        setk(n)
+        cnt.zero_()
+        lib.pi3_attention_path_counters.argtypes = [ctypes.c_void_p]
+        lib.pi3_attention_path_counters(cnt.data_ptr())
+        launch(lib)
+        torch.cuda.synchronize()
+        lib.pi3_attention_path_counters(None)
+        w = cnt.sum(-1)[0].tolist()
+        print(f"paths {n:14s} bounded-score waves {w[0]}  online-max waves {w[1]} (= {w[1] // 8} workgroups of {(S + 511) // 512 * H})")

@@ -87,7 +87,9 @@ int pi3_attention(const void* q, const void* k, const void* v, long tok_stride, 
  * memory of 128 uint32, zeroed by the caller, laid out [kind][path][32 slots] (sum the slots): kind 0 = eight-wave
  * workgroups (global attention), 1 = four-/two-wave workgroups (frame-wise attention); path 0 = the wave's result comes
  * from the bounded-score loop, 1 = from the online-max loop (under knob attn_nomax = 2 these are the waves of workgroups
- * that rejected the optimistic pass and ran again).  One no-return atomic per wave while registered; NULL (the default) switches it off.
+ * that rejected the optimistic pass and ran again).  bf16 launches only: the IEEE-half form (MoGe) has one loop and is
+ * not counted (until round 5's last build its waves appeared under kind 1 / path 1: the "0.4 % online-max" of the
+ * frame-wise line in earlier bench records was MoGe's encoder, not pi3's).  One no-return atomic per wave while registered; NULL (the default) switches it off.
  * Process-wide; change it only while no attention launch is in flight.  bench.py reports the fractions with it. */
 int pi3_attention_path_counters(unsigned int* counters);
 

@@ -904,7 +904,7 @@ int pi3_attention64_launch(const void* q, const void* k, const void* v, long tok
   p.dbg = dbgbuf;
 #endif
   if (f16) {      // IEEE-half operands: LDS-DMA staging, online-max loop, eight- or four-wave workgroups
-    p.stats = g_attn_stats;
+    p.stats = nullptr;     // not a choice of path (half always takes the online-max loop): MoGe's launches stay out of pi3's counters
     if (nw_req == 4)
       hipLaunchKernelGGL((attn_fwd64_kernel<4, true, false, true>), dim3((unsigned)nwg), dim3(256), 0, stream, p);
     else

@@ -43,19 +43,7 @@
 #include <stdlib.h>
 #include <stdio.h>
 
-struct Attn64Params {
-  const bf16_t* q; const bf16_t* k; const bf16_t* v;
-  long tok_stride, batch_stride;
-  bf16_t* o; long o_tok_stride, o_batch_stride;
-  int S, H, B, nqb;
-  const float* k2max;   // [B][H] max over keys of |k|^2, or null (always online max)
-  int prio;             // 1: waves NW/2 .. NW-1 (the later-dispatched wave of every SIMD) run at s_setprio 1 (A/B knob)
-  int tailopt;          // 1: short-sequence waves skip query blocks / key halves that do not exist (A/B knob, default 1)
-  unsigned long long* dbg;   // -DPI3_ATTN_STAMPS builds only: s_memtime stamps of workgroup 0
-  unsigned* stats;      // optional caller-owned path counters (pi3_attention_path_counters), else null
-  int optim;            // 1: optimistic bounded-score loop + acceptance test (a64_reject); 0: a-priori test on k2max
-  int redo;             // 1: the follow-up launch of the optimistic form: only workgroups that left the mark run, on the online-max loop
-};
+#include "attn64_params.h"
 #ifndef A64_ABL   // development builds only (-DA64_ABL=n, a separate .so): timing ablations with WRONG results.
 #define A64_ABL 0   // 1 no exp, 3 no P.V MFMAs, 4 no Q.K^T MFMAs, 5 no barrier / DMA wait, 6 no row-sum MFMAs, 7 one LDS fragment reused
 #endif

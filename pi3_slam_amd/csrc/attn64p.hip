@@ -31,17 +31,8 @@
 #include "common.h"
 #include <stdlib.h>
 
-struct Attn64Params {
-  const bf16_t* q; const bf16_t* k; const bf16_t* v;
-  long tok_stride, batch_stride;
-  bf16_t* o; long o_tok_stride, o_batch_stride;
-  int S, H, B, nqb;
-  const float* k2max;
-  int prio, tailopt;    // (attn64.hip's knobs; unused by this kernel - the struct must match attn64.hip's field for field)
-  unsigned long long* dbg;
-  unsigned* stats;
-  int optim, redo;      // ignored here: this kernel keeps the a-priori test on k2max (null under attn_nomax = 2: online-max loop)
-};
+#include "attn64_params.h"   // (prio / tailopt / stats / optim / redo are attn64.hip's: this kernel keeps the a-priori test on k2max,
+                             //  which is null under attn_nomax = 2 - then the online-max loop)
 #ifndef P64_ABL   // development builds only (-DP64_ABL=1: no exp; timing ablation with WRONG results, never in the product .so)
 #define P64_ABL 0
 #endif

@@ -31,8 +31,8 @@
 #include "common.h"
 #include <stdlib.h>
 
-#include "attn64_params.h"   // (prio / tailopt / stats / optim / redo are attn64.hip's: this kernel keeps the a-priori test on k2max,
-                             //  which is null under attn_nomax = 2 - then the online-max loop)
+#include "attn64_params.h"   // (prio / tailopt / stats / optim / redo are attn64.hip's: this kernel decides by the a-priori test on
+                             //  k2max alone - waves outside the bound take the online-max loop, no optimistic pass)
 #ifndef P64_ABL   // development builds only (-DP64_ABL=1: no exp; timing ablation with WRONG results, never in the product .so)
 #define P64_ABL 0
 #endif

@@ -33,8 +33,22 @@ CASES = {
     # sequences and eight-wave workgroups on the global one); the tiny cases above go through the small-shape kernels.
     # Dense maps are stored every SUB-th pixel, intermediates every ROWS-th token (the file stays < 4 MB).
     "pi3_mid": (1, 8, 308, 406),
+    # the same chunk shape with the decoder's q / k LayerNorm gains x HOT_GAIN (scores x 12): |q| max|k| leaves the
+    # a-priori bound of the HIP attention's loop without a running maximum (attn64.hip) in every decoder block, frame-wise
+    # and global, the way real weights might - the reference's answer to what that loop must still reproduce
+    "pi3_mid_hot": (1, 8, 308, 406),
 }
-SUBSAMPLED = {"pi3_mid": (7, 64)}     # name: (pixel stride SUB, token-row stride ROWS)
+SUBSAMPLED = {"pi3_mid": (7, 64), "pi3_mid_hot": (7, 64)}     # name: (pixel stride SUB, token-row stride ROWS)
+HOT_GAIN = 3.5
+
+
+def hot_overrides(sd: dict, name: str) -> dict:
+    """Weight edits of a case (tensor name -> new tensor); empty for the plain recipe cases.  The GPU test applies the
+    same edit to the engine's weights."""
+    if name != "pi3_mid_hot":
+        return {}
+    return {k: v * HOT_GAIN for k, v in sd.items()
+            if k.startswith("decoder.") and k.endswith(("q_norm.weight", "k_norm.weight"))}
 
 
 def golden_images(name: str, B: int, N: int, H: int, W: int) -> torch.Tensor:
@@ -67,6 +81,12 @@ def main() -> None:
             continue
         sub, rows = SUBSAMPLED.get(name, (1, 1))
         imgs = golden_images(name, B, N, H, W)
+        plain_sd = sd
+        edits = hot_overrides(plain_sd, name)
+        if edits:
+            sd = dict(plain_sd, **edits)
+            model.load_state_dict(sd, strict=False)
+            print(f"{name}: {len(edits)} tensors edited")
         cap = {}
         hooks = [
             model.encoder.blocks[0].register_forward_pre_hook(lambda m, a: cap.__setitem__("tokens", a[0].detach().clone())),
@@ -123,6 +143,9 @@ def main() -> None:
         print("   reference bf16 rotation error (deg):", save["bf16err_rot_deg"])
         np.savez_compressed(os.path.join(out_dir, name + ".npz"), **save)
         print("   wrote", os.path.join(out_dir, name + ".npz"))
+        if edits:
+            sd = plain_sd
+            model.load_state_dict(sd, strict=False)
 
 
 if __name__ == "__main__":

@@ -96,6 +96,69 @@ def test_full_model_mid_size_through_the_shipped_kernels(full_engine):
     assert (out["local_points"][..., 2] > 0).all()
 
 
+def test_full_model_with_attention_outside_the_a_priori_score_bound(full_engine):
+    """Real weights may not keep |q| max|k| <= 90 (the a-priori bound of the attention loop without a running maximum).
+    Fixture pi3_mid_hot (oracle/gen_golden.py): the REAL `Pi3` class on the pi3_mid chunk shape with the decoder's q / k
+    LayerNorm gains multiplied by 3.5 (scores x 12), which puts the decoder's attention - frame-wise and global, S = 5 144
+    on the hand-placed eight-wave kernel - outside that bound while the scores themselves stay inside the exponent range.
+    Knob attn_nomax = 1 (rounds 3-4) sends those waves to the online-max loop; the default (2) keeps the fast loop after
+    testing its row sums (attn64.hip, a64_reject); 0 is the online-max loop everywhere.  All three must reproduce the
+    reference within 2x its own bf16-autocast deviation on this model (6x larger than on the plain recipe weights: the
+    sharper softmax amplifies rounding), and the counters say which loop ran."""
+    from oracle.gen_golden import CASES, golden_images, hot_overrides
+    from pi3_slam_amd import lib, ops
+    g = np.load(os.path.join(GOLDEN, "pi3_mid_hot.npz"))
+    B, N, H, W = CASES["pi3_mid_hot"]
+    sub, rows = (int(v) for v in g["strides"])
+    imgs = golden_images("pi3_mid_hot", B, N, H, W)
+    edits = hot_overrides({k: v for k, v in full_engine.w.items() if "_norm.weight" in k}, "pi3_mid_hot")
+    assert len(edits) == 2 * full_engine.cfg.dec_depth
+    saved = {k: full_engine.w[k].clone() for k in edits}
+    counters = torch.zeros(2, 2, 32, device=next(iter(saved.values())).device, dtype=torch.int32)
+    outs, paths = {}, {}
+    try:
+        for k, v in edits.items():
+            full_engine.w[k].copy_(v)
+        ops.attention_path_counters(counters)
+        for knob in (0, 1, 2):
+            lib.set_knob("attn_nomax", knob)
+            counters.zero_()
+            out = full_engine.forward(imgs, return_intermediates=(knob == 2))
+            torch.cuda.synchronize()
+            outs[knob] = {k: out[k].float().cpu() for k in ("points", "local_points", "conf", "camera_poses")}
+            if knob == 2:
+                inter = {k: v.float().cpu() for k, v in out["_intermediates"].items()}
+            paths[knob] = counters.sum(-1).cpu()
+    finally:
+        lib.set_knob("attn_nomax", 2)
+        torch.cuda.synchronize()
+        ops.attention_path_counters(None)
+        for k in edits:
+            full_engine.w[k].copy_(saved[k])
+    assert paths[0][:, 0].sum().item() == 0                                   # knob 0: nothing on the bounded-score loop
+    assert paths[1][0, 1].item() > 0 and paths[1][1, 1].item() > 0, paths[1]    # knob 1: decoder waves (global and frame-wise) fall back
+    assert paths[2][:, 1].sum().item() == 0, paths[2]                         # knob 2: every wave keeps the fast loop ...
+    assert paths[2].sum().item() == paths[0].sum().item()                     # ... and every wave is counted once
+    for knob in (2, 1, 0):
+        for k in ("points", "local_points", "conf", "camera_poses"):
+            got = outs[knob][k]
+            assert torch.isfinite(got).all()
+            if k != "camera_poses":
+                got = got[:, :, ::sub, ::sub]
+            d = (got - torch.from_numpy(g[k])).abs()
+            anchor_mean, anchor_max = g["bf16err_" + k]
+            print(f"pi3_mid_hot knob {knob} {k}: mean|d| {d.mean().item() / anchor_mean:.2f} x / max|d| {d.max().item() / anchor_max:.2f} x "
+                  "the reference's bf16-autocast deviation")
+            assert d.mean().item() <= 2.0 * anchor_mean, (knob, k, d.mean().item(), anchor_mean)
+            assert d.max().item() <= 2.0 * anchor_max, (knob, k, d.max().item(), anchor_max)
+        assert _rot_err_deg(outs[knob]["camera_poses"], torch.from_numpy(g["camera_poses"])) <= 2.0 * g["bf16err_rot_deg"][0]
+    for k in g.files:                       # the first decoder blocks (one frame-wise, one global attention outside the bound)
+        if k in ("i_enc_out", "i_dec0", "i_dec1"):
+            ref = torch.from_numpy(g[k])
+            r = ((inter[k[2:]][::rows] - ref).abs().mean() / ref.abs().mean()).item()
+            assert r < 1.5e-2, (k, r)
+
+
 # Measured on MI355X (round 4, gpurun_out/r4a/new_tests.log): 0 of the 13 160 keypoint masks of chunk_mid differ from the
 # reference's fp32 run.  The gate allows 2x the measured figure with a floor of 0.1 % (13 keypoints): a mask flips when a
 # bf16-perturbed confidence or depth ratio crosses its threshold, which another card or a kernel change may produce

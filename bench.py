@@ -585,7 +585,9 @@ def softmax_paths(counters: torch.Tensor, online_max, attn_flops: float) -> dict
     form of rounds 3-4 (knob 1: |q| max|k| <= 90 for every row of a wave, a Cauchy-Schwarz bound that one large key breaks)
     gives the same counts on recipe weights."""
     w = counters.sum(-1).cpu().tolist()
-    out = {}
+    out = {"loop_selection": "knob attn_nomax = 2: bounded-score loop kept by the a-priori bound |q| max|k| <= 90 where it holds, "
+                             "elsewhere by the test 2^-60 <= row sum <= 2^120 and finite outputs, rejected workgroups re-run on "
+                             "the online-max loop in a follow-up launch (attn64.hip a64_reject); online_max_waves counts those"}
     for name, (fast, slow) in (("global_attention", w[0]), ("frame_attention", w[1])):
         out[name] = {"bounded_score_waves": int(fast), "online_max_waves": int(slow),
                      "fraction_bounded": (fast / (fast + slow)) if fast + slow else None}

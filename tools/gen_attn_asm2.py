@@ -23,11 +23,12 @@ NW = 8 if N == 2 else 4                     # waves per workgroup
 PIECES = 16 // NW                           # 1 KiB LDS-DMA pieces per wave and tile (K and V each: 8 KiB)
 
 # ---- fixed arch VGPRs -------------------------------------------------------------------------------------------------
-nfix = 32 * N + 8 * N + 8 + 8 + 4 + 2 + 2 * (PIECES // 2) + 2 + (2 * N if 'rowsum_vadd' in ABL else 0)
+VSUM = "rowsum_vadd" in ABL or "rowsum_pkadd" in ABL      # row sums on the VALU: two f32 accumulators per block
+nfix = 32 * N + 8 * N + 8 + 8 + 4 + 2 + 2 * (PIECES // 2) + 2 + (2 * N if VSUM else 0)
 nacc = 32 * N + 16 * N + 4 * N
 ARCH = 512 // (2 if N == 2 else 1) - nacc            # arch VGPRs available beside the accumulator registers
 ARCH = min(ARCH, 256)
-V0 = ARCH - nfix - 2
+V0 = (ARCH - nfix - 2) & ~1          # even: v_pk_add_f32 wants aligned register pairs
 cur = [V0]
 
 
@@ -46,7 +47,7 @@ VADDR = [alloc(1), alloc(1)]
 KSRC = [alloc(1) for _ in range(PIECES // 2)]
 VSRC = [alloc(1) for _ in range(PIECES // 2)]
 ONES = alloc(2)
-LSUM = [alloc(2) for _ in range(N)] if "rowsum_vadd" in ABL else None
+LSUM = [alloc(2) for _ in range(N)] if VSUM else None
 LASTV = cur[0] - 1
 assert LASTV < ARCH and V0 >= 24, (V0, LASTV, ARCH)
 # ---- fixed accumulator registers ------------------------------------------------------------------------------------------
@@ -95,7 +96,17 @@ def slot(kt, s2, *, pv=True, qk=True, ex=True, rowsum=True, kaddr_update=False, 
             r = S[blk] + 8 * s2 + i
             g = min(j // 2 + 1, G - 1)
             fill[g].insert(0, f"v_add_f32_e32 v{LSUM[blk] + (i & 1)}, v{LSUM[blk] + (i & 1)}, v{r}")
-    if rowsum and pv and "norowsum" not in ABL and "rowsum_vadd" not in ABL:
+    if ex and "rowsum_pkadd" in ABL:           # the same as ONE packed add per pair of exps (v_pk_add_f32 on aligned pairs)
+        for j in range(4 * N):
+            blk, i = exps[2 * j]
+            r = S[blk] + 8 * s2 + i
+            assert r % 2 == 0 and LSUM[blk] % 2 == 0
+            ins = f"v_pk_add_f32 {vr(LSUM[blk], 2)}, {vr(LSUM[blk], 2)}, {vr(r, 2)}"
+            if j + 1 < G:
+                fill[j + 1].insert(0, ins)
+            else:
+                fill[G - 1].append(ins)          # behind the last gap's converts: two instructions after its exps
+    if rowsum and pv and "norowsum" not in ABL and not VSUM:
         n = 0
         for blk in range(N):
             for half in range(2):

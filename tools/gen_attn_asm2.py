@@ -23,7 +23,7 @@ NW = 8 if N == 2 else 4                     # waves per workgroup
 PIECES = 16 // NW                           # 1 KiB LDS-DMA pieces per wave and tile (K and V each: 8 KiB)
 
 # ---- fixed arch VGPRs -------------------------------------------------------------------------------------------------
-VSUM = "rowsum_vadd" in ABL or "rowsum_pkadd" in ABL      # row sums on the VALU: two f32 accumulators per block
+VSUM = "rowsum_vadd" in ABL or "rowsum_pkadd" in ABL or "rowsum_dot2" in ABL     # row sums on the VALU: two f32 accumulators per block
 nfix = 32 * N + 8 * N + 8 + 8 + 4 + 2 + 2 * (PIECES // 2) + 2 + (2 * N if VSUM else 0)
 nacc = 32 * N + 16 * N + 4 * N
 ARCH = 512 // (2 if N == 2 else 1) - nacc            # arch VGPRs available beside the accumulator registers
@@ -106,6 +106,12 @@ def slot(kt, s2, *, pv=True, qk=True, ex=True, rowsum=True, kaddr_update=False, 
                 fill[j + 1].insert(0, ins)
             else:
                 fill[G - 1].append(ins)          # behind the last gap's converts: two instructions after its exps
+    if rowsum and pv and "rowsum_dot2" in ABL:     # v_dot2c_f32_bf16 with packed ones on the packed P of quarter q-1: one per MFMA gap
+        n = 0
+        for blk in range(N):
+            for r in range(4):
+                fill[n % G].append(f"v_dot2c_f32_bf16_e32 v{LSUM[blk] + (r & 1)}, v{prev[blk] + r}, v{ONES}")
+                n += 1
     if rowsum and pv and "norowsum" not in ABL and not VSUM:
         n = 0
         for blk in range(N):

@@ -535,7 +535,7 @@ def main(args) -> None:
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_DENSE_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_BF16_DENSE_TFLOPS, "traffic": ATTN_TRAFFIC_BYTES,
                          "traffic_source": ATTN_TRAFFIC_SOURCE,
-                         "kernel": "attn_fwd64a_kernel (global attention, S=64300, 16 heads, d=64; hand-placed main loop, round 5)",
+                         "kernel": "attn_fwd64b_kernel (global attention, S=64300, 16 heads, d=64; hand-placed main loop, one wave per SIMD x 128 rows, round 5)",
                          "launch_ms": attn_ms, "launches_timed": len(attn_events),
                          "end_to_end_tflops": fl["total"] * args.steps / dt / 1e12,
                          "softmax_paths": softmax_paths(path_counters, online_max, attn_flops)},

@@ -769,6 +769,201 @@ __global__ __launch_bounds__(512, 2) void attn_fwd64a_kernel(Attn64Params p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// attn_fwd64b_kernel (round 5, late): the same hand-placed loop with ONE wave per SIMD - four waves per workgroup, 128 query
+// rows (four 32-row blocks) per wave, the whole 512-register file per wave (launch bound 256 x 1).  Every K / V fragment
+// read from LDS then feeds four MFMAs instead of two: half the fragment traffic per FLOP, which is what still pays in a
+// power-limited loop (-2.3 ... -2.7 % in tools/micro/attn_loop_bench).  Generated by `tools/gen_attn_asm2.py 4 ... product`
+// (attn64b_loop.inc): O and the row sums are "+a" operands, Q is loaded inside the block into a192..a255, the loop's
+// state sits in v66..v253.  Same workgroup -> rows map (512 rows), same rings, same arithmetic in the same order per row
+// as attn_fwd64a_kernel, so the results are bit-identical and a rejected workgroup's mark is found by the same follow-up
+// launch.  Launched only for the optimistic form (knob attn_nomax = 2) and nt >= 8: there is no second body in here.
+// ---------------------------------------------------------------------------------------------------------------------
+#include <attn64b_loop.inc>
+__global__ __launch_bounds__(256, 1) void attn_fwd64b_kernel(Attn64Params p) {
+  __shared__ __attribute__((aligned(1024))) char lds[40960];
+  constexpr bool F16 = false;
+  const int tid = threadIdx.x, wave = tid >> 6;
+  const int nwg = p.nqb * p.H * p.B;
+  const int id = xcd_remap(blockIdx.x, nwg);
+  const int qb = id % p.nqb;
+  const int head = (id / p.nqb) % p.H;
+  const int b = id / (p.nqb * p.H);
+  const int S = p.S;
+  const int nt = (S + A64_KT - 1) / A64_KT;
+  const int q0 = qb * 512 + wave * 128;
+  const bf16_t* qbase = p.q + (long)b * p.batch_stride + head * 64;
+  const bf16_t* kbase = p.k + (long)b * p.batch_stride + head * 64;
+  const bf16_t* vbase = p.v + (long)b * p.batch_stride + head * 64;
+  const long tile_bytes = (long)A64_KT * p.tok_stride * 2;
+  const bool tail = (S & (A64_KT - 1)) != 0;
+
+  int kswz, krow_off, vrow_l, vch_l, vin_l, vswz, r_, h_, drow0, dpos;
+#define A64B_LANE_CONSTS(LANE)                                                                                     \
+  {                                                                                                               \
+    r_ = (LANE) & 31; h_ = (LANE) >> 5;                                                                           \
+    drow0 = wave * 16 + ((LANE) >> 3); dpos = (LANE) & 7;          /* pieces 2 wave, 2 wave + 1: rows drow0, drow0 + 8 */ \
+    kswz = (r_ >> 1) & 7;                                                                                         \
+    krow_off = r_ * 128;                                                                                          \
+    const int gi = (LANE) & 15, gg = ((LANE) >> 4) & 1;                                                           \
+    vrow_l = 4 * h_ + (gi >> 2);                                                                                  \
+    const int vcol_l = 16 * gg + 4 * (gi & 3);                                                                    \
+    vch_l = vcol_l >> 3;                                                                                          \
+    vin_l = (vcol_l & 7) * 2;                                                                                     \
+    vswz = ((vrow_l >> 1) & 1) << 2;                                                                              \
+  }
+  A64B_LANE_CONSTS(tid & 63)
+
+  // a-priori test (the shortcut of the optimistic form: a workgroup wholly inside the bound is not tested afterwards)
+  bool fast = false;
+  if (p.k2max) {
+    const float k2 = p.k2max[b * p.H + head];
+    float qn = 0.f;
+#pragma unroll
+    for (int blk = 0; blk < 4; ++blk) {
+      const bf16_t* pq = qbase + (long)min(q0 + 32 * blk + r_, S - 1) * p.tok_stride;
+      float a = 0.f;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const bf16x8 f = *(const bf16x8*)(pq + 16 * s + 8 * h_);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a += (float)f[e] * (float)f[e];
+      }
+      a += __shfl_xor(a, 32, 64);
+      qn = fmaxf(qn, a);
+    }
+    fast = __all(qn * k2 <= A64_BOUND2);
+  }
+  const bool sure = __syncthreads_and(fast) != 0;
+
+  f32x16 o[4][2];
+  f32x4 lacc[4];
+  float msc[4], lsc[4];
+#pragma unroll
+  for (int blk = 0; blk < 4; ++blk) {
+    o[blk][0] = o[blk][1] = (f32x16)(0.f);
+    lacc[blk] = (f32x4)(0.f);
+    msc[blk] = lsc[blk] = 0.f;
+  }
+  auto dma_k = [&](int T) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int drow = drow0 + 8 * i;
+      int grow = T * A64_KT + drow;
+      grow = grow < S ? grow : S - 1;                  // only the last, partial tile clamps
+      a64_glds16((const char*)(kbase + (long)grow * p.tok_stride) + ((dpos ^ ((drow >> 1) & 7)) << 4),
+                 lds + A64A_KSLOT(T) + (wave * 2 + i) * 1024);
+    }
+  };
+  auto dma_v = [&](int T) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int drow = drow0 + 8 * i;
+      int grow = T * A64_KT + drow;
+      grow = grow < S ? grow : S - 1;
+      a64_glds16((const char*)(vbase + (long)grow * p.tok_stride) + ((dpos ^ (((drow >> 1) & 1) << 2)) << 4),
+                 lds + A64A_VSLOT(T) + (wave * 2 + i) * 1024);
+    }
+  };
+  dma_k(0);
+  dma_v(0);
+  dma_k(1);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  // one 64-key tile in C++ (four of ~1 000): the four blocks one after the other, Q fragments of a block loaded for it
+#define A64B_TILE(T, FIRST, LAST)                                                                                  \
+  {                                                                                                               \
+    if ((T) + 1 < nt) dma_v((T) + 1);                                                                             \
+    if ((T) + 2 < nt) dma_k((T) + 2);                                                                             \
+    const char* kl = lds + A64A_KSLOT(T) + krow_off;                                                              \
+    const char* vl = lds + A64A_VSLOT(T);                                                                         \
+    _Pragma("unroll") for (int blk = 0; blk < 4; ++blk) {                                                         \
+      bf16x8 qf[4];                                                                                               \
+      const bf16_t* pq = qbase + (long)min(q0 + 32 * blk + r_, S - 1) * p.tok_stride;                             \
+      _Pragma("unroll") for (int s = 0; s < 4; ++s) qf[s] = *(const bf16x8*)(pq + 16 * s + 8 * h_);               \
+      A64A_BLOCK(T, FIRST, LAST, qf, o[blk], lsc[blk], lacc[blk], msc[blk])                                       \
+      __builtin_amdgcn_sched_barrier(0);                                                                          \
+    }                                                                                                             \
+    if (!(LAST)) {                                                                                                \
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                            \
+      __syncthreads();                                                                                            \
+    }                                                                                                             \
+  }
+#define h h_      /* A64_MASK reads `h` */
+  A64B_TILE(0, true, false)
+  {
+    const unsigned lds0 = A64A_LDSADDR(lds);
+    const unsigned ka0 = lds0 + 8192 + krow_off + ((h_ ^ kswz) << 4);          // d-steps 1..3: ^ 32 s (inside the block)
+    const unsigned va0 = lds0 + 16384 + vrow_l * 128 + ((vch_l ^ vswz) << 4) + vin_l;      // dt 1: ^ 64
+    unsigned ksrc[2], vsrc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int drow = drow0 + 8 * i;
+      ksrc[i] = (unsigned)(drow * p.tok_stride * 2) + ((dpos ^ ((drow >> 1) & 7)) << 4);
+      vsrc[i] = (unsigned)(drow * p.tok_stride * 2) + ((dpos ^ (((drow >> 1) & 1) << 2)) << 4);
+    }
+    const bf16_t* qp[4];
+#pragma unroll
+    for (int blk = 0; blk < 4; ++blk) qp[blk] = qbase + (long)min(q0 + 32 * blk + r_, S - 1) * p.tok_stride + 8 * h_;
+    const unsigned cnt = (unsigned)(nt - 4);
+    const unsigned long long kg = (unsigned long long)(__UINTPTR_TYPE__)kbase + 3ull * (unsigned long long)tile_bytes;
+    const unsigned long long vg = (unsigned long long)(__UINTPTR_TYPE__)vbase + 2ull * (unsigned long long)tile_bytes;
+    const unsigned kg_lo = __builtin_amdgcn_readfirstlane((unsigned)kg), kg_hi = __builtin_amdgcn_readfirstlane((unsigned)(kg >> 32));
+    const unsigned vg_lo = __builtin_amdgcn_readfirstlane((unsigned)vg), vg_hi = __builtin_amdgcn_readfirstlane((unsigned)(vg >> 32));
+    const unsigned long long kgs = ((unsigned long long)kg_hi << 32) | kg_lo, vgs = ((unsigned long long)vg_hi << 32) | vg_lo;
+    const unsigned tb = __builtin_amdgcn_readfirstlane((unsigned)tile_bytes);
+    const unsigned kd0 = __builtin_amdgcn_readfirstlane(lds0 + wave * 2048);
+    asm volatile(A64B4_LOOP_ASM
+                 : [o00] "+a"(o[0][0]), [o01] "+a"(o[0][1]), [o10] "+a"(o[1][0]), [o11] "+a"(o[1][1]), [o20] "+a"(o[2][0]),
+                   [o21] "+a"(o[2][1]), [o30] "+a"(o[3][0]), [o31] "+a"(o[3][1]), [l0] "+a"(lacc[0]), [l1] "+a"(lacc[1]),
+                   [l2] "+a"(lacc[2]), [l3] "+a"(lacc[3])
+                 : [ka0] "v"(ka0), [va0] "v"(va0), [ksrc0] "v"(ksrc[0]), [ksrc1] "v"(ksrc[1]), [vsrc0] "v"(vsrc[0]),
+                   [vsrc1] "v"(vsrc[1]), [qp0] "v"(qp[0]), [qp1] "v"(qp[1]), [qp2] "v"(qp[2]), [qp3] "v"(qp[3]), [cnt] "s"(cnt),
+                   [kg] "s"(kgs), [vg] "s"(vgs), [tb] "s"(tb), [kd0] "s"(kd0)
+                 : "memory", "scc", "vcc", "m0", A64B4_CLOBBER_V, A64B4_CLOBBER_A, A64B4_CLOBBER_S);
+  }
+  {
+    int lane2 = (int)(threadIdx.x & 63);
+    asm volatile("" : "+v"(lane2));                    // opaque: nothing derived from the lane id before the loop stays live
+    A64B_LANE_CONSTS(lane2)
+  }
+  A64B_TILE(nt - 3, false, false)
+  A64B_TILE(nt - 2, false, false)
+  A64B_TILE(nt - 1, false, true)
+#undef h
+
+  if (!sure) {         // acceptance test of the optimistic loop (a64_reject); workgroup-uniform
+    bool bad = false;
+#pragma unroll
+    for (int blk = 0; blk < 4; ++blk) bad = bad || a64_reject(lsc[blk] + lacc[blk][0], o[blk]);
+    if (__syncthreads_or(bad)) {
+      if (tid == 0) *a64_mark_ptr(p, b, qb, head, 512) = A64_MARK;
+      return;
+    }
+  }
+  if (p.stats && (threadIdx.x & 63) == 0) atomicAdd(p.stats + 0 + (blockIdx.x & 31), 2u);      // two 64-row wave units per wave
+#pragma unroll
+  for (int blk = 0; blk < 4; ++blk) {
+    const float lsum = lsc[blk] + lacc[blk][0];
+    const float inv = 1.0f / (lsum + __shfl_xor(lsum, 32, 64));
+    const int row = q0 + 32 * blk + r_;
+    if (row < S) {
+      bf16_t* optr = p.o + (long)b * p.o_batch_stride + (long)row * p.o_tok_stride + head * 64;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f32x16& ov = o[blk][dt];
+          u32x2 w;
+          w[0] = pack_bf16x2(ov[4 * g + 0] * inv, ov[4 * g + 1] * inv);
+          w[1] = pack_bf16x2(ov[4 * g + 2] * inv, ov[4 * g + 3] * inv);
+          *(u32x2*)(optr + 32 * dt + 8 * g + 4 * h_) = w;
+        }
+    }
+  }
+}
+
 // max over keys of |k|^2 per (batch, head) for the bounded-score test; out must be zeroed (non-negative floats order
 // like their bit patterns, so the reduction is an integer atomicMax)
 #define A64_KNORM_BLOCKS 24   // blocks per (batch, head): 24 * 16 heads = 384 blocks, one atomic each
@@ -921,11 +1116,16 @@ int pi3_attention64_launch(const void* q, const void* k, const void* v, long tok
     const char* e = getenv("PI3_ATTN_MSUM");
     msum = e ? atoi(e) : 1;
   }
-  // knob attn_asm (PI3_ATTN_ASM): 1 (default) = the kernel with the hand-placed main loop (attn_fwd64a_kernel; workgroups
-  // it does not cover run the compiler-scheduled body inside it), 0 = the compiler-scheduled kernel.  Bit-identical results.
-  const bool use_asm = PI3_KNOB("attn_asm", 1) != 0;
+  // knob attn_asm (PI3_ATTN_ASM): the eight-wave-sized (512-row) workgroups' kernel.  2 (default) = attn_fwd64b_kernel, the
+  // hand-placed loop with one wave per SIMD x 128 rows (optimistic form and >= 8 key tiles; otherwise form 1); 1 =
+  // attn_fwd64a_kernel, the same loop with two waves per SIMD x 64 rows (workgroups it does not cover run the
+  // compiler-scheduled body inside it); 0 = the compiler-scheduled kernel.  Bit-identical results.
+  const int asm_form = (int)PI3_KNOB("attn_asm", 2);
+  const bool use_asm = asm_form != 0;
   auto launch = [&](bool allow_asm) {
-    if (nw == 8 && glds && msum && (p.k2max || p.optim) && allow_asm)
+    if (nw == 8 && glds && msum && p.optim && allow_asm && asm_form == 2 && S >= 8 * A64_KT - (A64_KT - 1))
+      hipLaunchKernelGGL(attn_fwd64b_kernel, dim3((unsigned)nwg), dim3(256), 0, stream, p);
+    else if (nw == 8 && glds && msum && (p.k2max || p.optim) && allow_asm)
       hipLaunchKernelGGL(attn_fwd64a_kernel, dim3((unsigned)nwg), dim3(512), 0, stream, p);
     else if (nw == 8 && glds && msum)
       hipLaunchKernelGGL((attn_fwd64_kernel<8, true, true>), dim3((unsigned)nwg), dim3(512), 0, stream, p);

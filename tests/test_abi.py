@@ -78,3 +78,12 @@ def test_generated_attention_loop_is_in_sync_with_its_generator(tmp_path):
     assert out.read_text() == committed
     # the loop's fixed registers stay clear of the compiler's share (operands live below v150) and inside the file
     assert '#define A64A_V0 150' in committed and '"v255"' in committed and '"v256"' not in committed
+    # attn64b_loop.inc (attn_fwd64b_kernel: one wave per SIMD x 128 rows) = `gen_attn_asm2.py 4 <out> product`
+    out_b = tmp_path / "loop_b.inc"
+    subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_attn_asm2.py"), "4", str(out_b), "product"], check=True,
+                   env=env, capture_output=True)
+    committed_b = open(os.path.join(ROOT, "pi3_slam_amd", "csrc", "attn64b_loop.inc")).read()
+    assert out_b.read_text() == committed_b
+    # its fixed registers: v66..v253 and a192..a255 (Q); the twelve "+a" operands (O, row sums: 144 registers) fit below a192
+    assert '"v66"' in committed_b and '"v65"' not in committed_b and '"v254"' not in committed_b
+    assert '"a192"' in committed_b and '"a191"' not in committed_b and '"a255"' in committed_b

@@ -72,18 +72,20 @@ def test_global_attention_full_size_all_rows(dev, S):
             worst = (max(worst[0], mx), max(worst[1], mean))
             assert mx < 8e-3 and mean < 5e-3, (S, h, mx, mean)   # the gate of test_kernels_gpu.py:96-97
         del ref
-    # the hand-placed main loop (attn_fwd64a_kernel, the default) against the compiler-scheduled kernel (knob attn_asm = 0):
-    # the same arithmetic in the same order, so the 64 300 x 1 024 outputs must be equal BIT FOR BIT - every workgroup of
-    # heads 1-8 and 10-15 runs the generated loop, heads 0 and 9 contain workgroups that fall back to the C++ body
+    # the hand-placed main loops (attn_fwd64b_kernel: one wave per SIMD x 128 rows, the default; attn_fwd64a_kernel: two waves
+    # x 64 rows, knob attn_asm = 1) against the compiler-scheduled kernel (knob 0): the same arithmetic in the same order, so
+    # the 64 300 x 1 024 outputs must be equal BIT FOR BIT - every workgroup of heads 1-8 and 10-15 keeps the generated
+    # loop's result, heads 0 and 9 contain workgroups that reject it and run again on the online-max loop
     from pi3_slam_amd import lib
-    out_c = torch.empty_like(out)
-    lib.set_knob("attn_asm", 0)
     try:
-        ops.attention(qkv, out_c, B, S, H)
-        torch.cuda.synchronize()
+        for form in (1, 0):
+            out_c = torch.empty_like(out)
+            lib.set_knob("attn_asm", form)
+            ops.attention(qkv, out_c, B, S, H)
+            torch.cuda.synchronize()
+            assert torch.equal(out, out_c), (form, int((out != out_c).sum()))
     finally:
-        lib.set_knob("attn_asm", 1)
-    assert torch.equal(out, out_c), int((out != out_c).sum())
+        lib.set_knob("attn_asm", 2)
     # with max |k|^2 supplied by the caller (what the fused qkv epilogue does in the engine): same result bit for bit
     k = qkv.view(S, 3, H, 64)[:, 1].float()
     k2 = (k * k).sum(-1).amax(0).contiguous()

@@ -96,6 +96,7 @@ def test_gemm_rejects_bad_shapes(dev):
         ops.gemm(a, w, torch.zeros(4, 128, device=dev, dtype=torch.bfloat16))      # K % 64 != 0
 
 
+ATTN_ASM_DEFAULT = 2        # knob attn_asm: 0 compiler-scheduled kernel, 1 hand-placed loop 2 waves / SIMD, 2 hand-placed loop 1 wave / SIMD x 128 rows
 ATTN_NOMAX_DEFAULT = 2      # knob attn_nomax: 0 online-max loop everywhere, 1 a-priori bound on |q| max|k|, 2 optimistic (attn64.hip)
 
 
@@ -653,7 +654,8 @@ def test_attention_optimistic_loop_accepts_rejects_and_reruns(dev, B, S, H, rows
 @pytest.mark.parametrize("B,S,H,spoil", [(1, 4096, 1, 0), (1, 4097, 2, 0), (2, 4160, 3, 0), (1, 4544, 2, 1), (1, 5000, 16, 0),
                                          (3, 4608, 1, 2), (1, 8191, 4, 0), (1, 12345, 2, 1), (1, 4099, 1, 0)])
 def test_attention_hand_placed_loop_equals_the_compiler_kernel_bitwise(dev, B, S, H, spoil):
-    """attn_fwd64a_kernel (generated inline-asm main loop, the default for the eight-wave kernel) against the
+    """attn_fwd64b_kernel (generated inline-asm main loop, one wave per SIMD x 128 rows: the default) and attn_fwd64a_kernel
+    (the same loop on eight waves x 64 rows, knob attn_asm = 1) against the
     compiler-scheduled attn_fwd64_kernel<8> (knob attn_asm = 0): the same arithmetic in the same order, so equal BIT FOR
     BIT - at the shortest sequences the kernel takes (64 tiles), tile counts 0 / 1 / 2 mod 3 (the K ring has three slots)
     and even / odd (the V ring two), full and partial last tiles (1 ... 63 keys), several batches and heads, and with
@@ -672,17 +674,18 @@ def test_attention_hand_placed_loop_equals_the_compiler_kernel_bitwise(dev, B, S
         outs = []
         try:
             lib.set_knob("attn_nomax", nomax)
-            for asm in (1, 0):
+            for asm in (2, 1, 0):        # (form 2 exists for the optimistic form only: under attn_nomax = 1 it is form 1 again)
                 lib.set_knob("attn_asm", asm)
                 o = torch.full((B * S, H * 64), float("nan"), device=dev, dtype=torch.bfloat16)
                 ops.attention(qkv, o, B, S, H)
                 torch.cuda.synchronize()
                 outs.append(o)
         finally:
-            lib.set_knob("attn_asm", 1)
+            lib.set_knob("attn_asm", ATTN_ASM_DEFAULT)
             lib.set_knob("attn_nomax", ATTN_NOMAX_DEFAULT)
         assert torch.isfinite(outs[0].float()).all()
-        assert torch.equal(outs[0], outs[1]), (nomax, int((outs[0] != outs[1]).sum()))
+        assert torch.equal(outs[0], outs[2]), (nomax, int((outs[0] != outs[2]).sum()))
+        assert torch.equal(outs[1], outs[2]), (nomax, int((outs[1] != outs[2]).sum()))
     if spoil != 2 and S <= 8191:
         mx, mean = rel(outs[0], attn_ref(qkv, B, S, H))
         assert mx < 8e-3 and mean < 5e-3, (mx, mean)

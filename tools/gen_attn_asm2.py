@@ -4,6 +4,12 @@ SIMD with the whole 512-register file, the structure the guide's d = 128 kernel 
 FIXED accumulator registers (no operand limit), Q loaded inside the block.
 
     python tools/gen_attn_asm2.py NBLK OUT.inc [bench]
+    python tools/gen_attn_asm2.py 4 pi3_slam_amd/csrc/attn64b_loop.inc product      # the product loop of attn_fwd64b_kernel
+
+`product` (NBLK = 4): O and the row-sum accumulators are "+a" operands (%[o<blk><dt>], %[l<blk>]) carried in from tile 0 and out
+to the last tiles of the C++ side; Q is loaded inside the block into fixed accumulator registers at the top of the file;
+the K / V fragment addresses of d-steps 1..3 / dt 1 are derived from %[ka0] / %[va0] (the swizzles are XORs below the
+128-byte row: LDS base 128-aligned); the loop runs tiles 1 .. nt-4 (count operand) like tools/gen_attn_asm.py's.
 
 `bench`: a timing harness variant (tools/micro/attn_loop_bench.hip): runs the loop on whatever the buffers hold.
 Slot = (tile t, 32-key half kt, 16-key step s2) with G = 4 NBLK MFMA gaps:
@@ -18,6 +24,7 @@ import sys
 NBLK = int(sys.argv[1])
 OUT = sys.argv[2]
 N = NBLK
+PRODUCT = len(sys.argv) > 3 and sys.argv[3] == "product"      # the loop of attn_fwd64b_kernel (attn64.hip): O / row sums are operands
 ABL = set(os.environ.get("A64A_ABL", "").split(","))
 NW = 8 if N == 2 else 4                     # waves per workgroup
 PIECES = 16 // NW                           # 1 KiB LDS-DMA pieces per wave and tile (K and V each: 8 KiB)
@@ -55,6 +62,20 @@ O = [[(blk * 2 + dt) * 16 for dt in range(2)] for blk in range(N)]
 Q = [[32 * N + (blk * 4 + s) * 4 for s in range(4)] for blk in range(N)]
 LACC = [32 * N + 16 * N + 4 * blk for blk in range(N)]
 LASTA = 32 * N + 16 * N + 4 * N - 1
+FIRSTA = 0
+if PRODUCT:
+    FIRSTA = 256 - 16 * N
+    Q = [[FIRSTA + (blk * 4 + s) * 4 for s in range(4)] for blk in range(N)]
+    LASTA = 255
+
+
+def o_reg(blk, dt):
+    return f"%[o{blk}{dt}]" if PRODUCT else ar(O[blk][dt], 16)
+
+
+def l_reg(blk):
+    return f"%[l{blk}]" if PRODUCT else ar(LACC[blk], 4)
+
 S_CNT, S_KG, S_VG, S_TB, S_KDST, S_VDST, S_KD0, S_KD1, S_KD2, S_VDELTA, S_KDELTA, S_TMP = (
     "s60", "s[62:63]", "s[64:65]", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74")
 S_KG_LO, S_KG_HI, S_VG_LO, S_VG_HI = "s62", "s63", "s64", "s65"
@@ -116,7 +137,7 @@ def slot(kt, s2, *, pv=True, qk=True, ex=True, rowsum=True, kaddr_update=False, 
         n = 0
         for blk in range(N):
             for half in range(2):
-                acc = ar(LACC[blk], 4)
+                acc = l_reg(blk)
                 fill[2 * n + 1].append(f"v_mfma_f32_4x4x4_16b_bf16 {acc}, {vr(ONES, 2)}, {vr(prev[blk] + 2 * half, 2)}, {acc}")
                 n += 1
     if qk:
@@ -134,7 +155,7 @@ def slot(kt, s2, *, pv=True, qk=True, ex=True, rowsum=True, kaddr_update=False, 
     mf = []
     for dt in range(2):
         for blk in range(N):
-            o = ar(O[blk][dt], 16)
+            o = o_reg(blk, dt)
             mf.append(f"v_mfma_f32_32x32x16_bf16 {o}, {vr(VF[dt], 4)}, {vr(prev[blk], 4)}, {o}" if pv and "nopv" not in ABL else None)
     for n, s in enumerate(dsteps):
         for blk in range(N):
@@ -208,10 +229,16 @@ def tile_tail():
 
 def entry():
     emit("; ==== entry")
-    for i in range(4):
-        emit(f"v_mov_b32_e32 v{KADDR[i]}, %[ka{i}]")
-    emit(f"v_mov_b32_e32 v{VADDR[0]}, %[va0]")
-    emit(f"v_mov_b32_e32 v{VADDR[1]}, %[va1]")
+    if PRODUCT:
+        for i in range(4):
+            emit(f"v_xor_b32_e32 v{KADDR[i]}, {32 * i}, %[ka0]")
+        emit(f"v_mov_b32_e32 v{VADDR[0]}, %[va0]")
+        emit(f"v_xor_b32_e32 v{VADDR[1]}, 64, %[va0]")
+    else:
+        for i in range(4):
+            emit(f"v_mov_b32_e32 v{KADDR[i]}, %[ka{i}]")
+        emit(f"v_mov_b32_e32 v{VADDR[0]}, %[va0]")
+        emit(f"v_mov_b32_e32 v{VADDR[1]}, %[va1]")
     for i in range(PIECES // 2):
         emit(f"v_add_u32_e32 v{KSRC[i]}, {i}*%[rowstep], %[ksrc]" if False else f"v_mov_b32_e32 v{KSRC[i]}, %[ksrc{i}]")
         emit(f"v_mov_b32_e32 v{VSRC[i]}, %[vsrc{i}]")
@@ -235,9 +262,9 @@ def entry():
     for blk in range(N):
         for s in range(4):
             emit(f"global_load_dwordx4 {ar(Q[blk][s], 4)}, %[qp{blk}], off offset:{32 * s}")
-    for r in range(32 * N):
+    for r in range(0 if PRODUCT else 32 * N):
         emit(f"v_accvgpr_write_b32 a{r}, 0")
-    for blk in range(N):
+    for blk in range(0 if PRODUCT else N):
         for r in range(4):
             emit(f"v_accvgpr_write_b32 a{LACC[blk] + r}, 0")
     for par in range(2):
@@ -270,6 +297,8 @@ def build():
     emit("s_waitcnt lgkmcnt(0)")
     emit("s_nop 7")
     emit("s_nop 7")
+    if PRODUCT:
+        return
     # bench: park one register of every accumulator in the output operand so that the result depends on all the work
     emit(f"v_accvgpr_read_b32 %[out], a{O[0][0]}")
     for blk in range(N):
@@ -288,6 +317,6 @@ with open(OUT, "w") as f:
         f.write('  "' + ln + '\\n\\t" \\\n')
     f.write('  ""\n')
     f.write(f"#define A64B{N}_CLOBBER_V " + ", ".join(f'"v{i}"' for i in range(V0, LASTV + 1)) + "\n")
-    f.write(f"#define A64B{N}_CLOBBER_A " + ", ".join(f'"a{i}"' for i in range(0, LASTA + 1)) + "\n")
+    f.write(f"#define A64B{N}_CLOBBER_A " + ", ".join(f'"a{i}"' for i in range(FIRSTA, LASTA + 1)) + "\n")
     f.write(f"#define A64B{N}_CLOBBER_S " + ", ".join(f'"s{i}"' for i in SCALARS) + "\n")
 print("wrote", OUT, len(lines), "lines; arch v", V0, "..", LASTV, "acc a0 ..", LASTA)

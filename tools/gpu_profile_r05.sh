@@ -14,7 +14,7 @@ for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GR
   timeout -k 10 200 rocprofv3 --kernel-trace --pmc $set -d $OUT/pmca_$tag --output-format csv -- python tools/dev_attn.py > $OUT/pmca_$tag.log 2>&1 || { echo "pmc attn $tag failed"; exit 1; }
   echo "pmc attn $tag done"
 done
-python tools/pmc_summary.py attn_fwd64a 5.0 $OUT/pmca_* > $OUT/attention_pmc.csv 2>&1
+python tools/pmc_summary.py attn_fwd64b 5.0 $OUT/pmca_* > $OUT/attention_pmc.csv 2>&1
 cat $OUT/attention_pmc.csv | cut -c1-200
 tail -c 400 $OUT/prof_bench.json
 find $OUT -name "*kernel_trace.csv" -size +20M -delete

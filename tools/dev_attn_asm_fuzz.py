@@ -11,9 +11,10 @@ cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 g = torch.Generator().manual_seed(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 bad = 0
 for c in range(cases):
-    S = int(torch.randint(4096, 14000, (1,), generator=g))
-    H = int(torch.randint(1, 5, (1,), generator=g))
-    B = int(torch.randint(1, 3, (1,), generator=g))
+    big = c % 10 == 9                      # every tenth case: a long sequence with many heads
+    S = int(torch.randint(20000, 70000, (1,), generator=g)) if big else int(torch.randint(4096, 14000, (1,), generator=g))
+    H = int(torch.randint(8, 17, (1,), generator=g)) if big else int(torch.randint(1, 5, (1,), generator=g))
+    B = 1 if big else int(torch.randint(1, 3, (1,), generator=g))
     spoil = int(torch.randint(0, 4, (1,), generator=g))
     scale = float(torch.rand(1, generator=g)) * 3 + 0.5
     qkv = torch.randn(B * S, 3 * H * 64, device=dev) * 0.6

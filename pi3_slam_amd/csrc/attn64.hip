@@ -224,11 +224,11 @@ __device__ __forceinline__ void a64_softmax(f32x16 (&sc)[2], float& m, f32x16 (&
 // GLDS: stage K/V with LDS-DMA (global_load_lds, swizzle on the source address) instead of registers + ds_write.
 // (the kernel body as a function of the LDS block: attn_fwd64_kernel wraps it; attn_fwd64a_kernel, below, falls back to it)
 template <int NW, bool GLDS = false, bool MSUM = false, bool F16 = false>
-__device__ __forceinline__ void a64_body(const Attn64Params& p, char* lds) {   // lds: K ring [2][64][128 B] then V ring [2][64][128 B]
+__device__ __forceinline__ void a64_body(const Attn64Params& p, char* lds, const int wg) {   // wg: workgroup index (blockIdx.x in the primary launches)   // lds: K ring [2][64][128 B] then V ring [2][64][128 B]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
   const int nwg = p.nqb * p.H * p.B;
-  const int id = xcd_remap(blockIdx.x, nwg);
+  const int id = xcd_remap(wg, nwg);
   const int qb = id % p.nqb;
   const int head = (id / p.nqb) % p.H;
   const int b = id / (p.nqb * p.H);
@@ -545,7 +545,37 @@ __device__ __forceinline__ void a64_body(const Attn64Params& p, char* lds) {   /
 template <int NW, bool GLDS = false, bool MSUM = false, bool F16 = false>
 __global__ __launch_bounds__(NW * 64, (NW == 2 ? 4 : 2)) void attn_fwd64_kernel(Attn64Params p) {
   __shared__ __attribute__((aligned(16))) char lds[32768];
-  a64_body<NW, GLDS, MSUM, F16>(p, lds);
+  a64_body<NW, GLDS, MSUM, F16>(p, lds, blockIdx.x);
+}
+
+// The follow-up launch of the optimistic form (p.redo = 1) on a SMALL grid: workgroup j looks at the marks of the primary
+// launch's workgroups j, j + G, j + 2 G, ... in one batch of loads (thread t: candidate j + t G) and runs the online-max
+// body for the marked ones.  With nothing rejected - the usual case - that is one load per workgroup of a 512-workgroup
+// grid: 5.6 us on average (3.5-4 us at best) in the rocprofv3 trace of the bench where the full grid took 7.5-7.7 us of
+// dependent-load rounds (94 attention calls per chunk: 0.7 -> 0.5 ms); with everything rejected the 512 workgroups keep
+// the card as busy as the full grid would.  G is a multiple of 8, so a
+// candidate stays on the XCD the primary launch ran it on (xcd_remap).  Spills in THIS instance do not matter.
+template <int NW>
+__global__ __launch_bounds__(NW * 64, 2) void attn_redo64_kernel(Attn64Params p) {
+  __shared__ __attribute__((aligned(16))) char lds[32768];
+  __shared__ unsigned char marked[NW * 64];
+  const int nwg = p.nqb * p.H * p.B, G = (int)gridDim.x, tid = threadIdx.x;
+  const int per = (nwg + G - 1) / G;              // <= NW * 64: the launcher sizes the grid
+  bool m = false;
+  if (tid < per) {
+    const int c = (int)blockIdx.x + tid * G;
+    if (c < nwg) {
+      const int id = xcd_remap(c, nwg);
+      m = __builtin_nontemporal_load(a64_mark_ptr(p, id / (p.nqb * p.H), id % p.nqb, (id / p.nqb) % p.H, NW * 64)) == A64_MARK;
+    }
+  }
+  marked[tid] = m;
+  if (!__syncthreads_or(m)) return;
+  for (int t = 0; t < per; ++t)
+    if (marked[t]) {                              // workgroup-uniform
+      a64_body<NW, true, true, false>(p, lds, (int)blockIdx.x + t * G);
+      __syncthreads();                            // the next candidate's staging must not overtake this one's last reads
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -606,7 +636,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd64a_kernel(Attn64Params p) {
   }
   const bool sure = __syncthreads_and(fast) != 0;               // every wave inside the a-priori bound (workgroup-uniform)
   if (!(nt >= 8 && (p.optim || sure))) {
-    a64_body<8, true, true, false>(p, lds);
+    a64_body<8, true, true, false>(p, lds, blockIdx.x);
     return;
   }
 
@@ -1143,7 +1173,16 @@ int pi3_attention64_launch(const void* q, const void* k, const void* v, long tok
   launch(use_asm);
   if (p.optim) {        // the follow-up launch: workgroups that rejected the bounded-score loop run the online-max loop (a64_reject)
     p.redo = 1;
-    launch(false);
+    if (glds && msum && (nw == 8 || nw == 4)) {
+      const long threads = nw * 64;
+      long grid = nwg < 512 ? nwg : 512;
+      const long need = (nwg + threads - 1) / threads;          // at most one candidate per thread
+      if (grid < need) grid = (need + 7) / 8 * 8;
+      if (nw == 8) hipLaunchKernelGGL(attn_redo64_kernel<8>, dim3((unsigned)grid), dim3(512), 0, stream, p);
+      else hipLaunchKernelGGL(attn_redo64_kernel<4>, dim3((unsigned)grid), dim3(256), 0, stream, p);
+    } else {
+      launch(false);
+    }
   }
 #ifdef PI3_ATTN_STAMPS
   {
